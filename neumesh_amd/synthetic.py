@@ -1,0 +1,95 @@
+"""Synthetic scenes for benchmarking and parity tests (numpy only, no device code).
+
+There is no DTU / NeRF-synthetic data, checkpoint or prior-mesh ``.ply`` in the build
+environment, so "DTU scan63" in BASELINE.json is honoured in *shape* only (SURVEY.md section 8d,
+scene **S-DTU**): a Fibonacci-sphere mesh with V ~ 1.4e5 vertices at the vertex spacing of a
+256^3 marching-cubes mesh (reference: extract_mesh.py:40-45,139), 32-d N(0,1) geometry /
+colour codes (reference: models/frameworks/neumesh/neumesh.py:47-52), indicator vectors =
+normals + noise, a pin-hole camera looking at the origin.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+
+@dataclass
+class SyntheticMesh:
+    vertices: np.ndarray        # [V,3] float32
+    vertex_normals: np.ndarray  # [V,3] float32 (analytic, unit)
+
+    @property
+    def num_vertices(self) -> int:
+        return int(self.vertices.shape[0])
+
+
+def fibonacci_blob(V: int = 140_000, radius: float = 0.75, bump: float = 0.05) -> SyntheticMesh:
+    """Vertices on r(theta,phi) = radius + bump*sin(7 theta)*cos(5 phi), Fibonacci-spiral sampled."""
+    i = np.arange(V, dtype=np.float64) + 0.5
+    z = 1.0 - 2.0 * i / V
+    theta = np.arccos(np.clip(z, -1.0, 1.0))
+    phi = (np.pi * (1.0 + 5.0 ** 0.5) * i) % (2.0 * np.pi)
+    st, ct, sp, cp = np.sin(theta), np.cos(theta), np.sin(phi), np.cos(phi)
+    r = radius + bump * np.sin(7.0 * theta) * np.cos(5.0 * phi)
+    rhat = np.stack([st * cp, st * sp, ct], -1)
+    that = np.stack([ct * cp, ct * sp, -st], -1)
+    phat = np.stack([-sp, cp, np.zeros_like(sp)], -1)
+    dr_dt = bump * 7.0 * np.cos(7.0 * theta) * np.cos(5.0 * phi)
+    dr_dp = -bump * 5.0 * np.sin(7.0 * theta) * np.sin(5.0 * phi)
+    n = rhat - (dr_dt / r)[:, None] * that - (dr_dp / (r * np.maximum(st, 1e-6)))[:, None] * phat
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    return SyntheticMesh((rhat * r[:, None]).astype(np.float32), n.astype(np.float32))
+
+
+def random_codes(V: int, dim: int, seed: int) -> np.ndarray:
+    return np.random.default_rng(seed).standard_normal((V, dim)).astype(np.float32)
+
+
+def noisy_indicator(normals: np.ndarray, seed: int = 3, sigma: float = 0.1) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    return (normals + sigma * rng.standard_normal(normals.shape)).astype(np.float32)
+
+
+def look_at_pose(cam_loc, target=(0.0, 0.0, 0.0), up=(0.0, 0.0, 1.0)) -> np.ndarray:
+    """OpenCV-convention camera-to-world 4x4 (x right, y down, z forward)."""
+    cam_loc = np.asarray(cam_loc, np.float64)
+    fwd = np.asarray(target, np.float64) - cam_loc
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, np.asarray(up, np.float64))
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    c2w = np.eye(4)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, cam_loc
+    return c2w.astype(np.float32)
+
+
+def orbit_pose(frame: int = 0, n_frames: int = 90, radius: float = 2.2, elevation: float = 0.35) -> np.ndarray:
+    a = 2.0 * np.pi * frame / n_frames
+    loc = radius * np.array([np.cos(a) * np.cos(elevation), np.sin(a) * np.cos(elevation), np.sin(elevation)])
+    return look_at_pose(loc)
+
+
+def pinhole_intrinsics(H: int, W: int, focal_scale: float = 1.2) -> np.ndarray:
+    K = np.eye(4, dtype=np.float32)
+    K[0, 0] = K[1, 1] = focal_scale * W
+    K[0, 2], K[1, 2] = W / 2.0, H / 2.0
+    return K
+
+
+def camera_rays(c2w: np.ndarray, intrinsics: np.ndarray, H: int, W: int, start: int = 0, count: int = -1):
+    """Rays of pixels [start, start+count) in row-major order, the convention of the reference's
+    utils/rend_util.py:123-176 (pose-matrix branch, N_rays=-1): pixel (i=col, j=row) is lifted
+    to z=1, normalised, rotated by c2w[:3,:3]; origin = c2w[:3,3]."""
+    n = H * W if count < 0 else count
+    pix = np.arange(start, start + n)
+    i = (pix % W).astype(np.float32)
+    j = (pix // W).astype(np.float32)
+    fx, fy, cx, cy, sk = intrinsics[0, 0], intrinsics[1, 1], intrinsics[0, 2], intrinsics[1, 2], intrinsics[0, 1]
+    y = (j - cy) / fy
+    x = (i - cx - sk * y) / fx
+    d = np.stack([x, y, np.ones_like(x)], -1).astype(np.float32)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    d = (d @ c2w[:3, :3].T).astype(np.float32)
+    o = np.broadcast_to(c2w[:3, 3].astype(np.float32), d.shape).copy()
+    return o, d

@@ -1,0 +1,210 @@
+"""oracle/gen_golden.py -- TEST INFRASTRUCTURE ONLY.  Run in the build container:
+
+    python -m oracle.gen_golden            # writes tests/golden/*.npz and prints a report
+
+What it does
+------------
+1. Imports the REAL reference (/root/reference, read-only) through oracle/refimport and builds
+   its NeuMesh model + SingleRenderer on seeded synthetic meshes via the reference's own
+   `build_framework` (FRNN replaced by the declared-arithmetic oracle K-NN -- FRNN is an
+   external CUDA package that is not part of /root/reference).
+2. Runs the reference's own methods (compute_distance / forward_density_only /
+   forward_with_nablas / forward / renderer) on seeded inputs.
+3. Runs the numpy restatement in oracle/ on the same inputs and REQUIRES agreement
+   (tolerances below) -- this is what pins the oracle to the reference.
+4. Stores the REFERENCE's outputs as fixtures under tests/golden/ (they travel to the GPU box;
+   /root/reference does not).
+
+The fixtures are regenerated only by hand; tests never call this script.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+
+_REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _REPO not in sys.path:
+    sys.path.insert(0, _REPO)
+
+from neumesh_amd import synthetic  # noqa: E402
+from oracle import compare  # noqa: E402
+from oracle import field as ofield  # noqa: E402
+from oracle import render as orender  # noqa: E402
+from oracle.refimport import harness  # noqa: E402
+
+GOLDEN = os.path.join(_REPO, "tests", "golden")
+REPORT = {}
+
+
+def _check(name, got, want, atol, rtol=0.0, per_point_tol=None):
+    """per_point_tol: optional array broadcastable to `want` added to atol element-wise."""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    diff = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    err = float(np.max(diff)) if got.size else 0.0
+    scale = float(np.max(np.abs(want))) if want.size else 0.0
+    tol = atol + rtol * scale + (0.0 if per_point_tol is None else per_point_tol)
+    ok = bool(np.all(diff <= tol))
+    REPORT[name] = {"max_abs_err": err, "scale": scale, "atol": atol, "ok": bool(ok)}
+    print(f"  {'OK ' if ok else 'BAD'} {name:34s} max|d|={err:.3e} (scale {scale:.3e}, atol {atol:.1e})")
+    assert ok, name
+
+
+def query_points(mesh, n, seed):
+    """Near-surface, mid-range, far / outside-bbox points + points exactly on vertices."""
+    rng = np.random.default_rng(seed)
+    V = mesh.num_vertices
+    a = mesh.vertices[rng.integers(0, V, n // 2)] + 0.01 * rng.standard_normal((n // 2, 3))
+    b = mesh.vertices[rng.integers(0, V, n // 4)] + 0.15 * rng.standard_normal((n // 4, 3))
+    c = rng.uniform(-2.5, 2.5, (n - n // 2 - n // 4 - 16, 3))
+    d = mesh.vertices[rng.integers(0, V, 16)]
+    return np.concatenate([a, b, c, d]).astype(np.float32)
+
+
+def oracle_from_reference(model, mesh):
+    import torch  # noqa: F401
+    cfg = ofield.FieldConfig(speed_factor=float(model.speed_factor),
+                             learn_indicator_weight=bool(model.learn_indicator_weight),
+                             enable_nablas_input=bool(model.enable_nablas_input))
+    return ofield.OracleField(mesh.vertices, {k: v for k, v in model.state_dict().items()}, cfg)
+
+
+def gen_field_fixture(tag, V, Q, seed, dup=0):
+    import torch
+    print(f"[{tag}] V={V} Q={Q}")
+    mesh = synthetic.fibonacci_blob(V)
+    if dup:  # duplicated vertices -> exact distance ties, resolved by vertex index
+        mesh = synthetic.SyntheticMesh(np.concatenate([mesh.vertices, mesh.vertices[:dup]]),
+                                       np.concatenate([mesh.vertex_normals, mesh.vertex_normals[:dup]]))
+    model, kw, renderer, _ = harness.build_reference(mesh, seed=0)
+    orc = oracle_from_reference(model, mesh)
+    q = query_points(mesh, Q, seed)
+    dirs = orender.normalize(np.random.default_rng(seed + 1).standard_normal((Q, 3)).astype(np.float32))
+    tq = torch.from_numpy(q)
+    with torch.no_grad():
+        r_ds, r_idx, r_w = model.compute_distance(tq)
+        r_sdf0 = model.forward_density_only(tq)
+    r_sdf, r_nab = model.forward_with_nablas(tq.clone())
+    r_sdf2, r_rgb, r_ds2, r_idx2, r_w2 = model.forward(tq.clone(), torch.from_numpy(dirs), return_ds=True)
+    r_col = model.forward_color(r_ds2.detach(), torch.from_numpy(dirs), model.color_features,
+                                r_idx2, r_w2.detach(), r_nab.detach())
+    ref = dict(ds=r_ds, idx=r_idx, w=r_w, sdf=r_sdf0, sdf_wn=r_sdf, nabla=r_nab, rgb=r_rgb, rgb_fc=r_col)
+    ref = {k: v.detach().numpy() for k, v in ref.items()}
+    # --- oracle restatement vs the reference's own code
+    o_ds, o_idx, o_w, o_g = orc.compute_distance(q, want_grad=True)
+    assert np.array_equal(o_idx, ref["idx"]), "kNN indices differ (same declared arithmetic!)"
+    _check(f"{tag}.ds", o_ds, ref["ds"], 2e-6)
+    _check(f"{tag}.w", o_w, ref["w"], 2e-6)
+    o_sdf, o_nab = orc.forward_with_nablas(q)
+    _check(f"{tag}.sdf", o_sdf, ref["sdf"], 5e-6)
+    _check(f"{tag}.sdf(with_nablas)", o_sdf, ref["sdf_wn"], 5e-6)
+    # fp32 sensitivity: the d-embedding carries sin/cos(2^7 * ds), so a 1-ulp change of ds moves
+    # d sdf/d ds by ~128*ulp(ds)*|.|: tolerance grows with |ds| (render samples have |ds| < ~0.2)
+    _check(f"{tag}.nabla(closed form vs autograd)", o_nab, ref["nabla"], 5e-6,
+           per_point_tol=2e-4 * np.abs(ref["ds"]))
+    o_sdf2, o_rgb, _ = orc.forward(q, dirs)
+    _check(f"{tag}.rgb", o_rgb, ref["rgb"], 5e-6)
+    _check(f"{tag}.rgb(forward_color)", o_rgb, ref["rgb_fc"], 5e-6)
+    np.savez_compressed(
+        os.path.join(GOLDEN, f"{tag}.npz"),
+        V=np.int64(V), dup=np.int64(dup), q=q, dirs=dirs,
+        idx=ref["idx"].astype(np.int32), d2=orc.knn(q)[1],
+        ds=ref["ds"], w=ref["w"], dds_dx=o_g, sdf=ref["sdf"], nabla=ref["nabla"], rgb=ref["rgb"],
+        s=np.float32(model.forward_s().item()),
+    )
+    return model
+
+
+def gen_render_fixture(tag, V, H, W, frame, seed=0, white_bkgd=False, n_samples=64):
+    import torch
+    print(f"[{tag}] V={V} rays={H * W}")
+    mesh = synthetic.fibonacci_blob(V)
+    model, kw, renderer, _ = harness.build_reference(mesh, seed=seed)
+    orc = oracle_from_reference(model, mesh)
+    # a patch of a larger virtual image so that the rays actually graze / hit / miss the object
+    big = 48
+    c2w, Kmat = synthetic.orbit_pose(frame), synthetic.pinhole_intrinsics(big, big, 1.0)
+    o_all, d_all_ = synthetic.camera_rays(c2w, Kmat, big, big)
+    rows = np.arange(big // 2 - H // 2, big // 2 + H - H // 2)
+    cols = np.arange(0, W * 4, 4) % big  # strided columns: centre hits, borders miss
+    sel = (rows[:, None] * big + cols[None, :]).reshape(-1)
+    rays_o, rays_d = o_all[sel], d_all_[sel] * np.float32(1.7)  # un-normalised on purpose (renderer.py:153)
+    kw = dict(kw)
+    kw.update(rayschunk=rays_o.shape[0], white_bkgd=white_bkgd, N_samples=n_samples, N_importance=n_samples)
+    # the reference does not return d_all; record the points it hands to forward_with_nablas
+    # (renderer.py:271-272) and recover d = (p - o) . dir  (exact to ~1e-7, tolerance 2e-6 below)
+    seen = {}
+    orig_fwn = model.forward_with_nablas
+
+    def spy(xyz):
+        seen["pts"] = xyz.detach().clone()
+        return orig_fwn(xyz)
+
+    model.forward_with_nablas = spy
+    with torch.no_grad():
+        rgb, depth, ex = renderer(torch.from_numpy(rays_o)[None], torch.from_numpy(rays_d)[None],
+                                  detailed_output=True, **kw)
+    model.forward_with_nablas = orig_fwn
+    ref = {k: v[0].detach().numpy() for k, v in ex.items()}
+    dirn = orender.normalize(rays_d)
+    pts = seen["pts"].numpy().reshape(rays_o.shape[0], -1, 3).astype(np.float64)
+    ref_d_all = np.sum((pts - rays_o[:, None, :]) * dirn[:, None, :], axis=-1)
+    cfg = orender.RenderConfig(white_bkgd=white_bkgd, calc_normal=bool(kw.get("calc_normal", False)),
+                               N_samples=n_samples, N_importance=n_samples)
+    out = orender.render_rays(orc, rays_o, rays_d, cfg, detailed=True)
+    # per-sample arrays: compared as sets / matched by depth (see oracle/compare.py for why)
+    worst, far_frac = compare.depth_set_distance(out["d_all"], ref_d_all)
+    print(f"    d_all set distance: max {worst:.3e}; samples without a partner within 2e-6: {100 * far_frac:.2f} %")
+    REPORT[f"{tag}.d_all"] = {"set_distance_max": worst, "unmatched_fraction": far_frac}
+    assert far_frac < 0.10 and worst < 5e-3
+    ref_pts = seen["pts"].numpy().reshape(rays_o.shape[0], -1, 3)
+    o_pts = (rays_o[:, None, :] + dirn[:, None, :] * out["d_all"][..., None]).astype(np.float32)
+    for name, atol in (("implicit_surface", 2e-6), ("implicit_nablas", 2e-5)):
+        if name in ref:
+            e, frac = compare.max_err_on_identical_points(o_pts, out[name], ref_pts, ref[name])
+            _check(f"{tag}.{name}(identical pts {100 * frac:.0f}%)", np.float32(e), np.float32(0.0), atol)
+            assert frac > 0.8
+    _check(f"{tag}.rgb", out["rgb"], ref["rgb"], 1e-4)
+    _check(f"{tag}.depth_volume", out["depth_volume"], ref["depth_volume"], 1e-4)
+    _check(f"{tag}.mask_volume", out["mask_volume"], ref["mask_volume"], 1e-4)
+    if cfg.calc_normal:
+        _check(f"{tag}.normals_volume", out["normals_volume"], ref["normals_volume"], 1e-4)
+    acc = ref["mask_volume"]
+    print(f"    acc: min {acc.min():.3f} mean {acc.mean():.3f} max {acc.max():.3f}; "
+          f"rays on fallback near/far: {int(np.sum(out['near'] == out['near_sphere']))}")
+    np.savez_compressed(
+        os.path.join(GOLDEN, f"{tag}.npz"),
+        V=np.int64(V), rays_o=rays_o, rays_d=rays_d, white_bkgd=np.bool_(white_bkgd),
+        N_samples=np.int64(n_samples), calc_normal=np.bool_(cfg.calc_normal),
+        near=out["near"], far=out["far"],            # oracle (reference does not expose them)
+        d_all=ref_d_all.astype(np.float32),           # reference (recovered from its query points)
+        d_coarse=out["d_coarse"], sdf_coarse=out["sdf_coarse"],  # oracle: input of the up-sampling test
+        d_final=ref["d_final"], implicit_surface=ref["implicit_surface"], alpha=ref["alpha"],
+        radiance=ref["radiance"], visibility_weights=ref["visibility_weights"],
+        rgb=ref["rgb"], depth_volume=ref["depth_volume"], mask_volume=ref["mask_volume"],
+        normals_volume=ref.get("normals_volume", np.zeros((0, 3), np.float32)),
+        implicit_nablas=ref.get("implicit_nablas", np.zeros((0, 3), np.float32)),
+    )
+    return model
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    model = gen_field_fixture("field_v3000", V=3000, Q=2048, seed=11)
+    # one weights file shared by every fixture (reference ctor, torch.manual_seed(0))
+    sd = {k: v.detach().numpy() for k, v in model.state_dict().items()
+          if k not in ("geometry_features", "color_features", "indicator_vector")}
+    np.savez_compressed(os.path.join(GOLDEN, "model_seed0.npz"), **sd)
+    gen_field_fixture("field_dup_v1200", V=1200, Q=512, seed=12, dup=64)
+    gen_render_fixture("render_v3000_dtu", V=3000, H=6, W=12, frame=3)
+    gen_render_fixture("render_v3000_lego", V=3000, H=4, W=12, frame=17, white_bkgd=True, n_samples=32)
+    with open(os.path.join(GOLDEN, "REPORT.json"), "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+    print("all oracle-vs-reference checks passed; fixtures written to", GOLDEN)
+
+
+if __name__ == "__main__":
+    main()

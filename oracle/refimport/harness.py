@@ -1,0 +1,69 @@
+"""oracle/refimport/harness.py -- TEST INFRASTRUCTURE ONLY (build container only).
+
+Imports the real reference (/root/reference, read-only, 100 % Python) behind the stub modules
+in ./stubs and builds its NeuMesh model + renderer on a synthetic mesh, exactly through the
+reference's own entry point `build_framework(args, "NeuMesh")`
+(models/frameworks/__init__.py:1-8 -> models/frameworks/neumesh/__init__.py:10-97).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+REFERENCE_ROOT = os.environ.get("NEUMESH_REFERENCE_ROOT", "/root/reference")
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(os.path.dirname(_HERE))
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "models", "frameworks", "neumesh"))
+
+
+def _activate():
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
+    for p in (REFERENCE_ROOT, os.path.join(_HERE, "stubs"), _REPO):
+        if p in sys.path:
+            sys.path.remove(p)
+    # stubs first, then the reference (its packages are `models`, `utils`, `dataio`), then the repo
+    sys.path[:0] = [os.path.join(_HERE, "stubs"), REFERENCE_ROOT, _REPO]
+
+
+def build_reference(mesh, seed: int = 0, s_value: float = 200.0, geometry_seed: int = 1,
+                    color_seed: int = 2, indicator_seed: int = 3, overrides=None):
+    """Returns (model, render_kwargs_test, renderer, args) built by the reference's own factory.
+
+    mesh: neumesh_amd.synthetic.SyntheticMesh.  Weights: torch default init under
+    manual_seed(seed) via the reference constructor; codes / indicator vectors re-seeded with
+    numpy so that the product (which never sees the reference) can build the same scene."""
+    _activate()
+    import numpy as np
+    import torch
+    import yaml
+    import open3d as o3d_stub          # the stub
+    from utils.io_util import ForceKeyErrorDict  # reference
+    from models.frameworks import build_framework  # reference
+    from neumesh_amd import synthetic
+
+    with open(os.path.join(REFERENCE_ROOT, "configs", "neumesh_dtu_scan63.yaml")) as f:
+        cfg = yaml.safe_load(f)
+    key = f"synthetic-mesh-{id(mesh)}"
+    o3d_stub.register_mesh(key, mesh.vertices, mesh.vertex_normals)
+    cfg["model"]["prior_mesh"] = key
+    cfg["training"]["teacher_ckpt"] = None
+    cfg["training"]["teacher_config"] = None
+    cfg["device_ids"] = ["cpu"]
+    for k, v in (overrides or {}).items():
+        a, b = k.split(":")
+        cfg[a][b] = v
+    args = ForceKeyErrorDict(**cfg)
+    torch.manual_seed(seed)
+    model, _trainer, _kw_train, kw_test, renderer = build_framework(args, "NeuMesh")
+    V = mesh.num_vertices
+    with torch.no_grad():
+        model.geometry_features.copy_(torch.from_numpy(synthetic.random_codes(V, model.geometry_features.shape[1], geometry_seed)))
+        model.color_features.copy_(torch.from_numpy(synthetic.random_codes(V, model.color_features.shape[1], color_seed)))
+        model.indicator_vector.copy_(torch.from_numpy(synthetic.noisy_indicator(mesh.vertex_normals, indicator_seed)))
+        model.ln_s.fill_(float(np.log(s_value) / model.speed_factor))
+    model.eval()
+    return model, kw_test, renderer, args
