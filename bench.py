@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the NeuMesh volumetric-render hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], shape only -- there is no DTU data / checkpoint in the
+environment, SURVEY.md section 8d scene S-DTU): V = 140 000-vertex prior mesh, 32-d geometry /
+colour codes, W=256 MLPs at default init, s = 200; one STEP = one 800x800 frame = 640 000 rays x
+(64 coarse + 64 importance) samples with bounded near/far (256 probes/ray) and normals, i.e. the
+kwargs get_model() hands render.py for configs/neumesh_dtu_scan63.yaml.  Rays are resident in HBM
+before the timed region.  With N GPUs every rank renders its own frame of the orbit per step
+(weak scaling: per-GPU work is fixed) and the final pixels are all-gathered over RCCL -- the only
+collective of the path.
+
+Prints ONE JSON line (rank 0): value = rays/s of the whole job; `roofline` = the dominant kernel
+(measured live with HIP events on the launch stream inside the timed region) against the fp32
+MFMA peak; `cpu_baseline` = the CPU oracle (numpy + kd-tree K-NN) on a bounded ray sample of the
+same frame (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_GEO = 353_280          # geometry MLP forward, per point
+FLOP_TANGENT = 271_360      # + forward-mode tangent (nabla)
+FLOP_COL = 500_736          # colour MLP
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+KNN_BYTES_PER_QUERY = 76    # 12 in + 8*4 idx + 8*4 w  
+
+MODEL_CFG = dict(D_density=3, D_color=4, W=256, geometry_dim=32, color_dim=32, multires_view=4, multires_d=8,
+                 multires_fg=2, multires_ft=2, enable_nablas_input=True, speed_factor=10.0, learn_indicator_weight=False)
+
+
+class _Mesh:
+    def __init__(self, m):
+        self.vertices, self.vertex_normals = m.vertices.astype(np.float64), m.vertex_normals.astype(np.float64)
+
+    def compute_vertex_normals(self):
+        return self
+
+
+def build_scene(V, device, seed=0, s_value=200.0):
+    import torch
+    from neumesh_amd import MeshGrid, NeuMesh, synthetic
+    mesh = synthetic.fibonacci_blob(V)
+    torch.manual_seed(seed)
+    model = NeuMesh(MeshGrid(_Mesh(mesh), device), **MODEL_CFG)
+    with torch.no_grad():
+        model.geometry_features.copy_(torch.from_numpy(synthetic.random_codes(V, 32, 1)))
+        model.color_features.copy_(torch.from_numpy(synthetic.random_codes(V, 32, 2)))
+        model.indicator_vector.copy_(torch.from_numpy(synthetic.noisy_indicator(mesh.vertex_normals, 3)))
+        model.ln_s.fill_(float(np.log(s_value) / MODEL_CFG["speed_factor"]))
+    return mesh, model.to(device).eval()
+
+
+def frame_rays(frame, H, W):
+    from neumesh_amd import synthetic
+    return synthetic.camera_rays(synthetic.orbit_pose(frame), synthetic.pinhole_intrinsics(H, W), H, W)
+
+
+def cpu_baseline(mesh, model, H, W, n_rays, gpu_rgb_frame0):
+    """Oracle (CPU restatement of the reference) on a strided sample of frame 0's rays."""
+    from oracle import compare, field as ofield, knn as oknn, render as orender
+    state = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    orc = ofield.OracleField(mesh.vertices, state, ofield.FieldConfig(speed_factor=MODEL_CFG["speed_factor"]))
+    from scipy.spatial import cKDTree
+    tree = cKDTree(mesh.vertices.astype(np.float64))
+    orc.knn_fn = lambda q, v, K: oknn.knn_kdtree(q, v, K, tree=tree)
+    o, d = frame_rays(0, H, W)
+    sel = np.linspace(0, H * W - 1, n_rays).astype(np.int64)
+    cfg = orender.RenderConfig(calc_normal=True)
+    orender.render_rays(orc, o[sel[:8]], d[sel[:8]], cfg)  # warm caches / thread pools
+    t = time.perf_counter()
+    out = orender.render_rays(orc, o[sel], d[sel], cfg)
+    dt = time.perf_counter() - t
+    res = {"value": n_rays / dt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+           "sample": f"{n_rays} rays strided over frame 0 of the same 800x800x128 workload, {dt:.1f} s; numpy fp32 oracle + "
+                     f"scipy cKDTree candidates re-ranked with the declared fp32 arithmetic (BLAS/OpenMP threads = all cores)"}
+    parity = None
+    if gpu_rgb_frame0 is not None:
+        g = gpu_rgb_frame0[sel]
+        parity = {"psnr_db": compare.psnr(g, out["rgb"]), "max_abs_rgb": float(np.abs(g - out["rgb"]).max()), "rays": int(n_rays)}
+    return res, parity
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--H", type=int, default=800)
+    ap.add_argument("--W", type=int, default=800)
+    ap.add_argument("--V", type=int, default=140_000)
+    ap.add_argument("--rayschunk", type=int, default=65536)
+    ap.add_argument("--cpu-rays", type=int, default=384, help="rays of the CPU-baseline sample (0 disables)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from neumesh_amd import _lib
+    from neumesh_amd.renderer import make_render_cfg, render_rays_fused
+    from neumesh_amd.sharded import pack_outputs
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    lib = _lib.load()
+
+    mesh, model = build_scene(args.V, dev)
+    cfg = make_render_cfg(calc_normal=True)
+    n_rays = args.H * args.W
+    total_steps = args.warmup + args.steps
+    rays = []
+    for s in range(total_steps):  # every rank renders its own frame of the orbit: inputs resident before timing
+        o, d = frame_rays(s * world + rank, args.H, args.W)
+        rays.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)))
+    tables = model.field_tables()
+    model.field_handle()
+    gathered = torch.empty((world * n_rays, 8), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step(i):
+        ret = render_rays_fused(model, rays[i][0], rays[i][1], cfg, args.rayschunk, tables=tables)
+        if world > 1:
+            packed, _ = pack_outputs(ret)
+            dist.all_gather_into_tensor(gathered, packed)   # the path's only collective: final pixels
+        return ret
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    rgb0 = None
+    for i in range(args.warmup):
+        ret = step(i)
+        if i == 0 and rank == 0:
+            rgb0 = ret["rgb"].cpu().numpy()
+    if args.warmup == 0 and rank == 0 and args.cpu_rays > 0 and world == 1:
+        rgb0 = None
+    fence()
+    lib.nm_profile_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total_steps):
+        ret = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel time inside the timed region (HIP events on the launch stream)
+    kinds = {0: ("knn_distance", None), 1: ("geo_mlp", FLOP_GEO), 2: ("geo_mlp_tangent", FLOP_GEO + FLOP_TANGENT), 3: ("color_mlp", FLOP_COL)}
+    prof = {}
+    for k, (name, flop) in kinds.items():
+        ms, n, u = C.c_double(), C.c_int64(), C.c_int64()
+        _lib.check(lib.nm_profile_read(k, C.byref(ms), C.byref(n), C.byref(u)), "nm_profile_read")
+        prof[name] = {"ms": ms.value, "launches": n.value, "points": u.value, "flop_per_point": flop}
+    lib.nm_profile_enable(0)
+
+    if rank == 0:
+        rays_total = world * n_rays * args.steps
+        value = rays_total / elapsed
+        dom = max(("geo_mlp", "geo_mlp_tangent", "color_mlp"), key=lambda k: prof[k]["ms"])
+        p = prof[dom]
+        achieved = p["points"] * p["flop_per_point"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
+        mlp_flop = sum(prof[k]["points"] * prof[k]["flop_per_point"] for k in ("geo_mlp", "geo_mlp_tangent", "color_mlp"))
+        mlp_ms = sum(prof[k]["ms"] for k in ("geo_mlp", "geo_mlp_tangent", "color_mlp"))
+        kd = prof["knn_distance"]
+        out = {
+            "metric": "rays/sec at 800x800x128 samples (DTU scan63 shape, synthetic scene S-DTU)",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_frame": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"S-DTU V={args.V} {args.H}x{args.W} rays/frame/GPU, 64+64 samples, bounded_near_far (256 probes), "
+                                   f"calc_normal, 639 K-NN queries + 383 geometry-MLP + 127 colour-MLP evals per ray",
+                       "rayschunk": args.rayschunk, "parallelism": f"rays sharded: {world} GPU(s) x 1 frame per step, 1 all-gather of pixels"},
+            "roofline": {"bound": "mfma", "kernel": {"geo_mlp": "nm_geo_mlp_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_kernel<true>",
+                                                     "color_mlp": "nm_col_mlp_kernel"}[dom],
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": None, "avg_launch_ms": p["ms"] / max(p["launches"], 1), "launches": p["launches"],
+                         "all_mlp_kernels_tflops": mlp_flop / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0,
+                         "share_of_step_time": {k: prof[k]["ms"] / (elapsed * 1e3) for k in prof},
+                         "knn_kernel": {"queries_per_s": kd["points"] / (kd["ms"] * 1e-3) if kd["ms"] > 0 else 0.0,
+                                        "algorithmic_GBs": kd["points"] * KNN_BYTES_PER_QUERY / (kd["ms"] * 1e-3) / 1e9 if kd["ms"] > 0 else 0.0,
+                                        "hbm_frac": (kd["points"] * KNN_BYTES_PER_QUERY / (kd["ms"] * 1e-3) / 1e9) / PEAK_HBM_GBS if kd["ms"] > 0 else 0.0}},
+        }
+        if world == 1 and args.cpu_rays > 0:
+            try:
+                base, parity = cpu_baseline(mesh, model, args.H, args.W, args.cpu_rays, rgb0)
+                out["cpu_baseline"] = base
+                if parity:
+                    out["parity_vs_oracle"] = parity
+                out["speedup_vs_cpu_baseline"] = value / base["value"]
+            except Exception as e:  # the baseline must never sink the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,188 @@
+/*
+ * neumesh_hip.h -- C ABI of libneumesh_hip.so (gfx950 / MI355X), the drop-in boundary of the
+ * NeuMesh volumetric-render hot path.
+ *
+ * Conventions
+ *   - every pointer marked "device" is a HIP device pointer owned by the CALLER (PyTorch
+ *     allocates); the library borrows it for the duration of the call's stream work and never
+ *     frees it.  The library owns only what its handles hold (nm_grid_t, nm_field_t).
+ *   - every entry point that launches work takes an explicit stream (hipStream_t passed as
+ *     void*), enqueues asynchronously and does NOT synchronise (exception: nm_grid_create and
+ *     nm_field_create/update, one-off setup calls, which synchronise the stream).
+ *   - return value: 0 = ok, non-zero = error; nm_last_error() gives a thread-local message.
+ *   - all floating point is IEEE fp32; K-NN indices are int64 at this boundary because the
+ *     reference indexes tensors with them (models/mesh_grid.py:126,134-136;
+ *     editing/texture_neumesh/texture_neumesh.py:85).
+ *
+ * Reference interfaces replaced (file:line relative to the NeuMesh reference tree):
+ *   nm_grid_create        frnn.frnn_grid_points(..., grid=None)  models/mesh_grid.py:64-74
+ *   nm_knn                frnn.frnn_grid_points(..., grid=g)     models/mesh_grid.py:109-119
+ *   nm_compute_distance   MeshGrid.compute_distance_frnn         models/mesh_grid.py:88-144
+ *   nm_field_density      NeuMesh.forward_density_only / forward_with_nablas
+ *                                                 models/frameworks/neumesh/neumesh.py:140-154
+ *   nm_field_forward      NeuMesh.forward                        neumesh.py:113-138
+ *   nm_field_color        NeuMesh.forward_color                  neumesh.py:156-168
+ *   nm_render_rays        volume_render -> render_rayschunk      models/renderer.py:105-368
+ */
+#ifndef NEUMESH_HIP_H
+#define NEUMESH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NM_ABI_VERSION 1
+#define NM_MAX_K 32
+
+typedef struct nm_grid_s* nm_grid_t;    /* spatial index over the mesh vertices */
+typedef struct nm_field_s* nm_field_t;  /* packed MLP weights + borrowed code tables */
+typedef void* nm_stream_t;              /* hipStream_t */
+
+int nm_abi_version(void);
+const char* nm_last_error(void);
+/* number of HIP devices visible to the library (0 => every compute entry point fails) */
+int nm_device_count(void);
+
+/* ----------------------------------------------------------------------------- spatial index
+ * Builds the search structure over `V` vertices (device, [V,3] fp32, row-major).
+ * leaf_level = 0 picks the octree depth automatically (about 8-12 vertices per occupied
+ * leaf).  The vertex data is COPIED (sorted copy lives in the handle); `verts` may be
+ * freed afterwards.  One-off call: copies to the host, builds, uploads, synchronises. */
+int nm_grid_create(const float* verts_device, int64_t V, int leaf_level, nm_stream_t stream,
+                   nm_grid_t* out);
+int nm_grid_destroy(nm_grid_t g);
+
+typedef struct nm_grid_info {
+    int64_t num_vertices;
+    int32_t leaf_level;         /* octree depth L: 2^L cells per axis */
+    int32_t occupied_leaves;
+    float origin[3];            /* min corner of the root cube */
+    float root_size;            /* edge of the root cube */
+    int64_t device_bytes;       /* memory held by the handle */
+} nm_grid_info;
+int nm_grid_get_info(nm_grid_t g, nm_grid_info* out);
+
+/* Exact K nearest vertices of each query (device [Q,3]) under the declared arithmetic
+ * (fp32, dx=q-v, d2=(dx*dx+dy*dy)+dz*dz, no FMA, ascending (d2, index)).
+ * idx: device [Q,K] int64, d2: device [Q,K] fp32 (squared distances, like FRNN).
+ * If V < K the missing slots are idx=-1, d2=-1 (FRNN's padding). 1 <= K <= NM_MAX_K. */
+int nm_knn(nm_grid_t g, const float* q_device, int64_t Q, int K, int64_t* idx_device,
+           float* d2_device, nm_stream_t stream);
+
+/* Fused K-NN + inverse-distance weights + indicator-blended projected signed distance.
+ * indicator: device [V,3]; w1: indicator weight (0.1 or sigmoid(indicator_weight_raw)).
+ * Outputs (each may be NULL to skip): ds [Q] fp32, idx [Q,K] int64, w [Q,K] fp32,
+ * dds_dx [Q,3] fp32 = closed-form d ds / d xyz with idx/w held constant (they are detached in
+ * the reference, mesh_grid.py:121-122).  K must be 8 when ds/dds_dx are requested. */
+int nm_compute_distance(nm_grid_t g, const float* q_device, int64_t Q,
+                        const float* indicator_device, float w1, int K, float* ds_device,
+                        int64_t* idx_device, float* w_device, float* dds_dx_device,
+                        nm_stream_t stream);
+
+/* ----------------------------------------------------------------------------------- field
+ * Dense layers are given as PyTorch stores nn.Linear: weight [out,in] row-major, bias [out]
+ * (weight-norm already folded: W = g * v / ||v||_row).  The library re-packs them. */
+typedef struct nm_field_desc {
+    int32_t W;                 /* hidden width; must be 256 */
+    int32_t D_density;         /* geometry MLP hidden layers (1..8) */
+    int32_t D_color;           /* colour MLP hidden layers (1..8) */
+    int32_t geometry_dim;      /* multiple of 4, <= 64 */
+    int32_t color_dim;         /* multiple of 4, <= 64 */
+    int32_t multires_d, multires_fg, multires_ft, multires_view; /* embedder bands, >= 0 */
+    int32_t enable_nablas_input;
+    int32_t use_view_dirs;     /* must be 1 */
+    const float* geo_weight[8];   /* device; layer 0: [W, in_geo], others [W,W] */
+    const float* geo_bias[8];     /* device [W] */
+    const float* density_weight;  /* device [1,W] */
+    const float* density_bias;    /* device [1] */
+    const float* col_weight[8];   /* device; layer 0: [W, in_col], others [W,W] */
+    const float* col_bias[8];
+    const float* rgb_weight;      /* device [3,W] */
+    const float* rgb_bias;        /* device [3] */
+} nm_field_desc;
+
+int nm_field_create(const nm_field_desc* desc, nm_stream_t stream, nm_field_t* out);
+int nm_field_update(nm_field_t f, const nm_field_desc* desc, nm_stream_t stream); /* re-pack */
+int nm_field_destroy(nm_field_t f);
+
+/* Tables + scalars that change without re-packing (borrowed device pointers, [V,dim]). */
+typedef struct nm_field_tables {
+    const float* geometry_features;  /* [V, geometry_dim] */
+    const float* color_features;     /* [V, color_dim] */
+    const float* indicator_vector;   /* [V, 3] */
+    float indicator_weight;          /* w1 */
+    float s;                         /* forward_s() = exp(ln_s * speed_factor) */
+} nm_field_tables;
+
+/* sdf (and nabla = d sdf / d xyz if nabla != NULL) at P points (device [P,3]).
+ * scratch: device buffer of nm_field_scratch_bytes(P) bytes. */
+int64_t nm_field_scratch_bytes(int64_t P);
+int nm_field_density(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const float* xyz,
+                     int64_t P, float* sdf, float* nabla, void* scratch, nm_stream_t stream);
+/* NeuMesh.forward(need_nablas=True): sdf [P], rgb [P,3]; optional nabla [P,3], ds [P],
+ * idx [P,8] int64, w [P,8] (return_ds=True path used by the editing wrappers). */
+int nm_field_forward(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const float* xyz,
+                     const float* view_dirs, int64_t P, float* sdf, float* rgb, float* nabla,
+                     float* ds, int64_t* idx, float* w, void* scratch, nm_stream_t stream);
+/* NeuMesh.forward_color(d, view_dirs, color_features, indices, weights, nabla). */
+int nm_field_color(nm_field_t f, const float* color_features, const float* ds,
+                   const float* view_dirs, const int64_t* idx, const float* w,
+                   const float* nabla, int64_t P, float* rgb, void* scratch,
+                   nm_stream_t stream);
+
+/* -------------------------------------------------------------------------------- renderer */
+typedef struct nm_render_cfg {
+    float obj_bounding_radius;   /* 1.0 */
+    int32_t N_samples;           /* 64 */
+    int32_t N_importance;        /* 64 */
+    int32_t N_upsample_iters;    /* 4; N_importance % N_upsample_iters == 0 */
+    int32_t bounded_near_far;    /* 1 */
+    int32_t calc_normal;         /* 0/1 */
+    int32_t white_bkgd;          /* 0/1 */
+    int32_t probe_grid;          /* 256 (compute_bounded_near_far sample_grid) */
+    float probe_thresh;          /* 0.1 (distance_thresh) */
+    float near_bypass, far_bypass; /* < 0 => unset */
+} nm_render_cfg;
+
+int64_t nm_render_workspace_bytes(const nm_render_cfg* cfg, int64_t R);
+
+/* Optional per-ray / per-sample debug outputs (device pointers, NULL to skip). */
+typedef struct nm_render_debug {
+    float* near_far;    /* [R,2] */
+    float* d_all;       /* [R, N_samples+N_importance] sorted sample depths */
+    float* sdf_all;     /* [R, N_samples+N_importance] */
+    float* nablas_all;  /* [R, N_samples+N_importance, 3] (calc_normal) */
+    float* radiance;    /* [R, N-1, 3] */
+    float* sdf_coarse;  /* [R, N_samples] */
+} nm_render_debug;
+
+/* One chunk of R rays (device [R,3] each; rays_d need not be normalised, renderer.py:153).
+ * Outputs: rgb [R,3], depth [R], acc [R], normals [R,3] (NULL unless calc_normal). */
+int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const float* rays_o,
+                   const float* rays_d, int64_t R, const nm_render_cfg* cfg, float* rgb,
+                   float* depth, float* acc, float* normals, const nm_render_debug* dbg,
+                   void* workspace, nm_stream_t stream);
+
+/* -------------------------------------------------------------------------- instrumentation
+ * Launches `iters` back-to-back passes of one internal kernel on `stream`, bracketed by HIP
+ * events recorded on that same stream; returns the average duration in milliseconds.
+ * which: 0 = K-NN+distance, 1 = geometry MLP (density only), 2 = geometry MLP (+tangent),
+ *        3 = colour MLP.  Used by bench.py for the roofline figure. */
+/* In-stream timing of the hot kernels inside ordinary calls (nm_render_rays, nm_field_*):
+ * nm_profile_enable(1) clears the log and starts bracketing every launch of the K-NN/distance,
+ * geometry-MLP (without / with tangent) and colour-MLP kernels with HIP events recorded on the
+ * launch stream; nm_profile_read(kind) waits for those events and returns the summed kernel
+ * time, the number of launches and the number of points processed.  kind: as `which` below. */
+int nm_profile_enable(int on);
+int nm_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* units);
+
+int nm_time_kernel(nm_field_t f, nm_grid_t g, const nm_field_tables* t, int which,
+                   const float* xyz, const float* view_dirs, int64_t P, void* scratch,
+                   int iters, float* avg_ms, nm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEUMESH_HIP_H */

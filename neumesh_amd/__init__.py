@@ -1,10 +1,27 @@
 """neumesh_amd -- MI355X-native (gfx950) implementation of NeuMesh's volumetric render inner loop.
 
 Only the hot path named by BASELINE.json:north_star is implemented: the
-host side mirrors the reference's own Python interface for that path, the device side is
-hand-written HIP behind the C ABI declared in ``include/neumesh_hip.h``.  Importing the
-package does not need a GPU; the first call that needs the HIP library loads it and fails
-loudly if it is missing (there is no CPU fallback in the product path).
-"""
+host side mirrors the reference's own Python interface for that path (same class / function
+names and argument meaning), the device side is hand-written HIP behind the C ABI declared in
+``include/neumesh_hip.h``.  Importing the package needs neither a GPU nor the built library;
+the first call that needs the HIP library loads it and fails loudly if it (or a GPU) is
+missing -- there is no CPU fallback in the product path.
 
-__all__ = ["synthetic"]
+    from neumesh_amd import build_framework          # models/frameworks/__init__.py
+    from neumesh_amd import MeshGrid, NeuMesh, SingleRenderer, volume_render
+    from neumesh_amd import frnn                     # drop-in for `import frnn`
+"""
+from . import synthetic  # noqa: F401  (numpy only)
+
+
+def __getattr__(name):  # lazy: torch is imported only when the model classes are touched
+    import importlib
+    table = {
+        "MeshGrid": "mesh_grid", "MeshPrimitive": "mesh_grid", "NeuMesh": "neumesh", "SingleRenderer": "renderer",
+        "volume_render": "renderer", "get_model": "framework", "build_framework": "framework",
+    }
+    if name in table:
+        return getattr(importlib.import_module(f".{table[name]}", __name__), name)
+    if name in ("frnn", "mesh_grid", "neumesh", "renderer", "framework", "ply", "sharded", "build", "_lib"):
+        return importlib.import_module(f".{name}", __name__)
+    raise AttributeError(name)

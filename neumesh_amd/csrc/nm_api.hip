@@ -1,0 +1,638 @@
+// nm_api.hip -- C ABI of libneumesh_hip.so (see include/neumesh_hip.h) and the host-side launch
+// sequence of the render hot path.  Built for gfx950 only:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -shared -fPIC nm_api.hip
+// -ffp-contract=off keeps the declared K-NN arithmetic (no FMA contraction); fused multiply-adds
+// are written explicitly (fmaf / MFMA) where they are wanted.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/neumesh_hip.h"
+#include "nm_grid_build.h"
+#include "nm_kernels.h"
+#include "nm_mlp.h"
+
+// ------------------------------------------------------------------------------ error state
+static thread_local std::string g_err;
+static int nm_fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+#define NM_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) return nm_fail("%s failed: %s", #call, hipGetErrorString(e_));  \
+    } while (0)
+#define NM_LAUNCH_CHECK()                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = hipGetLastError();                                                     \
+        if (e_ != hipSuccess) return nm_fail("kernel launch failed: %s", hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------- in-stream kernel timing
+// When enabled (nm_profile_enable), every launch of the four hot kernels is bracketed by a pair
+// of HIP events recorded on the SAME stream the kernel is launched on; nm_profile_read sums the
+// elapsed times per kernel kind.  Event records do not serialise anything; disabled by default.
+enum { NM_K_DISTANCE = 0, NM_K_GEO = 1, NM_K_GEO_NABLA = 2, NM_K_COLOR = 3, NM_K_KINDS = 4 };
+struct NmProfRec { hipEvent_t a, b; int kind; long long units; };
+static bool g_prof_on = false;
+static std::vector<NmProfRec> g_prof;
+struct NmProfScope {
+    NmProfRec r;
+    hipStream_t s;
+    bool on;
+    NmProfScope(int kind, long long units, hipStream_t stream) : s(stream), on(g_prof_on) {
+        if (!on) return;
+        r.kind = kind;
+        r.units = units;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(r.a, s);
+    }
+    ~NmProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, s);
+        g_prof.push_back(r);
+    }
+};
+
+static inline unsigned nm_blocks(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+static inline size_t nm_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---------------------------------------------------------------------------------- handles
+struct nm_grid_s {
+    NmGridView view;        // device pointers
+    float* verts = nullptr;  // device copy of the vertices in ORIGINAL order [V,3]
+    void* blob = nullptr;    // one allocation holding mask | leaf_start | sverts | verts
+    size_t blob_bytes = 0;
+    int occupied = 0;
+};
+
+struct nm_field_s {
+    nm_field_desc desc;  // copy (pointers inside are NOT retained)
+    NmGeoParams geo;
+    NmColParams col;
+    float* blob = nullptr;  // packed weights
+    size_t blob_floats = 0;
+};
+
+extern "C" {
+
+int nm_abi_version(void) { return NM_ABI_VERSION; }
+const char* nm_last_error(void) { return g_err.c_str(); }
+int nm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ================================================================================ grid
+int nm_grid_create(const float* verts_device, int64_t V, int leaf_level, nm_stream_t stream_, nm_grid_t* out) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!out) return nm_fail("nm_grid_create: out is NULL");
+    if (V < 1) return nm_fail("nm_grid_create: V=%lld", (long long)V);
+    if (leaf_level < 0 || leaf_level > NM_MAX_LEVEL) return nm_fail("nm_grid_create: leaf_level %d out of [0,%d]", leaf_level, NM_MAX_LEVEL);
+    std::vector<float> hv((size_t)V * 3);
+    NM_HIP(hipMemcpyAsync(hv.data(), verts_device, hv.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+    NM_HIP(hipStreamSynchronize(stream));
+    NmHostGrid hg;
+    if (!nm_build_host_grid(hv.data(), V, leaf_level, hg)) return nm_fail("nm_grid_create: non-finite vertex coordinates");
+    nm_grid_s* g = new nm_grid_s();
+    const size_t b_mask = nm_align(hg.mask.size());
+    const size_t b_leaf = nm_align(hg.leaf_start.size() * sizeof(uint32_t));
+    const size_t b_sv = nm_align(hg.sverts.size() * sizeof(float4));
+    const size_t b_v = nm_align(hv.size() * sizeof(float));
+    g->blob_bytes = b_mask + b_leaf + b_sv + b_v;
+    if (hipMalloc(&g->blob, g->blob_bytes) != hipSuccess) {
+        delete g;
+        return nm_fail("nm_grid_create: hipMalloc(%zu) failed", b_mask + b_leaf + b_sv + b_v);
+    }
+    char* base = (char*)g->blob;
+    hipError_t e = hipMemcpyAsync(base, hg.mask.data(), hg.mask.size(), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(base + b_mask, hg.leaf_start.data(), hg.leaf_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(base + b_mask + b_leaf, hg.sverts.data(), hg.sverts.size() * sizeof(float4), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(base + b_mask + b_leaf + b_sv, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        hipFree(g->blob);
+        delete g;
+        return nm_fail("nm_grid_create: upload failed: %s", hipGetErrorString(e));
+    }
+    g->view.ox = hg.ox; g->view.oy = hg.oy; g->view.oz = hg.oz;
+    g->view.root_size = hg.root_size;
+    g->view.slack = hg.slack;
+    g->view.L = hg.L;
+    g->view.V = hg.V;
+    g->view.mask = (const uint8_t*)base;
+    g->view.leaf_start = (const uint32_t*)(base + b_mask);
+    g->view.sverts = (const float4*)(base + b_mask + b_leaf);
+    g->verts = (float*)(base + b_mask + b_leaf + b_sv);
+    g->occupied = hg.occupied_leaves;
+    *out = g;
+    return 0;
+}
+
+int nm_grid_destroy(nm_grid_t g) {
+    if (!g) return 0;
+    if (g->blob) hipFree(g->blob);
+    delete g;
+    return 0;
+}
+
+int nm_grid_get_info(nm_grid_t g, nm_grid_info* out) {
+    if (!g || !out) return nm_fail("nm_grid_get_info: NULL argument");
+    out->num_vertices = g->view.V;
+    out->leaf_level = g->view.L;
+    out->occupied_leaves = g->occupied;
+    out->origin[0] = g->view.ox; out->origin[1] = g->view.oy; out->origin[2] = g->view.oz;
+    out->root_size = g->view.root_size;
+    out->device_bytes = (int64_t)g->blob_bytes;
+    return 0;
+}
+
+static NmPointSrc nm_src_xyz(const float* xyz) {
+    NmPointSrc s;
+    memset(&s, 0, sizeof(s));
+    s.mode = 0;
+    s.P = 1;
+    s.xyz = xyz;
+    return s;
+}
+
+int nm_knn(nm_grid_t g, const float* q, int64_t Q, int K, int64_t* idx, float* d2, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!g || !idx || !d2 || (!q && Q > 0)) return nm_fail("nm_knn: NULL argument");
+    if (K < 1 || K > NM_MAX_K) return nm_fail("nm_knn: K=%d out of [1,%d]", K, NM_MAX_K);
+    if (Q <= 0) return Q == 0 ? 0 : nm_fail("nm_knn: Q<0");
+    const NmPointSrc src = nm_src_xyz(q);
+    const dim3 grid(nm_blocks(Q, 256)), block(256);
+    long long* idx_ll = reinterpret_cast<long long*>(idx);
+    if (K <= 8) hipLaunchKernelGGL(nm_knn_kernel<8>, grid, block, 0, stream, g->view, src, (long long)Q, K, idx_ll, d2);
+    else if (K <= 16) hipLaunchKernelGGL(nm_knn_kernel<16>, grid, block, 0, stream, g->view, src, (long long)Q, K, idx_ll, d2);
+    else hipLaunchKernelGGL(nm_knn_kernel<32>, grid, block, 0, stream, g->view, src, (long long)Q, K, idx_ll, d2);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+static int nm_launch_distance(nm_grid_t g, const NmPointSrc& src, long long Q, const float* indicator, float w1,
+                              float* ds, int* idx32, long long* idx64, float* w, float* grad, hipStream_t stream) {
+    if (Q <= 0) return 0;
+    NmProfScope prof(NM_K_DISTANCE, Q, stream);
+    hipLaunchKernelGGL(nm_distance_kernel, dim3(nm_blocks(Q, 256)), dim3(256), 0, stream, g->view, src, Q, g->verts,
+                       indicator, w1, ds, idx32, idx64, w, grad);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_compute_distance(nm_grid_t g, const float* q, int64_t Q, const float* indicator, float w1, int K, float* ds,
+                        int64_t* idx, float* w, float* dds_dx, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!g || (!q && Q > 0)) return nm_fail("nm_compute_distance: NULL argument");
+    if (K != 8) return nm_fail("nm_compute_distance: K=%d unsupported (the fused kernel is built for K=8, the value the reference uses: models/mesh_grid.py:77)", K);
+    if (!indicator) return nm_fail("nm_compute_distance: indicator is NULL");
+    if (g->view.V < 8) return nm_fail("nm_compute_distance: mesh has %d < 8 vertices", g->view.V);
+    if (Q < 0) return nm_fail("nm_compute_distance: Q<0");
+    return nm_launch_distance(g, nm_src_xyz(q), Q, indicator, w1, ds, nullptr, reinterpret_cast<long long*>(idx), w, dds_dx, stream);
+}
+
+// =============================================================================== field
+static int nm_round16(int k) { return (k + 15) & ~15; }
+
+static int nm_field_validate(const nm_field_desc* d) {
+    if (!d) return nm_fail("nm_field: desc is NULL");
+    if (d->W != NM_W) return nm_fail("nm_field: W=%d unsupported (kernels are tiled for W=256, the reference's value: models/frameworks/neumesh/__init__.py:26)", d->W);
+    if (d->D_density < 1 || d->D_density > NM_MAX_LAYERS || d->D_color < 1 || d->D_color > NM_MAX_LAYERS) return nm_fail("nm_field: layer counts out of range");
+    if (d->geometry_dim < 4 || d->geometry_dim > 64 || d->geometry_dim % 4) return nm_fail("nm_field: geometry_dim=%d must be a multiple of 4 in [4,64]", d->geometry_dim);
+    if (d->color_dim < 4 || d->color_dim > 64 || d->color_dim % 4) return nm_fail("nm_field: color_dim=%d must be a multiple of 4 in [4,64]", d->color_dim);
+    if (d->multires_d < 0 || d->multires_fg < 0 || d->multires_ft < 0 || d->multires_view < 0) return nm_fail("nm_field: negative multires (identity embedders) unsupported");
+    if (d->multires_d > 16 || d->multires_view > 16) return nm_fail("nm_field: multires too large");
+    if (!d->use_view_dirs) return nm_fail("nm_field: use_view_dirs=0 unsupported");
+    const int in_geo = 1 + 2 * d->multires_d + d->geometry_dim * (1 + 2 * d->multires_fg);
+    const int in_col = (d->enable_nablas_input ? 3 : 0) + 1 + 2 * d->multires_d + 3 * (1 + 2 * d->multires_view) + d->color_dim * (1 + 2 * d->multires_ft);
+    if (in_geo > 256 || in_col > 256) return nm_fail("nm_field: MLP input width %d/%d exceeds the 256-column LDS tile", in_geo, in_col);
+    for (int l = 0; l < d->D_density; ++l) if (!d->geo_weight[l] || !d->geo_bias[l]) return nm_fail("nm_field: geo layer %d NULL", l);
+    for (int l = 0; l < d->D_color; ++l) if (!d->col_weight[l] || !d->col_bias[l]) return nm_fail("nm_field: col layer %d NULL", l);
+    if (!d->density_weight || !d->density_bias || !d->rgb_weight || !d->rgb_bias) return nm_fail("nm_field: output layer NULL");
+    return 0;
+}
+
+static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stream) {
+    const int in_geo = 1 + 2 * d->multires_d + d->geometry_dim * (1 + 2 * d->multires_fg);
+    const int in_col = (d->enable_nablas_input ? 3 : 0) + 1 + 2 * d->multires_d + 3 * (1 + 2 * d->multires_view) + d->color_dim * (1 + 2 * d->multires_ft);
+    size_t need = 0;
+    for (int l = 0; l < d->D_density; ++l) need += (size_t)NM_W * nm_round16(l == 0 ? in_geo : NM_W) + NM_W;
+    for (int l = 0; l < d->D_color; ++l) need += (size_t)NM_W * nm_round16(l == 0 ? in_col : NM_W) + NM_W;
+    need += NM_W + 3 * NM_W + 64;
+    if (need > f->blob_floats) {
+        if (f->blob) hipFree(f->blob);
+        f->blob = nullptr;
+        NM_HIP(hipMalloc((void**)&f->blob, need * sizeof(float)));
+        f->blob_floats = need;
+    }
+    float* p = f->blob;
+    auto pack = [&](const float* src, int in_dim, NmLayer& L, const float* bias) -> int {
+        L.Kpad = nm_round16(in_dim);
+        L.W = p;
+        hipLaunchKernelGGL(nm_pack_weight_kernel, dim3(nm_blocks((long long)NM_W * L.Kpad, 256)), dim3(256), 0, stream, src, NM_W, in_dim, L.Kpad, p);
+        p += (size_t)NM_W * L.Kpad;
+        L.b = p;
+        if (hipMemcpyAsync(p, bias, NM_W * sizeof(float), hipMemcpyDeviceToDevice, stream) != hipSuccess) return 1;
+        p += NM_W;
+        return 0;
+    };
+    memset(&f->geo, 0, sizeof(f->geo));
+    memset(&f->col, 0, sizeof(f->col));
+    for (int l = 0; l < d->D_density; ++l)
+        if (pack(d->geo_weight[l], l == 0 ? in_geo : NM_W, f->geo.layer[l], d->geo_bias[l])) return nm_fail("nm_field: pack failed");
+    for (int l = 0; l < d->D_color; ++l)
+        if (pack(d->col_weight[l], l == 0 ? in_col : NM_W, f->col.layer[l], d->col_bias[l])) return nm_fail("nm_field: pack failed");
+    NM_LAUNCH_CHECK();
+    NM_HIP(hipMemcpyAsync(p, d->density_weight, NM_W * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    f->geo.wd = p;
+    p += NM_W;
+    NM_HIP(hipMemcpyAsync(p, d->rgb_weight, 3 * NM_W * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    f->col.wrgb = p;
+    p += 3 * NM_W;
+    float hb[4] = {0, 0, 0, 0};
+    NM_HIP(hipMemcpyAsync(&hb[0], d->density_bias, sizeof(float), hipMemcpyDeviceToHost, stream));
+    NM_HIP(hipMemcpyAsync(&hb[1], d->rgb_bias, 3 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    NM_HIP(hipStreamSynchronize(stream));
+    f->geo.D = d->D_density;
+    f->geo.bd = hb[0];
+    f->geo.multires_d = d->multires_d;
+    f->geo.multires_fg = d->multires_fg;
+    f->geo.gdim = d->geometry_dim;
+    f->geo.d_emb = 1 + 2 * d->multires_d;
+    f->geo.in_dim = in_geo;
+    f->col.D = d->D_color;
+    f->col.brgb[0] = hb[1]; f->col.brgb[1] = hb[2]; f->col.brgb[2] = hb[3];
+    f->col.multires_d = d->multires_d;
+    f->col.multires_ft = d->multires_ft;
+    f->col.multires_view = d->multires_view;
+    f->col.cdim = d->color_dim;
+    f->col.use_nabla = d->enable_nablas_input ? 1 : 0;
+    f->col.d_emb = 1 + 2 * d->multires_d;
+    f->col.in_dim = in_col;
+    f->desc = *d;
+    return 0;
+}
+
+int nm_field_create(const nm_field_desc* desc, nm_stream_t stream, nm_field_t* out) {
+    if (!out) return nm_fail("nm_field_create: out is NULL");
+    if (nm_field_validate(desc)) return 1;
+    nm_field_s* f = new nm_field_s();
+    if (nm_field_pack(f, desc, (hipStream_t)stream)) {
+        if (f->blob) hipFree(f->blob);
+        delete f;
+        return 1;
+    }
+    *out = f;
+    return 0;
+}
+
+int nm_field_update(nm_field_t f, const nm_field_desc* desc, nm_stream_t stream) {
+    if (!f) return nm_fail("nm_field_update: NULL handle");
+    if (nm_field_validate(desc)) return 1;
+    return nm_field_pack(f, desc, (hipStream_t)stream);
+}
+
+int nm_field_destroy(nm_field_t f) {
+    if (!f) return 0;
+    if (f->blob) hipFree(f->blob);
+    delete f;
+    return 0;
+}
+
+// scratch layout for P points: ds | idx32[8] | w[8] | grad[3] | nabla[3] | valu_tmp (self-check only)
+struct NmScratch {
+    float* ds;
+    int* idx;
+    float* w;
+    float* grad;
+    float* nabla;
+    size_t bytes;
+};
+static NmScratch nm_carve(void* base, long long P) {
+    NmScratch s;
+    char* p = (char*)base;
+    size_t o = 0;
+    s.ds = (float*)(p + o);    o += nm_align((size_t)P * 4);
+    s.idx = (int*)(p + o);     o += nm_align((size_t)P * 32);
+    s.w = (float*)(p + o);     o += nm_align((size_t)P * 32);
+    s.grad = (float*)(p + o);  o += nm_align((size_t)P * 12);
+    s.nabla = (float*)(p + o); o += nm_align((size_t)P * 12);
+    s.bytes = o;
+    return s;
+}
+int64_t nm_field_scratch_bytes(int64_t P) { return (int64_t)nm_carve(nullptr, P < 1 ? 1 : P).bytes; }
+
+static int nm_check_field_args(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const char* who) {
+    if (!f || !g || !t) return nm_fail("%s: NULL handle/tables", who);
+    if (!t->geometry_features || !t->color_features || !t->indicator_vector) return nm_fail("%s: NULL table", who);
+    if (g->view.V < 8) return nm_fail("%s: mesh has %d < 8 vertices", who, g->view.V);
+    return 0;
+}
+
+static int nm_launch_geo(nm_field_t f, const float* table, const float* ds, const int* idx, const float* w,
+                         const float* grad, long long P, bool nabla, float* sdf, int Pper, int stride, int off,
+                         float* nabla_out, hipStream_t stream) {
+    if (P <= 0) return 0;
+    NmProfScope prof(nabla ? NM_K_GEO_NABLA : NM_K_GEO, P, stream);
+    if (nabla) {
+        hipLaunchKernelGGL((nm_geo_mlp_kernel<true, false>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo, table, ds,
+                           idx, w, grad, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr);
+    } else {
+        hipLaunchKernelGGL((nm_geo_mlp_kernel<false, false>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->geo, table, ds,
+                           idx, w, grad, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr);
+    }
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+static int nm_launch_col(nm_field_t f, const float* table, const float* ds, const int* idx, const float* w,
+                         const float* nabla, const float* dirs, int dir_div, long long P, float* rgb, hipStream_t stream) {
+    if (P <= 0) return 0;
+    NmProfScope prof(NM_K_COLOR, P, stream);
+    hipLaunchKernelGGL((nm_col_mlp_kernel<false>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->col, table, ds, idx, w,
+                       nabla, dirs, dir_div, P, rgb, (float*)nullptr);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_field_density(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const float* xyz, int64_t P, float* sdf,
+                     float* nabla, void* scratch, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (nm_check_field_args(f, g, t, "nm_field_density")) return 1;
+    if (P < 0 || (P > 0 && (!xyz || !sdf || !scratch))) return nm_fail("nm_field_density: bad arguments");
+    if (P == 0) return 0;
+    const NmScratch s = nm_carve(scratch, P);
+    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx, nullptr, s.w,
+                           nabla ? s.grad : nullptr, stream)) return 1;
+    return nm_launch_geo(f, t->geometry_features, s.ds, s.idx, s.w, s.grad, P, nabla != nullptr, sdf, 1, 1, 0, nabla, stream);
+}
+
+int nm_field_forward(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const float* xyz, const float* view_dirs,
+                     int64_t P, float* sdf, float* rgb, float* nabla, float* ds, int64_t* idx, float* w, void* scratch,
+                     nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (nm_check_field_args(f, g, t, "nm_field_forward")) return 1;
+    if (P < 0 || (P > 0 && (!xyz || !view_dirs || !sdf || !rgb || !scratch))) return nm_fail("nm_field_forward: bad arguments");
+    if (P == 0) return 0;
+    const NmScratch s = nm_carve(scratch, P);
+    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx,
+                           reinterpret_cast<long long*>(idx), s.w, s.grad, stream)) return 1;
+    float* nab = nabla ? nabla : s.nabla;
+    if (nm_launch_geo(f, t->geometry_features, s.ds, s.idx, s.w, s.grad, P, true, sdf, 1, 1, 0, nab, stream)) return 1;
+    if (nm_launch_col(f, t->color_features, s.ds, s.idx, s.w, nab, view_dirs, 1, P, rgb, stream)) return 1;
+    if (ds) NM_HIP(hipMemcpyAsync(ds, s.ds, (size_t)P * 4, hipMemcpyDeviceToDevice, stream));
+    if (w) NM_HIP(hipMemcpyAsync(w, s.w, (size_t)P * 32, hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
+int nm_field_color(nm_field_t f, const float* color_features, const float* ds, const float* view_dirs, const int64_t* idx,
+                   const float* w, const float* nabla, int64_t P, float* rgb, void* scratch, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!f) return nm_fail("nm_field_color: NULL handle");
+    if (P < 0 || (P > 0 && (!color_features || !ds || !view_dirs || !idx || !w || !rgb || !scratch))) return nm_fail("nm_field_color: bad arguments");
+    if (f->col.use_nabla && !nabla && P > 0) return nm_fail("nm_field_color: nabla required (enable_nablas_input)");
+    if (P == 0) return 0;
+    const NmScratch s = nm_carve(scratch, P);
+    hipLaunchKernelGGL(nm_idx64_to_32_kernel, dim3(nm_blocks(P * 8, 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const long long*>(idx), (long long)P * 8, s.idx);
+    NM_LAUNCH_CHECK();
+    return nm_launch_col(f, color_features, ds, s.idx, w, nabla, view_dirs, 1, P, rgb, stream);
+}
+
+// ============================================================================== renderer
+struct NmWorkspace {
+    float *dirn, *nf0, *nf, *d, *sdf, *dmid, *probe;
+    float *rgb_mid, *nab_pts, *nab_mid;
+    NmScratch pts;  // K-NN outputs for up to R*N points
+    size_t bytes;
+};
+static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) {
+    NmWorkspace w;
+    const int N = c->N_samples + c->N_importance;
+    char* p = (char*)base;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { char* r = p + o; o += nm_align(bytes); return r; };
+    w.dirn = (float*)take((size_t)R * 12);
+    w.nf0 = (float*)take((size_t)R * 8);
+    w.nf = (float*)take((size_t)R * 8);
+    w.d = (float*)take((size_t)R * N * 4);
+    w.sdf = (float*)take((size_t)R * N * 4);
+    w.dmid = (float*)take((size_t)R * N * 4);
+    w.probe = (float*)take((size_t)R * (c->bounded_near_far ? c->probe_grid : 1) * 4);
+    w.rgb_mid = (float*)take((size_t)R * N * 12);
+    w.nab_pts = (float*)take((size_t)R * N * 12);
+    w.nab_mid = (float*)take((size_t)R * N * 12);
+    w.pts = nm_carve(p + o, R * N);
+    o += w.pts.bytes;
+    w.bytes = o;
+    return w;
+}
+
+static int nm_check_cfg(const nm_render_cfg* c) {
+    if (!c) return nm_fail("nm_render: cfg is NULL");
+    if (c->N_samples < 2 || c->N_importance < 0 || c->N_samples + c->N_importance > NM_MAX_SAMPLES) return nm_fail("nm_render: N_samples=%d N_importance=%d unsupported (sum <= %d)", c->N_samples, c->N_importance, NM_MAX_SAMPLES);
+    if (c->N_importance > 0 && (c->N_upsample_iters < 1 || c->N_importance % c->N_upsample_iters)) return nm_fail("nm_render: N_importance %% N_upsample_iters != 0");
+    if (c->bounded_near_far && (c->probe_grid < 2 || c->probe_grid > 4096)) return nm_fail("nm_render: probe_grid=%d", c->probe_grid);
+    return 0;
+}
+
+int64_t nm_render_workspace_bytes(const nm_render_cfg* cfg, int64_t R) {
+    if (nm_check_cfg(cfg) || R < 1) return -1;
+    return (int64_t)nm_carve_ws(nullptr, cfg, R).bytes;
+}
+
+int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const float* rays_o, const float* rays_d, int64_t R,
+                   const nm_render_cfg* c, float* rgb, float* depth, float* acc, float* normals, const nm_render_debug* dbg,
+                   void* workspace, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (nm_check_field_args(f, g, t, "nm_render_rays") || nm_check_cfg(c)) return 1;
+    if (R < 0 || (R > 0 && (!rays_o || !rays_d || !rgb || !depth || !acc || !workspace))) return nm_fail("nm_render_rays: bad arguments");
+    if (c->calc_normal && !normals) return nm_fail("nm_render_rays: calc_normal set but normals is NULL");
+    if (R == 0) return 0;
+    const NmWorkspace ws = nm_carve_ws(workspace, c, R);
+    const int N = c->N_samples + c->N_importance, cap = N;
+    const dim3 rgrid(nm_blocks(R, 64)), rblock(64);
+
+    // rays: normalise directions, sphere near/far (renderer.py:153, rend_util.py:179-199)
+    hipLaunchKernelGGL(nm_rays_setup_kernel, rgrid, rblock, 0, stream, rays_o, rays_d, (long long)R, c->obj_bounding_radius, ws.dirn, ws.nf0);
+    NM_LAUNCH_CHECK();
+    NmPointSrc src;
+    memset(&src, 0, sizeof(src));
+    src.rays_o = rays_o;
+    src.dirn = ws.dirn;
+    src.dstride = cap;
+    const float* nf = ws.nf0;
+    if (c->bounded_near_far) {  // renderer.py:66-102
+        src.mode = 2;
+        src.P = c->probe_grid;
+        src.nearfar = ws.nf0;
+        src.depth_out = nullptr;
+        if (nm_launch_distance(g, src, (long long)R * c->probe_grid, t->indicator_vector, t->indicator_weight, ws.probe, nullptr, nullptr, nullptr, nullptr, stream)) return 1;
+        hipLaunchKernelGGL(nm_rays_bounds_kernel, rgrid, rblock, 0, stream, ws.probe, (long long)R, c->probe_grid, c->probe_thresh, ws.nf0, ws.nf);
+        NM_LAUNCH_CHECK();
+        nf = ws.nf;
+    }
+    if (c->near_bypass >= 0.f || c->far_bypass >= 0.f) {  // renderer.py:172-175
+        if (nf == ws.nf0) {
+            NM_HIP(hipMemcpyAsync(ws.nf, ws.nf0, (size_t)R * 8, hipMemcpyDeviceToDevice, stream));
+            nf = ws.nf;
+        }
+        hipLaunchKernelGGL(nm_rays_bypass_kernel, rgrid, rblock, 0, stream, (long long)R, c->near_bypass, c->far_bypass, ws.nf);
+        NM_LAUNCH_CHECK();
+    }
+    // coarse samples + SDF (renderer.py:193-207)
+    src.mode = 2;
+    src.P = c->N_samples;
+    src.nearfar = nf;
+    src.depth_out = ws.d;
+    src.doff = 0;
+    if (nm_launch_distance(g, src, (long long)R * c->N_samples, t->indicator_vector, t->indicator_weight, ws.pts.ds, ws.pts.idx, nullptr, ws.pts.w, nullptr, stream)) return 1;
+    if (nm_launch_geo(f, t->geometry_features, ws.pts.ds, ws.pts.idx, ws.pts.w, nullptr, (long long)R * c->N_samples, false, ws.sdf, c->N_samples, cap, 0, nullptr, stream)) return 1;
+    if (dbg && dbg->sdf_coarse) {
+        hipLaunchKernelGGL(nm_copy_strided_kernel, dim3(nm_blocks(R * c->N_samples, 256)), dim3(256), 0, stream, ws.sdf, (long long)R, c->N_samples, cap, dbg->sdf_coarse);
+        NM_LAUNCH_CHECK();
+    }
+    // hierarchical up-sampling (renderer.py:208-258)
+    int n = c->N_samples, pending = 0;
+    if (c->N_importance > 0) {
+        const int n_new = c->N_importance / c->N_upsample_iters;
+        for (int it = 0; it < c->N_upsample_iters; ++it) {
+            hipLaunchKernelGGL(nm_rays_upsample_kernel, rgrid, rblock, 0, stream, ws.d, ws.sdf, (long long)R, cap, n, pending, it, n_new);
+            NM_LAUNCH_CHECK();
+            src.mode = 1;
+            src.P = n_new;
+            src.depth = ws.d;
+            src.doff = n;
+            src.depth_out = nullptr;
+            if (nm_launch_distance(g, src, (long long)R * n_new, t->indicator_vector, t->indicator_weight, ws.pts.ds, ws.pts.idx, nullptr, ws.pts.w, nullptr, stream)) return 1;
+            if (nm_launch_geo(f, t->geometry_features, ws.pts.ds, ws.pts.idx, ws.pts.w, nullptr, (long long)R * n_new, false, ws.sdf, n_new, cap, n, nullptr, stream)) return 1;
+            n += n_new;
+            pending = n_new;
+        }
+    }
+    hipLaunchKernelGGL(nm_rays_finalize_kernel, rgrid, rblock, 0, stream, ws.d, ws.sdf, (long long)R, cap, n, pending, ws.dmid);
+    NM_LAUNCH_CHECK();
+    // SDF (+ nablas) at all N sample points (renderer.py:264, 271-276)
+    src.mode = 1;
+    src.P = N;
+    src.depth = ws.d;
+    src.doff = 0;
+    if (nm_launch_distance(g, src, (long long)R * N, t->indicator_vector, t->indicator_weight, ws.pts.ds, ws.pts.idx, nullptr, ws.pts.w, c->calc_normal ? ws.pts.grad : nullptr, stream)) return 1;
+    if (nm_launch_geo(f, t->geometry_features, ws.pts.ds, ws.pts.idx, ws.pts.w, ws.pts.grad, (long long)R * N, c->calc_normal != 0, ws.sdf, N, cap, 0, c->calc_normal ? ws.nab_pts : nullptr, stream)) return 1;
+    // SDF + nabla + radiance at the N-1 mid-points (renderer.py:266-267, 279-282)
+    src.P = N - 1;
+    src.depth = ws.dmid;
+    if (nm_launch_distance(g, src, (long long)R * (N - 1), t->indicator_vector, t->indicator_weight, ws.pts.ds, ws.pts.idx, nullptr, ws.pts.w, ws.pts.grad, stream)) return 1;
+    if (nm_launch_geo(f, t->geometry_features, ws.pts.ds, ws.pts.idx, ws.pts.w, ws.pts.grad, (long long)R * (N - 1), true, nullptr, 1, 1, 0, ws.nab_mid, stream)) return 1;
+    if (nm_launch_col(f, t->color_features, ws.pts.ds, ws.pts.idx, ws.pts.w, ws.nab_mid, ws.dirn, N - 1, (long long)R * (N - 1), ws.rgb_mid, stream)) return 1;
+    // alpha + compositing (renderer.py:278, 302-333)
+    hipLaunchKernelGGL(nm_rays_composite_kernel, rgrid, rblock, 0, stream, ws.sdf, ws.d, (long long)R, cap, N, t->s, ws.rgb_mid,
+                       c->calc_normal ? ws.nab_pts : (const float*)nullptr, c->white_bkgd, rgb, depth, acc, c->calc_normal ? normals : (float*)nullptr);
+    NM_LAUNCH_CHECK();
+    if (dbg) {
+        if (dbg->near_far) NM_HIP(hipMemcpyAsync(dbg->near_far, nf, (size_t)R * 8, hipMemcpyDeviceToDevice, stream));
+        if (dbg->d_all) NM_HIP(hipMemcpyAsync(dbg->d_all, ws.d, (size_t)R * N * 4, hipMemcpyDeviceToDevice, stream));
+        if (dbg->sdf_all) NM_HIP(hipMemcpyAsync(dbg->sdf_all, ws.sdf, (size_t)R * N * 4, hipMemcpyDeviceToDevice, stream));
+        if (dbg->nablas_all && c->calc_normal) NM_HIP(hipMemcpyAsync(dbg->nablas_all, ws.nab_pts, (size_t)R * N * 12, hipMemcpyDeviceToDevice, stream));
+        if (dbg->radiance) NM_HIP(hipMemcpyAsync(dbg->radiance, ws.rgb_mid, (size_t)R * (N - 1) * 12, hipMemcpyDeviceToDevice, stream));
+    }
+    return 0;
+}
+
+// ======================================================================== instrumentation
+int nm_profile_enable(int on) {
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_on = on != 0;
+    return 0;
+}
+
+int nm_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* units) {
+    if (kind < 0 || kind >= NM_K_KINDS || !total_ms || !launches || !units) return nm_fail("nm_profile_read: bad arguments");
+    double ms = 0.0;
+    int64_t n = 0, u = 0;
+    for (auto& r : g_prof) {
+        if (r.kind != kind) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) return nm_fail("nm_profile_read: event sync failed");
+        float e = 0.f;
+        if (hipEventElapsedTime(&e, r.a, r.b) != hipSuccess) return nm_fail("nm_profile_read: elapsed failed");
+        ms += e;
+        n += 1;
+        u += r.units;
+    }
+    *total_ms = ms;
+    *launches = n;
+    *units = u;
+    return 0;
+}
+
+int nm_time_kernel(nm_field_t f, nm_grid_t g, const nm_field_tables* t, int which, const float* xyz, const float* view_dirs,
+                   int64_t P, void* scratch, int iters, float* avg_ms, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (nm_check_field_args(f, g, t, "nm_time_kernel")) return 1;
+    if (!xyz || !scratch || !avg_ms || P < 1 || iters < 1) return nm_fail("nm_time_kernel: bad arguments");
+    if (which == 3 && !view_dirs) return nm_fail("nm_time_kernel: view_dirs required for the colour kernel");
+    const NmScratch s = nm_carve(scratch, P);
+    // inputs of the MLP kernels come from one K-NN pass
+    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx, nullptr, s.w, s.grad, stream)) return 1;
+    if (which == 3 && nm_launch_geo(f, t->geometry_features, s.ds, s.idx, s.w, s.grad, P, true, nullptr, 1, 1, 0, s.nabla, stream)) return 1;
+    hipEvent_t e0, e1;
+    NM_HIP(hipEventCreate(&e0));
+    NM_HIP(hipEventCreate(&e1));
+    int rc = 0;
+    // the sdf/rgb outputs of the timed kernels go to the (otherwise unused here) nabla/grad slots
+    float* sink = s.nabla;
+    for (int i = -1; i < iters && !rc; ++i) {  // i = -1: untimed warm-up
+        if (i == 0) hipEventRecord(e0, stream);
+        switch (which) {
+            case 0: rc = nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx, nullptr, s.w, s.grad, stream); break;
+            case 1: rc = nm_launch_geo(f, t->geometry_features, s.ds, s.idx, s.w, s.grad, P, false, sink, 1, 1, 0, nullptr, stream); break;
+            case 2: rc = nm_launch_geo(f, t->geometry_features, s.ds, s.idx, s.w, s.grad, P, true, nullptr, 1, 1, 0, sink, stream); break;
+            case 3: rc = nm_launch_col(f, t->color_features, s.ds, s.idx, s.w, s.nabla, view_dirs, 1, P, s.grad, stream); break;
+            default: rc = nm_fail("nm_time_kernel: which=%d", which);
+        }
+    }
+    if (!rc) {
+        hipEventRecord(e1, stream);
+        if (hipEventSynchronize(e1) != hipSuccess) rc = nm_fail("nm_time_kernel: event sync failed");
+        float ms = 0.f;
+        if (!rc && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = nm_fail("nm_time_kernel: elapsed failed");
+        *avg_ms = ms / (float)iters;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return rc;
+}
+
+// Device self-check hook (tests only): the geometry / colour MLP computed with the scalar-ALU
+// reference layer instead of the MFMA tile code, same inputs, same outputs.  valu_tmp: device
+// buffer of ceil(P/32) * 64*256 floats.
+int nm_selfcheck_field(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const float* xyz, const float* view_dirs,
+                       int64_t P, float* sdf, float* nabla, float* rgb, void* scratch, float* valu_tmp, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (nm_check_field_args(f, g, t, "nm_selfcheck_field")) return 1;
+    if (!xyz || !view_dirs || !sdf || !nabla || !rgb || !scratch || !valu_tmp || P < 1) return nm_fail("nm_selfcheck_field: bad arguments");
+    const NmScratch s = nm_carve(scratch, P);
+    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx, nullptr, s.w, s.grad, stream)) return 1;
+    hipLaunchKernelGGL((nm_geo_mlp_kernel<true, true>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo, t->geometry_features,
+                       s.ds, s.idx, s.w, s.grad, (long long)P, sdf, 1, 1, 0, nabla, valu_tmp);
+    NM_LAUNCH_CHECK();
+    hipLaunchKernelGGL((nm_col_mlp_kernel<true>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->col, t->color_features, s.ds,
+                       s.idx, s.w, nabla, view_dirs, 1, (long long)P, rgb, valu_tmp);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

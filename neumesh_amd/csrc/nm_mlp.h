@@ -1,0 +1,431 @@
+// nm_mlp.h -- device-only: the fused "gather - interpolate - embed - MLP" kernels on fp32 MFMA.
+//
+// Reference semantics (file:line in the NeuMesh tree):
+//   interpolation            models/frameworks/neumesh/neumesh.py:11-13
+//   Embedder.forward         models/base.py:52-70 (per band: sin(x f) over all dims, cos(x f) ...)
+//   _forward_density         neumesh.py:204-237  (177 -> 256 x3 softplus(beta=100) -> 1)
+//   nabla                    neumesh.py:225-232  (autograd there; forward-mode tangent here)
+//   _forward_color           neumesh.py:239-260  (207 -> 256 x4 ReLU -> 3 sigmoid)
+//
+// Tiling (gfx950, wave64): one workgroup = 4 waves = a 64-row x 256-column activation tile that
+// lives in LDS (row stride 260 floats => ds_read_b128 of a column block is bank-conflict free).
+// Wave w owns output columns [64w, 64w+64) for all 64 rows = 2x2 tiles of
+// v_mfma_f32_32x32x2_f32 (4 independent accumulators: enough to saturate the fp32 matrix pipe
+// from one wave per SIMD).  A operands come from LDS (16-byte reads, 8 k-values per lane per
+// step), B operands straight from the packed weights in L2 (each wave reads a disjoint quarter
+// of every layer, 32 contiguous bytes per lane per step; no LDS staging needed at the fp32 MFMA
+// rate of 64 cycles/instruction).  The 2 lane-halves of a 32x32x2 MFMA take k-blocks
+// [16J,16J+8) and [16J+8,16J+16): the sum over k is a permuted but fixed fp32 fma chain.
+// With nabla: rows 0-31 are the points' activations h, rows 32-63 their tangents
+// t = d h / d ds; both run through the same weights, t_out = (W t_in) * softplus'(z).
+// LDS per workgroup: 66.8 KB => two workgroups per CU, so one workgroup's VALU phases
+// (gather / sin-cos embedding / softplus epilogue) overlap the other's MFMA phase.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NM_ROWS 64
+#define NM_W 256
+#define NM_LDS_STRIDE 260
+#define NM_MAX_LAYERS 8
+
+typedef float nm_f32x16 __attribute__((ext_vector_type(16)));
+
+struct NmLayer {
+    const float* W;  // packed [256][Kpad], zero padded
+    const float* b;  // [256]
+    int Kpad;        // multiple of 16
+};
+
+struct NmGeoParams {
+    NmLayer layer[NM_MAX_LAYERS];
+    int D;
+    const float* wd;  // density_linear weight [256]
+    float bd;
+    int multires_d, multires_fg, gdim;
+    int d_emb, in_dim;  // 1+2*multires_d ; d_emb + gdim*(1+2*multires_fg)
+};
+
+struct NmColParams {
+    NmLayer layer[NM_MAX_LAYERS];
+    int D;
+    const float* wrgb;  // [3][256]
+    float brgb[3];
+    int multires_d, multires_ft, multires_view, cdim, use_nabla;
+    int d_emb, in_dim;
+};
+
+// softplus(beta=100, threshold=20) and its derivative exactly as torch computes them:
+// forward: x*beta > 20 ? x : log1p(exp(x*beta))/beta ; backward: x*beta > 20 ? 1 : z/(z+1), z=exp(x*beta)
+__device__ __forceinline__ float nm_softplus100(float x, float* grad) {
+    const float xb = x * 100.0f;
+    if (xb > 20.0f) {
+        if (grad) *grad = 1.0f;
+        return x;
+    }
+    const float z = expf(xb);
+    if (grad) *grad = __fdiv_rn(z, z + 1.0f);
+    return __fdiv_rn(log1pf(z), 100.0f);
+}
+
+// One dense layer on the LDS tile: act[64][K] -> act[64][256] (in place).
+// ACT: 0 softplus100 (geometry), 1 ReLU (colour).  TANGENT: rows 32-63 are tangents (no bias,
+// multiplied by the activation derivative of the matching row 0-31).  k_hi: number of leading
+// input columns that are non-zero for rows 32-63 (multiple of 16; = Kpad unless layer 0 of the
+// tangent pass, where only the d-embedding columns are live).
+template <int ACT, bool TANGENT>
+__device__ __forceinline__ void nm_mlp_layer(float* act, const float* __restrict__ W, const float* __restrict__ bias,
+                                             int Kpad, int k_hi) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int n0 = wave * 64;
+    nm_f32x16 acc00 = {0}, acc01 = {0}, acc10 = {0}, acc11 = {0};
+    const float* a0p = act + li * NM_LDS_STRIDE + 8 * h;
+    const float* a1p = act + (32 + li) * NM_LDS_STRIDE + 8 * h;
+    const float* b0p = W + (size_t)(n0 + li) * Kpad + 8 * h;
+    const float* b1p = W + (size_t)(n0 + 32 + li) * Kpad + 8 * h;
+    const int nJ = Kpad >> 4;
+    const int nJ1 = k_hi >> 4;
+    for (int J = 0; J < nJ; ++J) {
+        const float4 b00 = *reinterpret_cast<const float4*>(b0p + 16 * J);
+        const float4 b01 = *reinterpret_cast<const float4*>(b0p + 16 * J + 4);
+        const float4 b10 = *reinterpret_cast<const float4*>(b1p + 16 * J);
+        const float4 b11 = *reinterpret_cast<const float4*>(b1p + 16 * J + 4);
+        const float4 a00 = *reinterpret_cast<const float4*>(a0p + 16 * J);
+        const float4 a01 = *reinterpret_cast<const float4*>(a0p + 16 * J + 4);
+        const float av0[8] = {a00.x, a00.y, a00.z, a00.w, a01.x, a01.y, a01.z, a01.w};
+        const float bv0[8] = {b00.x, b00.y, b00.z, b00.w, b01.x, b01.y, b01.z, b01.w};
+        const float bv1[8] = {b10.x, b10.y, b10.z, b10.w, b11.x, b11.y, b11.z, b11.w};
+        if (J < nJ1) {
+            const float4 a10 = *reinterpret_cast<const float4*>(a1p + 16 * J);
+            const float4 a11 = *reinterpret_cast<const float4*>(a1p + 16 * J + 4);
+            const float av1[8] = {a10.x, a10.y, a10.z, a10.w, a11.x, a11.y, a11.z, a11.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc01, 0, 0, 0);
+                acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv0[e], acc10, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], bv1[e], acc11, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv0[e], acc00, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], bv1[e], acc01, 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();  // every wave has finished reading the input tile
+    const float bias0 = bias[n0 + li], bias1 = bias[n0 + 32 + li];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;  // MFMA 32x32 C/D layout
+        float* o0 = act + row * NM_LDS_STRIDE + n0 + li;
+        float* o1 = act + (32 + row) * NM_LDS_STRIDE + n0 + li;
+        const float z00 = acc00[reg] + bias0, z01 = acc01[reg] + bias1;
+        if (TANGENT) {
+            float g0, g1;
+            float y0, y1;
+            if (ACT == 0) {
+                y0 = nm_softplus100(z00, &g0);
+                y1 = nm_softplus100(z01, &g1);
+            } else {
+                y0 = fmaxf(z00, 0.f); g0 = z00 > 0.f ? 1.f : 0.f;
+                y1 = fmaxf(z01, 0.f); g1 = z01 > 0.f ? 1.f : 0.f;
+            }
+            o0[0] = y0;
+            o0[32] = y1;
+            o1[0] = acc10[reg] * g0;
+            o1[32] = acc11[reg] * g1;
+        } else {
+            const float z10 = acc10[reg] + bias0, z11 = acc11[reg] + bias1;
+            if (ACT == 0) {
+                o0[0] = nm_softplus100(z00, nullptr);
+                o0[32] = nm_softplus100(z01, nullptr);
+                o1[0] = nm_softplus100(z10, nullptr);
+                o1[32] = nm_softplus100(z11, nullptr);
+            } else {
+                o0[0] = fmaxf(z00, 0.f);
+                o0[32] = fmaxf(z01, 0.f);
+                o1[0] = fmaxf(z10, 0.f);
+                o1[32] = fmaxf(z11, 0.f);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Same layer on the scalar ALUs (one output element per thread-iteration, plain fmaf chain in
+// natural k order).  NOT part of the product path: used by nm_selfcheck_* to cross-check the
+// MFMA tile code on the device (catches fragment-layout mistakes that a symmetric test misses).
+template <int ACT, bool TANGENT>
+__device__ void nm_mlp_layer_valu(float* act, float* tmp /*[64][256] global*/, const float* __restrict__ W,
+                                  const float* __restrict__ bias, int Kpad) {
+    for (int e = threadIdx.x; e < NM_ROWS * NM_W; e += blockDim.x) {
+        const int row = e >> 8, n = e & 255;
+        float s = 0.f;
+        for (int k = 0; k < Kpad; ++k) s = fmaf(act[row * NM_LDS_STRIDE + k], W[(size_t)n * Kpad + k], s);
+        tmp[e] = s;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NM_ROWS * NM_W; e += blockDim.x) {
+        const int row = e >> 8, n = e & 255;
+        float y;
+        if (TANGENT && row >= 32) {
+            const float z = tmp[(row - 32) * NM_W + n] + bias[n];
+            float g;
+            if (ACT == 0) nm_softplus100(z, &g); else g = z > 0.f ? 1.f : 0.f;
+            y = tmp[e] * g;
+        } else {
+            const float z = tmp[e] + bias[n];
+            y = ACT == 0 ? nm_softplus100(z, nullptr) : fmaxf(z, 0.f);
+        }
+        act[row * NM_LDS_STRIDE + n] = y;
+    }
+    __syncthreads();
+}
+
+// sum_k features[idx_k][c*4..c*4+3] * w_k  (neumesh.py:11-13), k ascending
+__device__ __forceinline__ float4 nm_interp4(const float* __restrict__ table, int dim, const int* idx8, const float* w8, int chunk) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(table + (size_t)idx8[k] * dim + 4 * chunk);
+        const float wk = w8[k];
+        a.x = __fadd_rn(a.x, __fmul_rn(v.x, wk));
+        a.y = __fadd_rn(a.y, __fmul_rn(v.y, wk));
+        a.z = __fadd_rn(a.z, __fmul_rn(v.z, wk));
+        a.w = __fadd_rn(a.w, __fmul_rn(v.w, wk));
+    }
+    return a;
+}
+
+// writes x and its `bands` sin/cos bands for `dim`-wide feature vector chunk (4 values at
+// feature position 4*chunk) into an embedding that starts at row[0]
+__device__ __forceinline__ void nm_embed4(float* row, int dim, int bands, int chunk, float4 x) {
+    const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * chunk + e;
+        row[c] = xs[e];
+        float f = 1.0f;
+        for (int b = 0; b < bands; ++b) {
+            float s, co;
+            sincosf(xs[e] * f, &s, &co);
+            row[dim * (1 + 2 * b) + c] = s;
+            row[dim * (2 + 2 * b) + c] = co;
+            f *= 2.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ geometry MLP kernel
+// Points q in [0, npts): inputs ds[q], idx[q][8], w[q][8] (from the K-NN/distance kernel) and,
+// with NABLA, grad[q][3] = d ds/d xyz.  Output sdf to sdf_out[(q / P) * stride + off + q % P]
+// (P = samples per ray of this call; P = 1, stride = 1 for flat outputs) and
+// nabla_out[q][3] = (d sdf/d ds) * grad[q].
+template <bool NABLA, bool VALU_CHECK>
+__global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, const float* __restrict__ table,
+                                                            const float* __restrict__ ds, const int* __restrict__ idx,
+                                                            const float* __restrict__ w, const float* __restrict__ grad,
+                                                            long long npts, float* __restrict__ sdf_out, int P,
+                                                            int stride, int off, float* __restrict__ nabla_out,
+                                                            float* __restrict__ valu_tmp) {
+    __shared__ __attribute__((aligned(16))) float act[NM_ROWS * NM_LDS_STRIDE + NM_ROWS];
+    float* red = act + NM_ROWS * NM_LDS_STRIDE;
+    constexpr int PTS = NABLA ? 32 : 64;
+    const long long base = (long long)blockIdx.x * PTS;
+    const int Kpad0 = prm.layer[0].Kpad;
+    const int t_hi = ((prm.d_emb + 15) >> 4) << 4;  // live tangent columns, rounded to 16
+
+    // ---- prologue: build the input rows
+    for (int task = threadIdx.x; task < PTS * 8; task += 256) {
+        const int p = task >> 3, j = task & 7;
+        const long long q = base + p;
+        float* row = act + p * NM_LDS_STRIDE;
+        float* trow = act + (32 + p) * NM_LDS_STRIDE;
+        // zero padding columns (and the whole row of out-of-range points)
+        if (q >= npts) {
+            for (int c = j; c < Kpad0; c += 8) row[c] = 0.f;
+            if (NABLA) for (int c = j; c < Kpad0; c += 8) trow[c] = 0.f;
+            continue;
+        }
+        for (int c = prm.in_dim + j; c < Kpad0; c += 8) row[c] = 0.f;
+        const float dsv = ds[q];
+        if (j == 0) {
+            row[0] = dsv;
+            if (NABLA) trow[0] = 1.0f;
+        }
+        if (NABLA) for (int c = prm.d_emb + j; c < Kpad0; c += 8) trow[c] = 0.f;
+        for (int b = j; b < prm.multires_d; b += 8) {
+            const float f = (float)(1 << b);
+            float s, co;
+            sincosf(dsv * f, &s, &co);
+            row[1 + 2 * b] = s;
+            row[2 + 2 * b] = co;
+            if (NABLA) {
+                trow[1 + 2 * b] = f * co;
+                trow[2 + 2 * b] = -f * s;
+            }
+        }
+        int idx8[8];
+        float w8[8];
+        {
+            const int4 i0 = *reinterpret_cast<const int4*>(idx + q * 8), i1 = *reinterpret_cast<const int4*>(idx + q * 8 + 4);
+            const float4 w0 = *reinterpret_cast<const float4*>(w + q * 8), w1 = *reinterpret_cast<const float4*>(w + q * 8 + 4);
+            idx8[0] = i0.x; idx8[1] = i0.y; idx8[2] = i0.z; idx8[3] = i0.w;
+            idx8[4] = i1.x; idx8[5] = i1.y; idx8[6] = i1.z; idx8[7] = i1.w;
+            w8[0] = w0.x; w8[1] = w0.y; w8[2] = w0.z; w8[3] = w0.w;
+            w8[4] = w1.x; w8[5] = w1.y; w8[6] = w1.z; w8[7] = w1.w;
+        }
+        for (int chunk = j; chunk < (prm.gdim >> 2); chunk += 8) {
+            const float4 fg = nm_interp4(table, prm.gdim, idx8, w8, chunk);
+            nm_embed4(row + prm.d_emb, prm.gdim, prm.multires_fg, chunk, fg);
+        }
+    }
+    __syncthreads();
+
+    // ---- hidden layers
+    for (int l = 0; l < prm.D; ++l) {
+        const NmLayer L = prm.layer[l];
+        const int k_hi = (NABLA && l == 0) ? t_hi : L.Kpad;
+        if (VALU_CHECK) nm_mlp_layer_valu<0, NABLA>(act, valu_tmp + (size_t)blockIdx.x * NM_ROWS * NM_W, L.W, L.b, L.Kpad);
+        else nm_mlp_layer<0, NABLA>(act, L.W, L.b, L.Kpad, k_hi);
+    }
+
+    // ---- density_linear (neumesh.py:101,218): 4 threads per row, interleaved columns
+    {
+        const int row = threadIdx.x >> 2, q4 = threadIdx.x & 3;
+        const float* a = act + row * NM_LDS_STRIDE;
+        float s = 0.f;
+        for (int m = 0; m < 64; ++m) s = fmaf(a[q4 + 4 * m], prm.wd[q4 + 4 * m], s);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (q4 == 0) red[row] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < PTS) {
+        const long long q = base + threadIdx.x;
+        if (q < npts) {
+            const float sdf = red[threadIdx.x] + prm.bd;
+            if (sdf_out) sdf_out[(q / P) * stride + off + (q % P)] = sdf;
+            if (NABLA && nabla_out) {
+                const float dsdf = red[32 + threadIdx.x];
+                nabla_out[q * 3 + 0] = dsdf * grad[q * 3 + 0];
+                nabla_out[q * 3 + 1] = dsdf * grad[q * 3 + 1];
+                nabla_out[q * 3 + 2] = dsdf * grad[q * 3 + 2];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ colour MLP kernel
+// rgb[q] = sigmoid(W_rgb relu(...relu(W_0 [nabla, embed_d(ds), embed_view(dir), embed_ft(ft)] + b_0)...) + b_rgb)
+// dirs: view direction of point q is dirs[(q / dir_div) * 3 ..] (dir_div = samples per ray when
+// every sample of a ray shares the ray direction, 1 for per-point directions).
+template <bool VALU_CHECK>
+__global__ __launch_bounds__(256, 2) void nm_col_mlp_kernel(NmColParams prm, const float* __restrict__ table,
+                                                            const float* __restrict__ ds, const int* __restrict__ idx,
+                                                            const float* __restrict__ w, const float* __restrict__ nabla,
+                                                            const float* __restrict__ dirs, int dir_div, long long npts,
+                                                            float* __restrict__ rgb_out, float* __restrict__ valu_tmp) {
+    __shared__ __attribute__((aligned(16))) float act[NM_ROWS * NM_LDS_STRIDE + 3 * NM_ROWS];
+    float* red = act + NM_ROWS * NM_LDS_STRIDE;
+    const long long base = (long long)blockIdx.x * NM_ROWS;
+    const int Kpad0 = prm.layer[0].Kpad;
+    const int o_d = prm.use_nabla ? 3 : 0;             // start of embed_d
+    const int o_v = o_d + prm.d_emb;                   // start of embed_view
+    const int o_f = o_v + 3 * (1 + 2 * prm.multires_view);  // start of embed_ft
+
+    for (int task = threadIdx.x; task < NM_ROWS * 8; task += 256) {
+        const int p = task >> 3, j = task & 7;
+        const long long q = base + p;
+        float* row = act + p * NM_LDS_STRIDE;
+        if (q >= npts) {
+            for (int c = j; c < Kpad0; c += 8) row[c] = 0.f;
+            continue;
+        }
+        for (int c = prm.in_dim + j; c < Kpad0; c += 8) row[c] = 0.f;
+        const float dsv = ds[q];
+        if (j == 0) {
+            row[o_d] = dsv;
+            if (prm.use_nabla) {
+                row[0] = nabla[q * 3 + 0];
+                row[1] = nabla[q * 3 + 1];
+                row[2] = nabla[q * 3 + 2];
+            }
+        }
+        for (int b = j; b < prm.multires_d; b += 8) {
+            float s, co;
+            sincosf(dsv * (float)(1 << b), &s, &co);
+            row[o_d + 1 + 2 * b] = s;
+            row[o_d + 2 + 2 * b] = co;
+        }
+        {
+            const float* dv = dirs + (q / dir_div) * 3;
+            if (j == 1) {
+                row[o_v] = dv[0];
+                row[o_v + 1] = dv[1];
+                row[o_v + 2] = dv[2];
+            }
+            for (int e = j; e < 3 * prm.multires_view; e += 8) {
+                const int dim = e % 3, b = e / 3;
+                float s, co;
+                sincosf(dv[dim] * (float)(1 << b), &s, &co);
+                row[o_v + 3 + 6 * b + dim] = s;
+                row[o_v + 6 + 6 * b + dim] = co;
+            }
+        }
+        int idx8[8];
+        float w8[8];
+        {
+            const int4 i0 = *reinterpret_cast<const int4*>(idx + q * 8), i1 = *reinterpret_cast<const int4*>(idx + q * 8 + 4);
+            const float4 w0 = *reinterpret_cast<const float4*>(w + q * 8), w1 = *reinterpret_cast<const float4*>(w + q * 8 + 4);
+            idx8[0] = i0.x; idx8[1] = i0.y; idx8[2] = i0.z; idx8[3] = i0.w;
+            idx8[4] = i1.x; idx8[5] = i1.y; idx8[6] = i1.z; idx8[7] = i1.w;
+            w8[0] = w0.x; w8[1] = w0.y; w8[2] = w0.z; w8[3] = w0.w;
+            w8[4] = w1.x; w8[5] = w1.y; w8[6] = w1.z; w8[7] = w1.w;
+        }
+        for (int chunk = j; chunk < (prm.cdim >> 2); chunk += 8) {
+            const float4 ft = nm_interp4(table, prm.cdim, idx8, w8, chunk);
+            nm_embed4(row + o_f, prm.cdim, prm.multires_ft, chunk, ft);
+        }
+    }
+    __syncthreads();
+
+    for (int l = 0; l < prm.D; ++l) {
+        const NmLayer L = prm.layer[l];
+        if (VALU_CHECK) nm_mlp_layer_valu<1, false>(act, valu_tmp + (size_t)blockIdx.x * NM_ROWS * NM_W, L.W, L.b, L.Kpad);
+        else nm_mlp_layer<1, false>(act, L.W, L.b, L.Kpad, L.Kpad);
+    }
+
+    {
+        const int row = threadIdx.x >> 2, q4 = threadIdx.x & 3;
+        const float* a = act + row * NM_LDS_STRIDE;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int m = 0; m < 64; ++m) {
+            const float av = a[q4 + 4 * m];
+            s0 = fmaf(av, prm.wrgb[q4 + 4 * m], s0);
+            s1 = fmaf(av, prm.wrgb[256 + q4 + 4 * m], s1);
+            s2 = fmaf(av, prm.wrgb[512 + q4 + 4 * m], s2);
+        }
+        s0 += __shfl_xor(s0, 1); s0 += __shfl_xor(s0, 2);
+        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
+        s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
+        if (q4 == 0) {
+            red[3 * row] = s0;
+            red[3 * row + 1] = s1;
+            red[3 * row + 2] = s2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NM_ROWS * 3) {
+        const int p = threadIdx.x / 3, c = threadIdx.x % 3;
+        const long long q = base + p;
+        if (q < npts) {
+            const float z = red[threadIdx.x] + prm.brgb[c];
+            rgb_out[q * 3 + c] = __fdiv_rn(1.0f, 1.0f + expf(-z));
+        }
+    }
+}

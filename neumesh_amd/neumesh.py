@@ -1,0 +1,319 @@
+"""NeuMesh field -- host-side mirror of the reference's
+``models/frameworks/neumesh/neumesh.py`` (class NeuMesh, :16-273) on the HIP library.
+
+Same constructor arguments, parameter names / shapes (so the reference's checkpoints load with
+``load_state_dict`` unchanged: SURVEY.md section 5) and the same public methods:
+
+    forward(xyz, view_dirs, need_nablas=True, nablas_only=False, return_ds=False)
+    forward_density_only(xyz) / forward_with_nablas(xyz) / forward_color(...) / forward_s()
+    forward_indicator_weight() / compute_distance(xyz)
+
+Under ``torch.no_grad()`` (how render.py calls the model, render.py:209) every method is one or
+two fused HIP launches (``nm_field_density`` / ``nm_field_forward`` / ``nm_field_color``).  With
+autograd enabled (training, editing fine-tunes) the K-NN still comes from the HIP kernel and
+the remaining arithmetic is expressed with torch ops on the device, so first and second
+derivatives behave as in the reference.
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+
+import torch
+import torch.nn as nn
+from torch import autograd
+
+from . import _lib
+
+
+class Embedder(nn.Module):
+    """models/base.py:15-70 with get_embedder's settings (:73-87): [x, sin(x f), cos(x f), ...],
+    f = 2**0 .. 2**(L-1)."""
+
+    def __init__(self, input_dim: int, n_freqs: int):
+        super().__init__()
+        self.input_dim, self.n_freqs = input_dim, n_freqs
+        self.out_dim = input_dim * (1 + 2 * n_freqs)
+
+    def forward(self, x):
+        out = [x]
+        for j in range(self.n_freqs):
+            f = float(2 ** j)
+            out.append(torch.sin(x * f))
+            out.append(torch.cos(x * f))
+        return torch.cat(out, dim=-1)
+
+
+def get_embedder(multires: int, input_dim: int = 3):
+    if multires < 0:
+        return nn.Identity(), input_dim
+    e = Embedder(input_dim, multires)
+    return e, e.out_dim
+
+
+def interpolation(features, indices, weights):
+    """neumesh.py:11-13."""
+    return torch.sum(features[indices] * weights.unsqueeze(-1), dim=-2)
+
+
+def _mlp(in_dim: int, width: int, depth: int, act, wn: bool) -> nn.Sequential:
+    """Sequential(Linear, act, Sequential(Linear, act), ...) -- the nesting that produces the
+    reference's state-dict keys `<name>.0.*`, `<name>.2.0.*`, `<name>.3.0.*`, ..."""
+    def lin(i, o):
+        layer = nn.Linear(i, o)
+        return nn.utils.weight_norm(layer) if wn else layer
+    mods = [lin(in_dim, width), act()]
+    for _ in range(depth - 1):
+        mods.append(nn.Sequential(lin(width, width), act()))
+    return nn.Sequential(*mods)
+
+
+class NeuMesh(nn.Module):
+    def __init__(self, mesh_grid, D_density: int, D_color: int, W: int, geometry_dim: int, color_dim: int,
+                 multires_view: int, multires_d: int, multires_fg: int, multires_ft: int,
+                 enable_nablas_input: bool, input_view_dim=3, input_d_dim=1, ln_s=0.2996, speed_factor=1.0,
+                 learn_indicator_weight=True):
+        super().__init__()
+        if input_view_dim != 3 or input_d_dim != 1:
+            raise ValueError("NeuMesh: input_view_dim=3 and input_d_dim=1 are the only supported values")
+        self.mesh_grid = mesh_grid
+        num_vertices = mesh_grid.get_number_of_vertices()
+        self.ln_s = nn.Parameter(torch.tensor([float(ln_s)]))
+        self.speed_factor = speed_factor
+        self.geometry_features = nn.Parameter(torch.randn(num_vertices, geometry_dim))
+        self.color_features = nn.Parameter(torch.randn(num_vertices, color_dim))
+        self.indicator_vector = nn.Parameter(mesh_grid.get_vertex_normal_torch().float().clone())
+        self.learn_indicator_weight = learn_indicator_weight
+        if learn_indicator_weight:
+            self.indicator_weight_raw = nn.Parameter(torch.tensor([-2.0]))
+        self.embed_fn_d, ch_d = get_embedder(multires_d, 1)
+        self.embed_fn_view, ch_view = get_embedder(multires_view, 3)
+        self.embed_fn_fg, ch_fg = get_embedder(multires_fg, geometry_dim)
+        self.embed_fn_ft, ch_ft = get_embedder(multires_ft, color_dim)
+        self.softplus = nn.Softplus(beta=100)
+        self.pts_linears = _mlp(ch_d + ch_fg, W, D_density, lambda: self.softplus, wn=True)
+        self.enable_nablas_input = enable_nablas_input
+        ch_color = ch_view + ch_ft + ch_d + (3 if enable_nablas_input else 0)
+        self.views_linears = _mlp(ch_color, W, D_color, lambda: nn.ReLU(inplace=True), wn=False)
+        self.density_linear = nn.utils.weight_norm(nn.Linear(W, 1))
+        self.color_linear = nn.Sequential(nn.Linear(W, 3), nn.Sigmoid())
+        self._cfg = dict(W=W, D_density=D_density, D_color=D_color, geometry_dim=geometry_dim, color_dim=color_dim,
+                         multires_d=multires_d, multires_fg=multires_fg, multires_ft=multires_ft,
+                         multires_view=multires_view)
+        self._field = None        # nm_field_t
+        self._field_key = None    # parameter versions the packed weights were built from
+        self._keep = None         # tensors whose pointers the last FieldDesc referenced
+
+    # ------------------------------------------------------------------ scalars
+    def forward_s(self):
+        return torch.exp(self.ln_s * self.speed_factor)
+
+    def forward_indicator_weight(self):
+        return torch.sigmoid(self.indicator_weight_raw)
+
+    def _w1(self):
+        return self.forward_indicator_weight() if self.learn_indicator_weight else 0.1
+
+    # ------------------------------------------------------------------ HIP field handle
+    def _geo_layers(self):
+        return [self.pts_linears[0]] + [self.pts_linears[i][0] for i in range(2, len(self.pts_linears))]
+
+    def _col_layers(self):
+        return [self.views_linears[0]] + [self.views_linears[i][0] for i in range(2, len(self.views_linears))]
+
+    def _mlp_params(self):
+        ps = []
+        for m in self._geo_layers() + [self.density_linear]:
+            ps += [m.weight_g, m.weight_v, m.bias]
+        for m in self._col_layers() + [self.color_linear[0]]:
+            ps += [m.weight, m.bias]
+        return ps
+
+    def field_handle(self):
+        """nm_field_t with the current MLP weights (weight-norm folded), re-packed when they change."""
+        ps = self._mlp_params()
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._field is not None and key == self._field_key:
+            return self._field
+        lib = _lib.load()
+        dev = ps[0].device
+        if dev.type != "cuda":
+            raise _lib.NeuMeshHipError("NeuMesh parameters must live on a HIP device (model.to('cuda')); no CPU fallback")
+        with torch.no_grad():
+            def folded(m):  # W = g * v / ||v||_row  (torch.nn.utils.weight_norm, dim=0)
+                return (m.weight_v * (m.weight_g / m.weight_v.norm(dim=1, keepdim=True))).float().contiguous()
+            gw = [folded(m) for m in self._geo_layers()]
+            gb = [m.bias.detach().float().contiguous() for m in self._geo_layers()]
+            dw, db = folded(self.density_linear), self.density_linear.bias.detach().float().contiguous()
+            cw = [m.weight.detach().float().contiguous() for m in self._col_layers()]
+            cb = [m.bias.detach().float().contiguous() for m in self._col_layers()]
+            rw = self.color_linear[0].weight.detach().float().contiguous()
+            rb = self.color_linear[0].bias.detach().float().contiguous()
+        d = _lib.FieldDesc()
+        c = self._cfg
+        d.W, d.D_density, d.D_color = c["W"], c["D_density"], c["D_color"]
+        d.geometry_dim, d.color_dim = c["geometry_dim"], c["color_dim"]
+        d.multires_d, d.multires_fg, d.multires_ft, d.multires_view = c["multires_d"], c["multires_fg"], c["multires_ft"], c["multires_view"]
+        d.enable_nablas_input, d.use_view_dirs = int(self.enable_nablas_input), 1
+        for i, (w_, b_) in enumerate(zip(gw, gb)):
+            d.geo_weight[i], d.geo_bias[i] = w_.data_ptr(), b_.data_ptr()
+        for i, (w_, b_) in enumerate(zip(cw, cb)):
+            d.col_weight[i], d.col_bias[i] = w_.data_ptr(), b_.data_ptr()
+        d.density_weight, d.density_bias = dw.data_ptr(), db.data_ptr()
+        d.rgb_weight, d.rgb_bias = rw.data_ptr(), rb.data_ptr()
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream(dev)
+            if self._field is None:
+                h = C.c_void_p()
+                _lib.check(lib.nm_field_create(C.byref(d), stream, C.byref(h)), "nm_field_create")
+                self._field = h
+            else:
+                _lib.check(lib.nm_field_update(self._field, C.byref(d), stream), "nm_field_update")
+        self._keep = (gw, gb, dw, db, cw, cb, rw, rb)  # the pack call synchronised; kept for clarity
+        self._field_key = key
+        return self._field
+
+    def field_tables(self, color_features=None):
+        """nm_field_tables for the current codes / scalars (borrowed pointers; returns the struct
+        and the tensors that must stay alive while it is in use)."""
+        gf = self.geometry_features.detach().float().contiguous()
+        cf = (self.color_features if color_features is None else color_features).detach().float().contiguous()
+        iv = self.indicator_vector.detach().float().contiguous()
+        t = _lib.FieldTables()
+        t.geometry_features, t.color_features, t.indicator_vector = gf.data_ptr(), cf.data_ptr(), iv.data_ptr()
+        t.indicator_weight = float(self._w1())
+        t.s = float(self.forward_s())
+        return t, (gf, cf, iv)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_field", None):
+                _lib.load(require_device=False).nm_field_destroy(self._field)
+                self._field = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ fused (no-grad) paths
+    def _fused_density(self, xyz, want_nabla: bool):
+        lib = _lib.load()
+        q = xyz.detach().float().reshape(-1, 3).contiguous()
+        P = q.shape[0]
+        sdf = torch.empty((P,), dtype=torch.float32, device=q.device)
+        nab = torch.empty((P, 3), dtype=torch.float32, device=q.device) if want_nabla else None
+        scratch = torch.empty((int(lib.nm_field_scratch_bytes(P)),), dtype=torch.uint8, device=q.device)
+        t, keep = self.field_tables()
+        with torch.cuda.device(q.device):
+            _lib.check(lib.nm_field_density(self.field_handle(), self.mesh_grid.grid.handle, C.byref(t), _lib.ptr(q), P,
+                                            _lib.ptr(sdf), _lib.ptr(nab), _lib.ptr(scratch), _lib.current_stream(q.device)),
+                       "nm_field_density")
+        del keep
+        return sdf.reshape(*xyz.shape[:-1], 1), (None if nab is None else nab.reshape(xyz.shape))
+
+    def _fused_forward(self, xyz, view_dirs, want_ds: bool):
+        lib = _lib.load()
+        q = xyz.detach().float().reshape(-1, 3).contiguous()
+        v = view_dirs.detach().float().expand_as(xyz).reshape(-1, 3).contiguous()
+        P, dev = q.shape[0], q.device
+        sdf = torch.empty((P,), dtype=torch.float32, device=dev)
+        rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        nab = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        ds = torch.empty((P,), dtype=torch.float32, device=dev) if want_ds else None
+        idx = torch.empty((P, 8), dtype=torch.int64, device=dev) if want_ds else None
+        w = torch.empty((P, 8), dtype=torch.float32, device=dev) if want_ds else None
+        scratch = torch.empty((int(lib.nm_field_scratch_bytes(P)),), dtype=torch.uint8, device=dev)
+        t, keep = self.field_tables()
+        with torch.cuda.device(dev):
+            _lib.check(lib.nm_field_forward(self.field_handle(), self.mesh_grid.grid.handle, C.byref(t), _lib.ptr(q), _lib.ptr(v), P,
+                                            _lib.ptr(sdf), _lib.ptr(rgb), _lib.ptr(nab), _lib.ptr(ds), _lib.ptr(idx), _lib.ptr(w),
+                                            _lib.ptr(scratch), _lib.current_stream(dev)), "nm_field_forward")
+        del keep
+        lead = xyz.shape[:-1]
+        out = (sdf.reshape(*lead, 1), rgb.reshape(*lead, 3), nab.reshape(*lead, 3))
+        if want_ds:
+            out = out + (ds.reshape(*lead, 1), idx.reshape(*lead, 8), w.reshape(*lead, 8))
+        return out
+
+    # ------------------------------------------------------------------ public API (reference names)
+    def compute_distance(self, xyz):
+        """neumesh.py:262-273."""
+        ds, indices, weights = self.mesh_grid.compute_distance(
+            xyz.reshape(-1, 3), indicator_vector=self.indicator_vector, indicator_weight=self._w1())
+        lead = xyz.shape[:-1]
+        return ds.reshape(*lead, -1), indices.reshape(*lead, -1), weights.reshape(*lead, -1)
+
+    def forward_density_only(self, xyz):
+        """neumesh.py:140-145."""
+        if not torch.is_grad_enabled():
+            return self._fused_density(xyz, False)[0]
+        ds, indices, weights = self.compute_distance(xyz)
+        return self._forward_density(xyz, ds, self.geometry_features, indices, weights, need_nablas=False)[0]
+
+    def forward_with_nablas(self, xyz):
+        """neumesh.py:147-154."""
+        if not torch.is_grad_enabled():
+            return self._fused_density(xyz, True)
+        xyz.requires_grad_(True)
+        with torch.enable_grad():
+            ds, indices, weights = self.compute_distance(xyz)
+        density, nablas, _ = self._forward_density(xyz, ds, self.geometry_features, indices, weights, need_nablas=True)
+        return density, nablas
+
+    def forward(self, xyz, view_dirs, need_nablas=True, nablas_only=False, return_ds=False):
+        """neumesh.py:113-138."""
+        if not torch.is_grad_enabled() and need_nablas:
+            sdf, rgb, nab, *rest = self._fused_forward(xyz, view_dirs, return_ds)
+            out = (sdf, nab) if nablas_only else (sdf, rgb)
+            return out + tuple(rest)
+        if need_nablas:
+            xyz.requires_grad_(True)
+        with (torch.enable_grad() if need_nablas else contextlib.nullcontext()):
+            ds, indices, weights = self.compute_distance(xyz)
+        density, nablas, d_emb = self._forward_density(xyz, ds, self.geometry_features, indices, weights, need_nablas=need_nablas)
+        out = (density, nablas) if nablas_only else (
+            density, self._forward_color(d_emb, view_dirs, self.color_features, indices, weights, nablas))
+        if return_ds:
+            out = out + (ds, indices, weights)
+        return out
+
+    def forward_color(self, d, view_dirs, color_features, indices=None, weights=None, nabla=None):
+        """neumesh.py:156-168."""
+        if not torch.is_grad_enabled():
+            lib = _lib.load()
+            lead = d.shape[:-1]
+            dd = d.detach().float().reshape(-1).contiguous()
+            P, dev = dd.shape[0], dd.device
+            v = view_dirs.detach().float().reshape(-1, 3).contiguous()
+            ii = indices.detach().reshape(-1, 8).to(torch.int64).contiguous()
+            ww = weights.detach().float().reshape(-1, 8).contiguous()
+            nn_ = None if nabla is None else nabla.detach().float().reshape(-1, 3).contiguous()
+            cf = color_features.detach().float().contiguous()
+            rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
+            scratch = torch.empty((int(lib.nm_field_scratch_bytes(P)),), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.nm_field_color(self.field_handle(), _lib.ptr(cf), _lib.ptr(dd), _lib.ptr(v), _lib.ptr(ii), _lib.ptr(ww),
+                                              _lib.ptr(nn_), P, _lib.ptr(rgb), _lib.ptr(scratch), _lib.current_stream(dev)),
+                           "nm_field_color")
+            return rgb.reshape(*lead, 3)
+        return self._forward_color(self.embed_fn_d(d), view_dirs, color_features, indices, weights, nabla)
+
+    # ------------------------------------------------------------------ autograd (torch-op) paths
+    def _forward_density(self, xyz, d, geometry_features, indices, weights, need_nablas=False):
+        """neumesh.py:204-237 in torch ops (used when autograd is on)."""
+        with (torch.enable_grad() if need_nablas else contextlib.nullcontext()):
+            d_emb = self.embed_fn_d(d)
+            fg_emb = self.embed_fn_fg(interpolation(geometry_features, indices, weights))
+            density = self.density_linear(self.pts_linears(torch.cat([d_emb, fg_emb], dim=-1)))
+        if not need_nablas:
+            return density, torch.zeros_like(density), d_emb
+        has_grad = torch.is_grad_enabled()
+        nabla = autograd.grad(density, xyz, torch.ones_like(density), create_graph=has_grad, retain_graph=has_grad,
+                              only_inputs=True)[0]
+        if not has_grad:
+            nabla = nabla.detach()
+        return density, nabla, d_emb
+
+    def _forward_color(self, d_emb, view_dirs, color_features, indices=None, weights=None, nabla=None):
+        """neumesh.py:239-260 in torch ops."""
+        parts = [nabla] if self.enable_nablas_input else []
+        parts += [d_emb, self.embed_fn_view(view_dirs), self.embed_fn_ft(interpolation(color_features, indices, weights))]
+        return self.color_linear(self.views_linears(torch.cat(parts, dim=-1)))

@@ -6,7 +6,8 @@ Why per-sample arrays cannot be compared index-by-index
 (u = 1.0) is placed by `searchsorted(cdf, 1.0)`, i.e. by whether the fp32 running sum
 `cdf[-1]` rounded to >= 1.0 or to < 1.0, and -- because the last bin's pdf is < eps=1e-5 for
 practically every ray, which triggers `denom[denom < eps] = 1` -- the sample lands either ON
-`bins[-1]` or ON `bins[-2]`.  Both are positions that are already in the sample list, so the
+`bins[-1]`, ON `bins[-2]`, or (pdf of the last bin just above eps) a fraction
+(cdf[-1]-1)/pdf_last before `bins[-1]`.  All of these lie inside the last, ~zero-weight bin, so the
 rendered pixel does not change (measured 2e-7 on RGB), but which duplicate appears depends on
 the summation order of `torch.sum`/`torch.cumsum` (CPU: float64 accumulator, sequential; CUDA:
 fp32 parallel scan).  The reference itself is therefore not reproducible across its own

@@ -72,14 +72,14 @@ def oracle_from_reference(model, mesh):
     return ofield.OracleField(mesh.vertices, {k: v for k, v in model.state_dict().items()}, cfg)
 
 
-def gen_field_fixture(tag, V, Q, seed, dup=0):
+def gen_field_fixture(tag, V, Q, seed, dup=0, mlp_state=None):
     import torch
     print(f"[{tag}] V={V} Q={Q}")
     mesh = synthetic.fibonacci_blob(V)
     if dup:  # duplicated vertices -> exact distance ties, resolved by vertex index
         mesh = synthetic.SyntheticMesh(np.concatenate([mesh.vertices, mesh.vertices[:dup]]),
                                        np.concatenate([mesh.vertex_normals, mesh.vertex_normals[:dup]]))
-    model, kw, renderer, _ = harness.build_reference(mesh, seed=0)
+    model, kw, renderer, _ = harness.build_reference(mesh, seed=0, mlp_state=mlp_state)
     orc = oracle_from_reference(model, mesh)
     q = query_points(mesh, Q, seed)
     dirs = orender.normalize(np.random.default_rng(seed + 1).standard_normal((Q, 3)).astype(np.float32))
@@ -118,11 +118,11 @@ def gen_field_fixture(tag, V, Q, seed, dup=0):
     return model
 
 
-def gen_render_fixture(tag, V, H, W, frame, seed=0, white_bkgd=False, n_samples=64):
+def gen_render_fixture(tag, V, H, W, frame, seed=0, white_bkgd=False, n_samples=64, mlp_state=None):
     import torch
     print(f"[{tag}] V={V} rays={H * W}")
     mesh = synthetic.fibonacci_blob(V)
-    model, kw, renderer, _ = harness.build_reference(mesh, seed=seed)
+    model, kw, renderer, _ = harness.build_reference(mesh, seed=seed, mlp_state=mlp_state)
     orc = oracle_from_reference(model, mesh)
     # a patch of a larger virtual image so that the rays actually graze / hit / miss the object
     big = 48
@@ -198,9 +198,9 @@ def main():
     sd = {k: v.detach().numpy() for k, v in model.state_dict().items()
           if k not in ("geometry_features", "color_features", "indicator_vector")}
     np.savez_compressed(os.path.join(GOLDEN, "model_seed0.npz"), **sd)
-    gen_field_fixture("field_dup_v1200", V=1200, Q=512, seed=12, dup=64)
-    gen_render_fixture("render_v3000_dtu", V=3000, H=6, W=12, frame=3)
-    gen_render_fixture("render_v3000_lego", V=3000, H=4, W=12, frame=17, white_bkgd=True, n_samples=32)
+    gen_field_fixture("field_dup_v1200", V=1200, Q=512, seed=12, dup=64, mlp_state=sd)
+    gen_render_fixture("render_v3000_dtu", V=3000, H=6, W=12, frame=3, mlp_state=sd)
+    gen_render_fixture("render_v3000_lego", V=3000, H=4, W=12, frame=17, white_bkgd=True, n_samples=32, mlp_state=sd)
     with open(os.path.join(GOLDEN, "REPORT.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
     print("all oracle-vs-reference checks passed; fixtures written to", GOLDEN)

@@ -30,7 +30,7 @@ def _activate():
 
 
 def build_reference(mesh, seed: int = 0, s_value: float = 200.0, geometry_seed: int = 1,
-                    color_seed: int = 2, indicator_seed: int = 3, overrides=None):
+                    color_seed: int = 2, indicator_seed: int = 3, overrides=None, mlp_state=None):
     """Returns (model, render_kwargs_test, renderer, args) built by the reference's own factory.
 
     mesh: neumesh_amd.synthetic.SyntheticMesh.  Weights: torch default init under
@@ -60,6 +60,11 @@ def build_reference(mesh, seed: int = 0, s_value: float = 200.0, geometry_seed: 
     torch.manual_seed(seed)
     model, _trainer, _kw_train, kw_test, renderer = build_framework(args, "NeuMesh")
     V = mesh.num_vertices
+    if mlp_state is not None:
+        # the reference ctor draws the codes before the Linear layers, so its default-init MLP
+        # weights depend on V through the RNG stream; fixtures share ONE weight set instead
+        res = model.load_state_dict({k: torch.as_tensor(v) for k, v in mlp_state.items()}, strict=False)
+        assert not res.unexpected_keys
     with torch.no_grad():
         model.geometry_features.copy_(torch.from_numpy(synthetic.random_codes(V, model.geometry_features.shape[1], geometry_seed)))
         model.color_features.copy_(torch.from_numpy(synthetic.random_codes(V, model.color_features.shape[1], color_seed)))

@@ -1,0 +1,63 @@
+"""CPU: the C-ABI library loads and exports exactly what include/neumesh_hip.h declares; the
+product path fails loudly without a GPU and never imports the oracle.  No compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import common  # noqa: F401  (sys.path)
+from neumesh_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "neumesh_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(nm_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_builds_for_gfx950():
+    path = build.build()
+    assert os.path.exists(path)
+    assert "--offload-arch=gfx950" in build.FLAGS and "-ffp-contract=off" in build.FLAGS
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 18
+    lib = ctypes.CDLL(build.build())
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in neumesh_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} declared but not bound in neumesh_amd/_lib.py"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_abi_version_and_error_string():
+    lib = _lib.load(require_device=False)
+    assert lib.nm_abi_version() == _lib.ABI_VERSION
+    assert isinstance(lib.nm_last_error(), bytes)
+
+
+def test_fails_loudly_without_gpu():
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(_lib.NeuMeshHipError, match="no CPU fallback"):
+        _lib.load()
+    from neumesh_amd.mesh_grid import GridHandle
+    with pytest.raises(_lib.NeuMeshHipError):
+        GridHandle(torch.zeros(10, 3))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "neumesh_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert not re.search(r"^\s*(from|import)\s+\S*hostcheck", src, flags=re.M), f
+                assert not re.search(r"#include\s+\"[^\"]*(oracle|hostcheck)", src), f
+                assert not re.search(r"(CDLL|dlopen)\([^)]*(oracle|hostcheck)", src), f

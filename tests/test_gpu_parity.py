@@ -1,0 +1,284 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI (ctypes), against the golden fixtures
+(= the reference's own outputs) and the oracle, plus size-independent properties at the
+BASELINE.json sizes.  Tolerances: K-NN indices / squared distances bit-exact; everything
+floating point within the 1e-4 RGB bound of BASELINE.json:north_star (most stages are 1e-6)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import common
+from oracle import compare, knn as oknn, render as orender
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    return torch
+
+
+@pytest.fixture(scope="module")
+def small(cuda_device):
+    mesh = common.scene_mesh(3000)
+    state = common.scene_state(mesh)
+    return mesh, state, common.make_model(mesh, state, cuda_device)
+
+
+@pytest.fixture(scope="module")
+def dtu_scale(cuda_device):
+    mesh = common.scene_mesh(140000)
+    state = common.scene_state(mesh)
+    return mesh, state, common.make_model(mesh, state, cuda_device)
+
+
+def _t(a, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_native_library_is_the_one_in_tree(cuda_device):
+    from neumesh_amd import _lib, build
+    lib = _lib.load()
+    assert lib.nm_device_count() >= 1
+    assert build.LIB_PATH.endswith("neumesh_amd/csrc/libneumesh_hip.so")
+    assert any("libneumesh_hip.so" in line for line in open("/proc/self/maps"))
+
+
+# --------------------------------------------------------------------------------- K-NN
+@pytest.mark.parametrize("K", [1, 3, 8, 16, 32])
+def test_knn_bit_exact_vs_oracle(small, cuda_device, K):
+    from neumesh_amd.mesh_grid import knn
+    mesh, _, model = small
+    fx = common.golden("field_v3000")
+    idx, d2 = knn(model.mesh_grid.grid, _t(fx["q"], cuda_device), K)
+    ridx, rd2 = oknn.knn_bruteforce(fx["q"], mesh.vertices, K)
+    assert idx.dtype == np.int64 or str(idx.dtype) == "torch.int64"
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    assert np.array_equal(d2.cpu().numpy(), rd2)
+    if K == 8:
+        assert np.array_equal(idx.cpu().numpy(), fx["idx"]) and np.array_equal(d2.cpu().numpy(), fx["d2"])
+
+
+def test_knn_duplicate_vertices_ties_by_index(cuda_device):
+    from neumesh_amd.mesh_grid import knn
+    fx = common.golden("field_dup_v1200")
+    mesh = common.scene_mesh(1200, 64)
+    model = common.make_model(mesh, common.scene_state(mesh), cuda_device)
+    idx, d2 = knn(model.mesh_grid.grid, _t(fx["q"], cuda_device), 8)
+    assert np.array_equal(idx.cpu().numpy(), fx["idx"]) and np.array_equal(d2.cpu().numpy(), fx["d2"])
+
+
+def test_knn_fewer_vertices_than_K_pads_minus_one(cuda_device, torch_mod):
+    from neumesh_amd import frnn
+    torch = torch_mod
+    v = torch.randn(1, 5, 3, device=cuda_device)
+    q = torch.randn(1, 64, 3, device=cuda_device)
+    d2, idx, _, grid = frnn.frnn_grid_points(q, v, None, None, K=8, r=100.0, grid=None, return_nn=False, return_sorted=True)
+    ridx, rd2 = oknn.knn_bruteforce(q[0].cpu().numpy(), v[0].cpu().numpy(), 8)
+    assert np.array_equal(idx[0].cpu().numpy(), ridx) and np.array_equal(d2[0].cpu().numpy(), rd2)
+    assert (idx[0, :, 5:] == -1).all()
+    d2b, idxb, _, grid2 = frnn.frnn_grid_points(q, v, None, None, K=4, r=100.0, grid=grid)   # cached grid, like mesh_grid.py:109-119
+    assert grid2 is grid and np.array_equal(idxb[0].cpu().numpy(), ridx[:, :4])
+    d2c, idxc, _, _ = frnn.frnn_grid_points(q, v, None, None, K=4, r=0.5, grid=grid)         # finite radius -> -1 padding
+    assert ((d2c[0] > 0.25) == False).all() and ((idxc[0] == -1) == (d2c[0] == -1)).all()  # noqa: E712
+
+
+def test_knn_empty_and_ragged_sizes(small, cuda_device, torch_mod):
+    from neumesh_amd.mesh_grid import knn
+    mesh, _, model = small
+    idx, d2 = knn(model.mesh_grid.grid, torch_mod.zeros((0, 3), device=cuda_device), 8)
+    assert idx.shape == (0, 8)
+    rng = np.random.default_rng(5)
+    for Q in (1, 63, 257, 1000):
+        q = rng.uniform(-1, 1, (Q, 3)).astype(np.float32)
+        idx, d2 = knn(model.mesh_grid.grid, _t(q, cuda_device), 8)
+        ridx, rd2 = oknn.knn_bruteforce(q, mesh.vertices, 8)
+        assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d2.cpu().numpy(), rd2)
+
+
+def test_knn_dtu_scale_vs_oracle_and_properties(dtu_scale, cuda_device, torch_mod):
+    """V = 1.4e5 (BASELINE.json config 2 shape): bit-exact vs brute force on 20 k queries of every
+    regime; on 2 M queries the size-independent properties (sorted, consistent, deterministic)."""
+    from neumesh_amd.mesh_grid import knn
+    torch = torch_mod
+    mesh, _, model = dtu_scale
+    rng = np.random.default_rng(9)
+    V = mesh.num_vertices
+    q = np.concatenate([mesh.vertices[rng.integers(0, V, 10000)] + 0.01 * rng.standard_normal((10000, 3)),
+                        mesh.vertices[rng.integers(0, V, 5000)] + 0.2 * rng.standard_normal((5000, 3)),
+                        rng.uniform(-2, 2, (4990, 3)), mesh.vertices[:10]]).astype(np.float32)
+    idx, d2 = knn(model.mesh_grid.grid, _t(q, cuda_device), 8)
+    ridx, rd2 = oknn.knn_bruteforce(q, mesh.vertices, 8)
+    assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d2.cpu().numpy(), rd2)
+    Q = 1 << 21
+    g = torch.Generator(device="cpu").manual_seed(1)
+    big = (torch.from_numpy(mesh.vertices)[torch.randint(0, V, (Q,), generator=g)] + 0.05 * torch.randn(Q, 3, generator=g)).to(cuda_device)
+    idx, d2 = knn(model.mesh_grid.grid, big, 8)
+    idx2, d22 = knn(model.mesh_grid.grid, big, 8)
+    assert torch.equal(idx, idx2) and torch.equal(d2, d22)                       # deterministic
+    assert bool((d2[:, 1:] >= d2[:, :-1]).all())                                 # ascending
+    ties = d2[:, 1:] == d2[:, :-1]
+    assert bool((idx[:, 1:][ties] > idx[:, :-1][ties]).all())                   # ties by index
+    verts = torch.from_numpy(mesh.vertices).to(cuda_device)
+    diff = big[:, None, :] - verts[idx]
+    rec = (diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]) + diff[..., 2] * diff[..., 2]
+    assert torch.equal(rec, d2)                                                  # d2 is the declared arithmetic
+    assert int(idx.min()) >= 0 and int(idx.max()) < V
+    assert bool((idx.sort(dim=1).values[:, 1:] != idx.sort(dim=1).values[:, :-1]).all())  # 8 distinct vertices
+
+
+# ------------------------------------------------------------------------------- field
+def test_compute_distance_matches_reference(small, cuda_device, torch_mod):
+    _, _, model = small
+    fx = common.golden("field_v3000")
+    q = _t(fx["q"], cuda_device)
+    with torch_mod.no_grad():
+        ds, idx, w = model.compute_distance(q)
+        ds2, _, _, g = model.mesh_grid.compute_distance_frnn(q, 8, model.indicator_vector, 0.1, want_grad=True)
+    assert tuple(ds.shape) == (len(fx["q"]), 1) and str(idx.dtype) == "torch.int64"
+    assert np.array_equal(idx.cpu().numpy(), fx["idx"])
+    np.testing.assert_allclose(ds.cpu().numpy(), fx["ds"], atol=3e-6)
+    np.testing.assert_allclose(w.cpu().numpy(), fx["w"], atol=1e-6)
+    np.testing.assert_allclose(g.cpu().numpy(), fx["dds_dx"], atol=2e-5, rtol=2e-5)
+    assert torch_mod.equal(ds, ds2)
+
+
+def test_field_methods_match_reference(small, cuda_device, torch_mod):
+    torch = torch_mod
+    _, _, model = small
+    fx = common.golden("field_v3000")
+    q, dirs = _t(fx["q"], cuda_device), _t(fx["dirs"], cuda_device)
+    tol_nab = 5e-6 + 2e-4 * np.abs(fx["ds"])   # fp32 sensitivity of the 2^7-band d-embedding, see oracle/gen_golden.py
+    with torch.no_grad():
+        sdf = model.forward_density_only(q)
+        sdf2, nab = model.forward_with_nablas(q)
+        sdf3, rgb, ds, idx, w = model.forward(q, dirs, return_ds=True)
+        sdf4, nab2 = model.forward(q, dirs, nablas_only=True)
+        rgb2 = model.forward_color(ds, dirs, model.color_features, idx, w, nab)
+    np.testing.assert_allclose(sdf.cpu().numpy(), fx["sdf"], atol=3e-6)
+    assert torch.equal(sdf, sdf2) and torch.equal(sdf, sdf3) and torch.equal(sdf, sdf4)   # one value per point, whatever the path
+    assert np.all(np.abs(nab.cpu().numpy() - fx["nabla"]) <= tol_nab)
+    assert torch.equal(nab, nab2)
+    np.testing.assert_allclose(rgb.cpu().numpy(), fx["rgb"], atol=3e-6)
+    assert torch.equal(rgb, rgb2)
+    assert np.array_equal(idx.cpu().numpy(), fx["idx"])
+    assert abs(float(model.forward_s()) - float(fx["s"])) < 1e-3
+
+
+def test_mfma_tile_code_equals_scalar_alu_reference(small, cuda_device, torch_mod):
+    """Device cross-check of the MFMA fragment layout: same kernel with the layer computed by a
+    plain per-thread fmaf loop (asymmetric weights/activations => a transposed tile would fail)."""
+    torch = torch_mod
+    from neumesh_amd import _lib
+    lib = _lib.load()
+    _, _, model = small
+    fx = common.golden("field_v3000")
+    q, dirs = _t(fx["q"], cuda_device), _t(fx["dirs"], cuda_device)
+    P = q.shape[0]
+    sdf, nab, rgb = torch.empty(P, device=cuda_device), torch.empty(P, 3, device=cuda_device), torch.empty(P, 3, device=cuda_device)
+    scratch = torch.empty(int(lib.nm_field_scratch_bytes(P)), dtype=torch.uint8, device=cuda_device)
+    tmp = torch.empty((P + 31) // 32 * 64 * 256, device=cuda_device)
+    t, keep = model.field_tables()
+    _lib.check(lib.nm_selfcheck_field(model.field_handle(), model.mesh_grid.grid.handle, C.byref(t), _lib.ptr(q), _lib.ptr(dirs), P,
+                                      _lib.ptr(sdf), _lib.ptr(nab), _lib.ptr(rgb), _lib.ptr(scratch), _lib.ptr(tmp),
+                                      _lib.current_stream(cuda_device)), "nm_selfcheck_field")
+    with torch.no_grad():
+        sdf_m, rgb_m = model.forward(q, dirs)
+        _, nab_m = model.forward_with_nablas(q)
+    near = np.abs(fx["ds"][:, 0]) < 0.2
+    np.testing.assert_allclose(sdf_m[:, 0].cpu().numpy(), sdf.cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(rgb_m.cpu().numpy(), rgb.cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(nab_m.cpu().numpy()[near], nab.cpu().numpy()[near], atol=1e-5)
+
+
+def test_autograd_path_matches_fused_path(small, cuda_device, torch_mod):
+    """Training-style call (grad enabled): HIP K-NN + torch ops; must agree with the fused kernels."""
+    torch = torch_mod
+    _, _, model = small
+    fx = common.golden("field_v3000")
+    q, dirs = _t(fx["q"][:512], cuda_device), _t(fx["dirs"][:512], cuda_device)
+    sdf_a, rgb_a = model.forward(q.clone(), dirs)
+    sdf_b, nab_a = model.forward_with_nablas(q.clone())
+    assert sdf_a.requires_grad and nab_a.requires_grad
+    with torch.no_grad():
+        sdf_f, rgb_f = model.forward(q, dirs)
+        _, nab_f = model.forward_with_nablas(q)
+    near = np.abs(fx["ds"][:512, 0]) < 0.2
+    np.testing.assert_allclose(sdf_a.detach().cpu().numpy(), sdf_f.cpu().numpy(), atol=3e-6)
+    np.testing.assert_allclose(rgb_a.detach().cpu().numpy(), rgb_f.cpu().numpy(), atol=3e-6)
+    np.testing.assert_allclose(nab_a.detach().cpu().numpy()[near], nab_f.cpu().numpy()[near], atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- renderer
+@pytest.mark.parametrize("tag", ["render_v3000_dtu", "render_v3000_lego"])
+def test_render_matches_reference_fixture(small, cuda_device, torch_mod, tag):
+    torch = torch_mod
+    from neumesh_amd import SingleRenderer
+    _, _, model = small
+    rf = common.golden(tag)
+    ns = int(rf["N_samples"])
+    renderer = SingleRenderer(model)
+    kw = dict(batched=True, calc_normal=bool(rf["calc_normal"]), white_bkgd=bool(rf["white_bkgd"]), N_samples=ns, N_importance=ns,
+              rayschunk=4096, perturb=False, N_nograd_samples=2048, N_upsample_iters=4, obj_bounding_radius=1.0, bounded_near_far=True,
+              H=6, W=12)   # unknown kwargs are swallowed like the reference's **dummy_kwargs
+    ro, rd = _t(rf["rays_o"], cuda_device)[None], _t(rf["rays_d"], cuda_device)[None]
+    with torch.no_grad():
+        rgb, depth, ex = renderer(ro, rd, detailed_output=True, **kw)
+        rgb_b, depth_b, ex_b = renderer(ro, rd, detailed_output=False, **{**kw, "rayschunk": 7})
+    assert tuple(rgb.shape) == (1, len(rf["rays_o"]), 3) and tuple(depth.shape) == (1, len(rf["rays_o"]))
+    assert set(ex_b.keys()) == {"rgb", "depth_volume", "mask_volume"} | ({"normals_volume"} if rf["calc_normal"] else set())
+    for k in ("implicit_surface", "radiance", "alpha", "cdf", "visibility_weights", "d_final"):
+        assert k in ex
+    assert torch.equal(rgb, rgb_b) and torch.equal(depth, depth_b)      # chunk size never changes a pixel
+    e = {k: v[0].cpu().numpy() for k, v in ex.items()}
+    np.testing.assert_allclose(e["rgb"], rf["rgb"], atol=1e-4)          # BASELINE.json: RGB within 1e-4
+    np.testing.assert_allclose(e["depth_volume"], rf["depth_volume"], atol=1e-4)
+    np.testing.assert_allclose(e["mask_volume"], rf["mask_volume"], atol=1e-4)
+    if rf["calc_normal"]:
+        np.testing.assert_allclose(e["normals_volume"], rf["normals_volume"], atol=1e-4)
+    np.testing.assert_allclose(e["near_far"], np.concatenate([rf["near"], rf["far"]], 1), atol=2e-6)
+    assert compare.psnr(e["rgb"], rf["rgb"]) > 100.0
+    worst, unmatched = compare.depth_set_distance(e["d_all"], rf["d_all"])
+    assert unmatched < 0.10 and worst < 5e-3                              # oracle/compare.py explains these two
+    # the field values the renderer used, on bit-identical sample points, equal the reference's
+    dirn = orender.normalize(rf["rays_d"])
+    pts = (rf["rays_o"][:, None, :] + dirn[:, None, :] * e["d_all"][..., None]).astype(np.float32)
+    rpts = (rf["rays_o"][:, None, :] + dirn[:, None, :] * rf["d_all"][..., None]).astype(np.float32)
+    err, frac = compare.max_err_matched_by_depth(e["d_all"], e["implicit_surface"], rf["d_all"], rf["implicit_surface"], tol_d=0.0)
+    del pts, rpts
+    assert frac > 0.5 and err < 5e-6
+
+
+def test_render_frame_properties_dtu_scale(dtu_scale, cuda_device, torch_mod):
+    """800x800-shape workload on the V=1.4e5 scene: a 64x64 window of the frame. Size-independent
+    properties: finite, 0<=acc<=1+eps, chunk invariance, determinism; 96 rays against the oracle."""
+    torch = torch_mod
+    from neumesh_amd import synthetic
+    from neumesh_amd.renderer import volume_render
+    mesh, state, model = dtu_scale
+    H = W = 800
+    c2w, K = synthetic.orbit_pose(5), synthetic.pinhole_intrinsics(H, W)
+    rows = np.arange(368, 432)
+    pix = (rows[:, None] * W + np.arange(368, 432)[None, :]).reshape(-1)
+    o, d = synthetic.camera_rays(c2w, K, H, W)
+    o, d = o[pix], d[pix]
+    kw = dict(calc_normal=True, N_samples=64, N_importance=64, perturb=False, detailed_output=False)
+    with torch.no_grad():
+        rgb, depth, ex = volume_render(_t(o, cuda_device), _t(d, cuda_device), model, rayschunk=4096, **kw)
+        rgb2, depth2, ex2 = volume_render(_t(o, cuda_device), _t(d, cuda_device), model, rayschunk=1000, **kw)
+    assert torch.equal(rgb, rgb2) and torch.equal(depth, depth2) and torch.equal(ex["normals_volume"], ex2["normals_volume"])
+    assert bool(torch.isfinite(rgb).all()) and bool(torch.isfinite(depth).all())
+    acc = ex["mask_volume"]
+    assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5
+    assert float(rgb.min()) >= 0.0 and float(rgb.max()) <= 1.0 + 1e-5
+    # oracle (kd-tree K-NN, checked == brute force in tests/test_oracle.py) on a strided subset
+    sub = np.arange(0, len(pix), 43)[:96]
+    orc = common.make_oracle(mesh, state)
+    orc.knn_fn = oknn.knn_kdtree
+    out = orender.render_rays(orc, o[sub], d[sub], orender.RenderConfig(calc_normal=True))
+    np.testing.assert_allclose(rgb.cpu().numpy()[sub], out["rgb"], atol=1e-4)
+    np.testing.assert_allclose(acc.cpu().numpy()[sub], out["mask_volume"], atol=1e-4)
+    np.testing.assert_allclose(depth.cpu().numpy()[sub], out["depth_volume"], atol=2e-4)
+    assert compare.psnr(rgb.cpu().numpy()[sub], out["rgb"]) > 90.0

@@ -1,0 +1,118 @@
+"""CPU: host-side logic of the package (PLY reader, state-dict layout, factory kwargs, ray
+sharding incl. a world_size-2 gloo run)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import common
+from neumesh_amd import ply, synthetic
+from neumesh_amd.sharded import pack_outputs, shard_range, unpack_outputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_ply_roundtrip_binary_and_ascii(tmp_path):
+    mesh = synthetic.fibonacci_blob(200)
+    tris = np.stack([np.arange(0, 198), np.arange(1, 199), np.arange(2, 200)], 1)
+    p = str(tmp_path / "m.ply")
+    ply.write_ply(p, mesh.vertices, tris, mesh.vertex_normals)
+    m = ply.read_ply(p)
+    np.testing.assert_allclose(m.vertices, mesh.vertices, atol=0)
+    np.testing.assert_allclose(m.vertex_normals, mesh.vertex_normals, atol=0)
+    assert np.array_equal(m.triangles, tris)
+    a = str(tmp_path / "a.ply")
+    with open(a, "w") as f:
+        f.write("ply\nformat ascii 1.0\ncomment x\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+                "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n1 1 0\n0 1 0\n4 0 1 2 3\n")
+    m = ply.read_ply(a).compute_vertex_normals()
+    assert m.triangles.shape == (2, 3)
+    np.testing.assert_allclose(m.vertex_normals, np.tile([[0, 0, 1.0]], (4, 1)), atol=1e-12)
+
+
+def test_state_dict_layout_matches_reference_checkpoints():
+    torch = pytest.importorskip("torch")
+    from neumesh_amd.neumesh import NeuMesh
+    mesh = common.scene_mesh(3000)
+
+    class FakeGrid:
+        def get_number_of_vertices(self):
+            return 3000
+
+        def get_vertex_normal_torch(self):
+            return torch.from_numpy(mesh.vertex_normals)
+
+    m = NeuMesh(FakeGrid(), **common.MODEL_CFG)
+    st = common.scene_state(mesh)   # keys come from the REFERENCE's state_dict (gen_golden.py)
+    res = m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in st.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    m2 = NeuMesh(FakeGrid(), **{**common.MODEL_CFG, "learn_indicator_weight": True})
+    assert "indicator_weight_raw" in m2.state_dict()
+    # torch-op (autograd) path == reference fixture when fed the fixture's K-NN (CPU, exact same ops)
+    fx = common.golden("field_v3000")
+    q = torch.from_numpy(fx["q"]).requires_grad_(True)
+    idx, w = torch.from_numpy(fx["idx"].astype(np.int64)), torch.from_numpy(fx["w"])
+    diff = q.unsqueeze(-2) - torch.from_numpy(mesh.vertices)[idx]
+    r = torch.norm(diff, dim=-1, keepdim=True)
+    mid = (m.indicator_vector[idx] * 0.1 + diff * r) / (0.1 + r)
+    ds = (w.unsqueeze(-1) * (diff * mid).sum(-1, keepdim=True)).sum(-2)
+    sdf, nab, demb = m._forward_density(q, ds, m.geometry_features, idx, w, need_nablas=True)
+    rgb = m._forward_color(demb, torch.from_numpy(fx["dirs"]), m.color_features, idx, w, nab)
+    np.testing.assert_allclose(sdf.detach().numpy(), fx["sdf"], atol=1e-6)
+    np.testing.assert_allclose(rgb.detach().numpy(), fx["rgb"], atol=1e-6)
+
+
+def test_shard_range_partitions_everything():
+    for n in (0, 1, 7, 640000, 1920001):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_unpack_roundtrip():
+    torch = pytest.importorskip("torch")
+    ret = {"rgb": torch.rand(5, 3), "depth_volume": torch.rand(5), "mask_volume": torch.rand(5), "normals_volume": torch.rand(5, 3)}
+    packed, keys = pack_outputs(ret)
+    assert packed.shape == (5, 8)
+    back = unpack_outputs(packed, keys)
+    for k in ret:
+        assert torch.equal(back[k], ret[k])
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from neumesh_amd.sharded import render_sharded
+dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{sys.argv[2]}", rank=int(sys.argv[3]), world_size=2)
+n = 1001
+o = torch.arange(n * 3, dtype=torch.float32).reshape(n, 3)
+d = torch.flip(o, dims=[0])
+def fake_render(ro, rd):   # deterministic per-ray function standing in for the HIP renderer
+    return {"rgb": ro * 0.5 + rd, "depth_volume": ro.sum(-1), "mask_volume": rd[:, 0], "normals_volume": ro - rd}
+full = render_sharded(fake_render, o, d)
+want = fake_render(o, d)
+ok = all(torch.equal(full[k], want[k]) for k in want)
+print("RANK", dist.get_rank(), "OK" if ok else "MISMATCH", flush=True)
+dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+def test_sharded_render_world_size_2_gloo(tmp_path):
+    pytest.importorskip("torch")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(port), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("OK" in o for o in outs), outs

@@ -1,0 +1,148 @@
+"""CPU: the host/device-shared headers of neumesh_amd/csrc (octree K-NN traversal, projected
+distance + closed-form gradient, per-ray stages) compiled with g++ (tests/hostcheck) and checked
+against the oracle.  This pins the ALGORITHMS the device kernels run; the kernels themselves are
+checked on the GPU (tests marked gpu)."""
+import numpy as np
+import pytest
+
+import common
+from hostcheck.loader import HostGrid, P, load
+from oracle import knn as oknn, render as orender
+
+
+def _queries(verts, n, seed):
+    rng = np.random.default_rng(seed)
+    V = len(verts)
+    k = min(8, V)
+    return np.concatenate([
+        verts[rng.integers(0, V, n // 2)] + 0.01 * rng.standard_normal((n // 2, 3)),   # near surface
+        verts[rng.integers(0, V, n // 4)] + 0.2 * rng.standard_normal((n // 4, 3)),    # mid range
+        rng.uniform(-3, 3, (n - n // 2 - n // 4 - k, 3)),                              # far / outside bbox
+        verts[:k],                                                                      # exactly on vertices
+    ]).astype(np.float32)
+
+
+@pytest.mark.parametrize("V,dup,K,level", [(3000, 0, 8, 0), (1200, 64, 8, 0), (20000, 0, 8, 0), (5000, 0, 1, 0),
+                                           (5000, 0, 16, 0), (5000, 0, 32, 0), (3000, 0, 8, 2), (3000, 0, 8, 7),
+                                           (9, 0, 8, 0), (5, 0, 8, 0), (1, 0, 8, 0)])
+def test_octree_knn_is_bit_exact(V, dup, K, level):
+    verts = common.scene_mesh(V, dup).vertices
+    q = _queries(verts, 2048 if V > 100 else 64, V + K)
+    idx, d2 = HostGrid(verts, level).knn(q, K)
+    ridx, rd2 = oknn.knn_bruteforce(q, verts, K)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(d2, rd2)
+
+
+def test_octree_knn_dtu_scale_mesh():
+    verts = common.scene_mesh(140000).vertices
+    q = _queries(verts, 6000, 7)
+    g = HostGrid(verts)
+    assert 5 <= g.level <= 8
+    idx, d2 = g.knn(q, 8)
+    ridx, rd2 = oknn.knn_bruteforce(q, verts, 8)
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+
+
+def test_octree_knn_degenerate_clouds():
+    rng = np.random.default_rng(3)
+    line = np.zeros((500, 3), np.float32); line[:, 0] = np.linspace(-1, 1, 500)
+    same = np.tile(np.array([[0.3, -0.2, 0.1]], np.float32), (40, 1))
+    clustered = np.concatenate([0.001 * rng.standard_normal((400, 3)), 5 + 0.001 * rng.standard_normal((400, 3))]).astype(np.float32)
+    for verts in (line, same, clustered):
+        q = np.concatenate([verts[:50], rng.uniform(-6, 6, (300, 3)).astype(np.float32)])
+        idx, d2 = HostGrid(verts).knn(q, 8)
+        ridx, rd2 = oknn.knn_bruteforce(q, verts, 8)
+        assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+
+
+def test_projected_distance_and_gradient_match_fixture():
+    fx = common.golden("field_v3000")
+    mesh = common.scene_mesh(3000)
+    st = common.scene_state(mesh)
+    ds, idx, w, g = HostGrid(mesh.vertices).compute_distance(fx["q"], st["indicator_vector"], 0.1)
+    assert np.array_equal(idx, fx["idx"])
+    np.testing.assert_allclose(ds, fx["ds"][:, 0], atol=2e-6)
+    np.testing.assert_allclose(w, fx["w"], atol=2e-6)
+    np.testing.assert_allclose(g, fx["dds_dx"], atol=2e-5, rtol=2e-5)
+
+
+def test_linspace_matches_torch_formula():
+    lib = load()
+    for n in (2, 16, 64, 256):
+        out = np.empty(n, np.float32)
+        lib.hc_linspace01(n, P(out))
+        assert np.array_equal(out, orender.torch_linspace01(n))
+
+
+def test_ray_setup_and_bounds():
+    lib = load()
+    rf = common.golden("render_v3000_dtu")
+    R = len(rf["rays_o"])
+    dirn, nf0 = np.empty((R, 3), np.float32), np.empty((R, 2), np.float32)
+    lib.hc_ray_setup(P(np.ascontiguousarray(rf["rays_o"])), P(np.ascontiguousarray(rf["rays_d"])), R, 1.0, P(dirn), P(nf0))
+    odir = orender.normalize(rf["rays_d"])
+    on, of = orender.near_far_from_sphere(rf["rays_o"], odir, 1.0)
+    np.testing.assert_allclose(dirn, odir, atol=1e-7)
+    np.testing.assert_allclose(nf0, np.concatenate([on, of], 1), atol=1e-6)
+    # bounds: feed the oracle's probe distances
+    mesh = common.scene_mesh(3000)
+    orc = common.make_oracle(mesh, common.scene_state(mesh))
+    n2, f2, probe = orender.compute_bounded_near_far(orc, rf["rays_o"], odir, on, of)
+    nf = np.empty((R, 2), np.float32)
+    lib.hc_ray_bounds(P(np.ascontiguousarray(probe, np.float32)), R, 256, 0.1, P(np.concatenate([on, of], 1).astype(np.float32)), P(nf))
+    np.testing.assert_allclose(nf, np.concatenate([n2, f2], 1), atol=1e-6)
+    np.testing.assert_allclose(nf, np.concatenate([rf["near"], rf["far"]], 1), atol=1e-6)
+
+
+def test_upsample_merge_follow_the_oracle():
+    """Drive the C++ per-ray up-sampling with the ORACLE's field values and compare every
+    iteration's new depths / the final sorted depth list."""
+    lib = load()
+    rf = common.golden("render_v3000_dtu")
+    mesh = common.scene_mesh(3000)
+    orc = common.make_oracle(mesh, common.scene_state(mesh))
+    R, cap = len(rf["rays_o"]), 128
+    odir = orender.normalize(rf["rays_d"])
+    d = np.zeros((R, cap), np.float32); sdf = np.zeros((R, cap), np.float32)
+    d[:, :64], sdf[:, :64] = rf["d_coarse"], rf["sdf_coarse"]
+    od, osdf = rf["d_coarse"].copy(), rf["sdf_coarse"].copy()
+    n, pending = 64, 0
+    for it in range(4):
+        if pending:
+            lib.hc_ray_merge(P(d), P(sdf), R, cap, n - pending, pending)
+        lib.hc_ray_upsample(P(d), P(sdf), R, cap, n, it, 16)
+        o_fine, _ = orender.upsample_step(od, osdf, it, 16)
+        got = d[:, n:n + 16]
+        # all but the u=1 sample agree to rounding; the last one is placed by whether the fp32
+        # cdf[-1] rounded above or below 1.0 (oracle/compare.py): anywhere inside the last bin
+        np.testing.assert_allclose(got[:, :15], o_fine[:, :15], atol=3e-6)
+        assert ((got[:, 15] >= od[:, -2] - 3e-6) & (got[:, 15] <= od[:, -1] + 3e-6)).all()
+        # continue both sides from the ORACLE's samples so the comparison stays aligned
+        d[:, n:n + 16] = o_fine
+        pts = (rf["rays_o"][:, None, :] + o_fine[..., None] * odir[:, None, :]).astype(np.float32)
+        s_f = orc.forward_density_only(pts)[..., 0]
+        sdf[:, n:n + 16] = s_f
+        od = np.concatenate([od, o_fine], -1); osdf = np.concatenate([osdf, s_f], -1)
+        order = np.argsort(od, -1, kind="stable")
+        od, osdf = np.take_along_axis(od, order, -1), np.take_along_axis(osdf, order, -1)
+        n += 16; pending = 16
+    lib.hc_ray_merge(P(d), P(sdf), R, cap, n - pending, pending)
+    assert np.array_equal(d, od) and np.array_equal(sdf, osdf)
+
+
+def test_composite_matches_reference_fixture():
+    lib = load()
+    rf = common.golden("render_v3000_dtu")
+    R, N = rf["implicit_surface"].shape
+    d_all = np.ascontiguousarray(rf["d_all"], np.float32)
+    # the reference's own per-sample outputs in, its composited pixels out
+    rgb, depth, acc, nrm = np.empty((R, 3), np.float32), np.empty(R, np.float32), np.empty(R, np.float32), np.empty((R, 3), np.float32)
+    fx = common.golden("field_v3000")
+    lib.hc_ray_composite(P(np.ascontiguousarray(rf["implicit_surface"])), P(d_all), R, N, float(fx["s"]),
+                         P(np.ascontiguousarray(rf["radiance"])), P(np.ascontiguousarray(rf["implicit_nablas"])), 0,
+                         P(rgb), P(depth), P(acc), P(nrm))
+    np.testing.assert_allclose(rgb, rf["rgb"], atol=2e-6)
+    np.testing.assert_allclose(acc, rf["mask_volume"], atol=2e-6)
+    np.testing.assert_allclose(depth, rf["depth_volume"], atol=2e-5)   # d_all is recovered to ~1e-7 only
+    np.testing.assert_allclose(nrm, rf["normals_volume"], atol=2e-6)
