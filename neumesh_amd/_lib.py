@@ -95,6 +95,10 @@ def load(require_device: bool = True):
     with require_device also when no HIP device is visible."""
     global _lib
     if _lib is None:
+        # torch ships its own libamdhip64; it must be the HIP runtime of the process, so make sure
+        # it is loaded BEFORE our library pulls in /opt/rocm's copy under the same SONAME
+        # (two runtimes in one process: "No HIP GPUs are available").
+        import torch  # noqa: F401
         path = lib_path()
         if not os.path.exists(path):
             raise NeuMeshHipError(

@@ -169,9 +169,9 @@ static NmPointSrc nm_src_xyz(const float* xyz) {
 
 int nm_knn(nm_grid_t g, const float* q, int64_t Q, int K, int64_t* idx, float* d2, nm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!g || !idx || !d2 || (!q && Q > 0)) return nm_fail("nm_knn: NULL argument");
     if (K < 1 || K > NM_MAX_K) return nm_fail("nm_knn: K=%d out of [1,%d]", K, NM_MAX_K);
     if (Q <= 0) return Q == 0 ? 0 : nm_fail("nm_knn: Q<0");
+    if (!g || !idx || !d2 || !q) return nm_fail("nm_knn: NULL argument");
     const NmPointSrc src = nm_src_xyz(q);
     const dim3 grid(nm_blocks(Q, 256)), block(256);
     long long* idx_ll = reinterpret_cast<long long*>(idx);
@@ -195,7 +195,8 @@ static int nm_launch_distance(nm_grid_t g, const NmPointSrc& src, long long Q, c
 int nm_compute_distance(nm_grid_t g, const float* q, int64_t Q, const float* indicator, float w1, int K, float* ds,
                         int64_t* idx, float* w, float* dds_dx, nm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!g || (!q && Q > 0)) return nm_fail("nm_compute_distance: NULL argument");
+    if (Q == 0) return 0;
+    if (!g || !q) return nm_fail("nm_compute_distance: NULL argument");
     if (K != 8) return nm_fail("nm_compute_distance: K=%d unsupported (the fused kernel is built for K=8, the value the reference uses: models/mesh_grid.py:77)", K);
     if (!indicator) return nm_fail("nm_compute_distance: indicator is NULL");
     if (g->view.V < 8) return nm_fail("nm_compute_distance: mesh has %d < 8 vertices", g->view.V);
