@@ -71,9 +71,11 @@ static inline size_t nm_align(size_t x) { return (x + 255) & ~(size_t)255; }
 struct nm_grid_s {
     NmGridView view;        // device pointers
     float* verts = nullptr;  // device copy of the vertices in ORIGINAL order [V,3]
-    void* blob = nullptr;    // one allocation holding mask | leaf_start | sverts | verts
+    void* blob = nullptr;    // one allocation holding nodes | sverts | verts
     size_t blob_bytes = 0;
     int occupied = 0;
+    float origin[3] = {0, 0, 0};
+    float root_size = 0;
 };
 
 struct nm_field_s {
@@ -106,35 +108,30 @@ int nm_grid_create(const float* verts_device, int64_t V, int leaf_level, nm_stre
     NmHostGrid hg;
     if (!nm_build_host_grid(hv.data(), V, leaf_level, hg)) return nm_fail("nm_grid_create: non-finite vertex coordinates");
     nm_grid_s* g = new nm_grid_s();
-    const size_t b_mask = nm_align(hg.mask.size());
-    const size_t b_leaf = nm_align(hg.leaf_start.size() * sizeof(uint32_t));
+    const size_t b_nodes = nm_align(hg.nodes.size() * sizeof(NmNode));
     const size_t b_sv = nm_align(hg.sverts.size() * sizeof(float4));
     const size_t b_v = nm_align(hv.size() * sizeof(float));
-    g->blob_bytes = b_mask + b_leaf + b_sv + b_v;
+    g->blob_bytes = b_nodes + b_sv + b_v;
     if (hipMalloc(&g->blob, g->blob_bytes) != hipSuccess) {
         delete g;
-        return nm_fail("nm_grid_create: hipMalloc(%zu) failed", b_mask + b_leaf + b_sv + b_v);
+        return nm_fail("nm_grid_create: hipMalloc(%zu) failed", b_nodes + b_sv + b_v);
     }
     char* base = (char*)g->blob;
-    hipError_t e = hipMemcpyAsync(base, hg.mask.data(), hg.mask.size(), hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(base + b_mask, hg.leaf_start.data(), hg.leaf_start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(base + b_mask + b_leaf, hg.sverts.data(), hg.sverts.size() * sizeof(float4), hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(base + b_mask + b_leaf + b_sv, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice, stream);
+    hipError_t e = hipMemcpyAsync(base, hg.nodes.data(), hg.nodes.size() * sizeof(NmNode), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(base + b_nodes, hg.sverts.data(), hg.sverts.size() * sizeof(float4), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(base + b_nodes + b_sv, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) {
         hipFree(g->blob);
         delete g;
         return nm_fail("nm_grid_create: upload failed: %s", hipGetErrorString(e));
     }
-    g->view.ox = hg.ox; g->view.oy = hg.oy; g->view.oz = hg.oz;
-    g->view.root_size = hg.root_size;
-    g->view.slack = hg.slack;
-    g->view.L = hg.L;
-    g->view.V = hg.V;
-    g->view.mask = (const uint8_t*)base;
-    g->view.leaf_start = (const uint32_t*)(base + b_mask);
-    g->view.sverts = (const float4*)(base + b_mask + b_leaf);
-    g->verts = (float*)(base + b_mask + b_leaf + b_sv);
+    g->view = nm_host_view(hg);
+    g->view.nodes = (const NmNode*)base;
+    g->view.sverts = (const float4*)(base + b_nodes);
+    g->verts = (float*)(base + b_nodes + b_sv);
+    g->origin[0] = hg.ox; g->origin[1] = hg.oy; g->origin[2] = hg.oz;
+    g->root_size = hg.root_size;
     g->occupied = hg.occupied_leaves;
     *out = g;
     return 0;
@@ -152,8 +149,8 @@ int nm_grid_get_info(nm_grid_t g, nm_grid_info* out) {
     out->num_vertices = g->view.V;
     out->leaf_level = g->view.L;
     out->occupied_leaves = g->occupied;
-    out->origin[0] = g->view.ox; out->origin[1] = g->view.oy; out->origin[2] = g->view.oz;
-    out->root_size = g->view.root_size;
+    out->origin[0] = g->origin[0]; out->origin[1] = g->origin[1]; out->origin[2] = g->origin[2];
+    out->root_size = g->root_size;
     out->device_bytes = (int64_t)g->blob_bytes;
     return 0;
 }
@@ -173,7 +170,7 @@ int nm_knn(nm_grid_t g, const float* q, int64_t Q, int K, int64_t* idx, float* d
     if (Q <= 0) return Q == 0 ? 0 : nm_fail("nm_knn: Q<0");
     if (!g || !idx || !d2 || !q) return nm_fail("nm_knn: NULL argument");
     const NmPointSrc src = nm_src_xyz(q);
-    const dim3 grid(nm_blocks(Q, 256)), block(256);
+    const dim3 grid(nm_query_blocks(src, Q)), block(256);
     long long* idx_ll = reinterpret_cast<long long*>(idx);
     if (K <= 8) hipLaunchKernelGGL(nm_knn_kernel<8>, grid, block, 0, stream, g->view, src, (long long)Q, K, idx_ll, d2);
     else if (K <= 16) hipLaunchKernelGGL(nm_knn_kernel<16>, grid, block, 0, stream, g->view, src, (long long)Q, K, idx_ll, d2);
@@ -186,7 +183,7 @@ static int nm_launch_distance(nm_grid_t g, const NmPointSrc& src, long long Q, c
                               float* ds, int* idx32, long long* idx64, float* w, float* grad, hipStream_t stream) {
     if (Q <= 0) return 0;
     NmProfScope prof(NM_K_DISTANCE, Q, stream);
-    hipLaunchKernelGGL(nm_distance_kernel, dim3(nm_blocks(Q, 256)), dim3(256), 0, stream, g->view, src, Q, g->verts,
+    hipLaunchKernelGGL(nm_distance_kernel, dim3(nm_query_blocks(src, Q)), dim3(256), 0, stream, g->view, src, Q, g->verts,
                        indicator, w1, ds, idx32, idx64, w, grad);
     NM_LAUNCH_CHECK();
     return 0;

@@ -16,9 +16,8 @@ struct NmHostGrid {
     int L = 1;
     int V = 0;
     int occupied_leaves = 0;
-    std::vector<uint8_t> mask;         // (8^L - 1)/7
-    std::vector<uint32_t> leaf_start;  // 8^L + 1
-    std::vector<float4> sverts;        // V
+    std::vector<NmNode> nodes;   // all levels, root first
+    std::vector<float4> sverts;  // V + 4 (padding)
 };
 
 static inline uint32_t nm_spread3(uint32_t v) {  // 8 bits -> every third bit
@@ -26,6 +25,13 @@ static inline uint32_t nm_spread3(uint32_t v) {  // 8 bits -> every third bit
     v = (v | (v << 8)) & 0x00f00fu;
     v = (v | (v << 4)) & 0x0c30c3u;
     v = (v | (v << 2)) & 0x249249u;
+    return v;
+}
+static inline uint32_t nm_compact3(uint32_t v) {  // inverse of nm_spread3
+    v &= 0x249249u;
+    v = (v | (v >> 2)) & 0x0c30c3u;
+    v = (v | (v >> 4)) & 0x00f00fu;
+    v = (v | (v >> 8)) & 0x0000ffu;
     return v;
 }
 static inline uint32_t nm_morton(uint32_t x, uint32_t y, uint32_t z) {
@@ -61,13 +67,13 @@ static inline bool nm_build_host_grid(const float* verts, int64_t V, int leaf_le
     g.ox = 0.5f * (lo[0] + hi[0]) - 0.5f * g.root_size;
     g.oy = 0.5f * (lo[1] + hi[1]) - 0.5f * g.root_size;
     g.oz = 0.5f * (lo[2] + hi[2]) - 0.5f * g.root_size;
-    g.slack = 2e-6f * (amax + g.root_size);
+    g.slack = 4e-6f * (amax + g.root_size);
     g.V = (int)V;
 
     std::vector<uint32_t> codes((size_t)V);
     int L = leaf_level;
     if (L <= 0) {
-        // smallest depth with <= 12 vertices per occupied leaf on average
+        // smallest depth with <= NM_LEAF_TARGET vertices per occupied leaf on average
         for (L = 1; L < NM_MAX_LEVEL; ++L) {
             for (int64_t i = 0; i < V; ++i) codes[(size_t)i] = nm_leaf_code(g, L, verts[3 * i], verts[3 * i + 1], verts[3 * i + 2]);
             std::vector<uint32_t> s(codes);
@@ -85,10 +91,7 @@ static inline bool nm_build_host_grid(const float* verts, int64_t V, int leaf_le
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         return codes[a] != codes[b] ? codes[a] < codes[b] : a < b;
     });
-
-    const size_t n_leaves = (size_t)1 << (3 * L);
-    g.leaf_start.assign(n_leaves + 1, 0u);
-    g.sverts.resize((size_t)V);
+    g.sverts.assign((size_t)V + 4, float4{NM_INF_F, NM_INF_F, NM_INF_F, nm_as_float(0x7fffffff)});
     for (size_t p = 0; p < (size_t)V; ++p) {
         const uint32_t i = order[p];
         float4 v;
@@ -97,28 +100,89 @@ static inline bool nm_build_host_grid(const float* verts, int64_t V, int leaf_le
         v.z = verts[3 * i + 2];
         v.w = nm_as_float((int)i);
         g.sverts[p] = v;
-        g.leaf_start[codes[i] + 1]++;
     }
-    g.occupied_leaves = 0;
-    for (size_t c = 0; c < n_leaves; ++c) {
-        if (g.leaf_start[c + 1]) g.occupied_leaves++;
-        g.leaf_start[c + 1] += g.leaf_start[c];
-    }
-    // child masks, bottom-up
-    g.mask.assign(nm_level_offset(L), 0);
-    for (int level = L - 1; level >= 0; --level) {
-        const size_t n = (size_t)1 << (3 * level);
-        const uint32_t off = nm_level_offset(level);
-        for (size_t m = 0; m < n; ++m) {
-            uint8_t bits = 0;
-            for (int c = 0; c < 8; ++c) {
-                const size_t child = (m << 3) | (size_t)c;
-                bool occ;
-                if (level + 1 == L) occ = g.leaf_start[child + 1] > g.leaf_start[child];
-                else occ = g.mask[nm_level_offset(level + 1) + child] != 0;
-                if (occ) bits |= (uint8_t)(1u << c);
+
+    // per level: sorted unique node codes, tight boxes, first-child / first-vertex index
+    struct Lvl {
+        std::vector<uint32_t> code, first;          // Morton code; first child (local) or first vertex
+        std::vector<float> lo, hi;                  // tight boxes, 3 floats per node
+    };
+    std::vector<Lvl> lv((size_t)L + 1);
+    {
+        Lvl& leaf = lv[(size_t)L];
+        for (size_t p = 0; p < (size_t)V; ++p) {
+            const uint32_t c = codes[order[p]];
+            if (leaf.code.empty() || leaf.code.back() != c) {
+                leaf.code.push_back(c);
+                leaf.first.push_back((uint32_t)p);
+                for (int a = 0; a < 3; ++a) { leaf.lo.push_back(NM_INF_F); leaf.hi.push_back(-NM_INF_F); }
             }
-            g.mask[off + m] = bits;
+            const size_t n = leaf.code.size() - 1;
+            const float xyz[3] = {g.sverts[p].x, g.sverts[p].y, g.sverts[p].z};
+            for (int a = 0; a < 3; ++a) {
+                leaf.lo[3 * n + a] = std::min(leaf.lo[3 * n + a], xyz[a]);
+                leaf.hi[3 * n + a] = std::max(leaf.hi[3 * n + a], xyz[a]);
+            }
+        }
+        g.occupied_leaves = (int)leaf.code.size();
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        const Lvl& ch = lv[(size_t)l + 1];
+        Lvl& cur = lv[(size_t)l];
+        for (size_t j = 0; j < ch.code.size(); ++j) {
+            const uint32_t pc = ch.code[j] >> 3;
+            if (cur.code.empty() || cur.code.back() != pc) {
+                cur.code.push_back(pc);
+                cur.first.push_back((uint32_t)j);
+                for (int a = 0; a < 3; ++a) { cur.lo.push_back(NM_INF_F); cur.hi.push_back(-NM_INF_F); }
+            }
+            const size_t n = cur.code.size() - 1;
+            for (int a = 0; a < 3; ++a) {
+                cur.lo[3 * n + a] = std::min(cur.lo[3 * n + a], ch.lo[3 * j + a]);
+                cur.hi[3 * n + a] = std::max(cur.hi[3 * n + a], ch.hi[3 * j + a]);
+            }
+        }
+    }
+    std::vector<uint32_t> off((size_t)L + 2, 0u);
+    for (int l = 0; l <= L; ++l) off[(size_t)l + 1] = off[(size_t)l] + (uint32_t)lv[(size_t)l].code.size();
+    g.nodes.assign((size_t)off[(size_t)L + 1], NmNode{});
+    for (int l = 0; l <= L; ++l) {
+        const Lvl& cur = lv[(size_t)l];
+        size_t parent_local = 0;
+        for (size_t n = 0; n < cur.code.size(); ++n) {
+            NmNode r{};
+            uint32_t mask = 0;
+            if (l == L) {
+                r.first = cur.first[n];
+                r.end = (n + 1 < cur.code.size()) ? cur.first[n + 1] : (uint32_t)V;
+            } else {
+                const Lvl& ch = lv[(size_t)l + 1];
+                r.first = off[(size_t)l + 1] + cur.first[n];
+                r.end = 0;
+                for (size_t j = cur.first[n]; j < ch.code.size() && (ch.code[j] >> 3) == cur.code[n]; ++j) mask |= 1u << (ch.code[j] & 7u);
+            }
+            if (l == 0) {
+                r.parent = 0;
+            } else {
+                const Lvl& par = lv[(size_t)l - 1];
+                while (par.code[parent_local] != (cur.code[n] >> 3)) ++parent_local;
+                r.parent = off[(size_t)l - 1] + (uint32_t)parent_local;
+            }
+            r.info = mask | ((cur.code[n] & 7u) << 8);
+            // tight box, expanded so that it certainly contains every fp32 vertex assigned to it
+            // and absorbs the rounding of (box - q) for queries within ~10x the scene scale
+            float blo[3], bhi[3];
+            for (int a = 0; a < 3; ++a) {
+                const float e = g.slack + 1e-6f * std::max(std::fabs(cur.lo[3 * n + a]), std::fabs(cur.hi[3 * n + a]));
+                blo[a] = cur.lo[3 * n + a] - e;
+                bhi[a] = cur.hi[3 * n + a] + e;
+            }
+            r.lox = blo[0]; r.loy = blo[1]; r.loz = blo[2];
+            r.hix = bhi[0]; r.hiy = bhi[1]; r.hiz = bhi[2];
+            r.cx = 0.5f * (blo[0] + bhi[0]);
+            r.cy = 0.5f * (blo[1] + bhi[1]);
+            r.cz = 0.5f * (blo[2] + bhi[2]);
+            g.nodes[(size_t)off[(size_t)l] + n] = r;
         }
     }
     return true;
@@ -126,13 +190,10 @@ static inline bool nm_build_host_grid(const float* verts, int64_t V, int leaf_le
 
 static inline NmGridView nm_host_view(const NmHostGrid& g) {
     NmGridView v;
-    v.ox = g.ox; v.oy = g.oy; v.oz = g.oz;
-    v.root_size = g.root_size;
-    v.slack = g.slack;
     v.L = g.L;
     v.V = g.V;
-    v.mask = g.mask.data();
-    v.leaf_start = g.leaf_start.data();
+    v.coop_extent = 0.75f * g.root_size;
+    v.nodes = g.nodes.data();
     v.sverts = g.sverts.data();
     return v;
 }

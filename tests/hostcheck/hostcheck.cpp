@@ -59,6 +59,97 @@ int hc_knn(void* p, const float* q, int64_t Q, int K, int64_t* idx, float* d2) {
     return 0;
 }
 
+// average traversal cost per query: out[0] = node records tested, out[1] = vertices scanned
+int hc_knn_stats(void* p, const float* q, int64_t Q, double* out) {
+    const NmGridView v = nm_host_view(((HostGridHandle*)p)->g);
+    long long st[2] = {0, 0};
+    for (int64_t i = 0; i < Q; ++i) {
+        float bd[8];
+        int bi[8];
+        nm_knn_search<8, true>(v, q[3 * i], q[3 * i + 1], q[3 * i + 2], bd, bi, st);
+    }
+    out[0] = (double)st[0] / (double)(Q > 0 ? Q : 1);
+    out[1] = (double)st[1] / (double)(Q > 0 ? Q : 1);
+    return 0;
+}
+
+// Host emulation of the wave-cooperative ("packet") traversal of nm_kernels.h: W queries share
+// ONE traversal (a node is opened if ANY query needs it; every query tests every vertex of an
+// opened leaf that it needs).  Checks exactness of the scheme and counts the shared work.
+// out[0] = node records tested per packet, out[1] = vertices scanned per packet.
+int hc_knn_packet(void* p, const float* q, int64_t Q, int Wd, int64_t* idx, float* d2, double* out) {
+    const NmGridView g = nm_host_view(((HostGridHandle*)p)->g);
+    long long nodes_t = 0, verts_t = 0, packets = 0;
+    std::vector<float> bd((size_t)Wd * 8);
+    std::vector<int> bi((size_t)Wd * 8);
+    for (int64_t base = 0; base < Q; base += Wd) {
+        const int n = (int)std::min<int64_t>(Wd, Q - base);
+        ++packets;
+        for (int l = 0; l < n * 8; ++l) { bd[(size_t)l] = NM_INF_F; bi[(size_t)l] = 0x7fffffff; }
+        float cx0 = 0, cy0 = 0, cz0 = 0;
+        for (int l = 0; l < n; ++l) { cx0 += q[3 * (base + l)]; cy0 += q[3 * (base + l) + 1]; cz0 += q[3 * (base + l) + 2]; }
+        cx0 /= n; cy0 /= n; cz0 /= n;
+        NmNode rec = g.nodes[0];
+        int first = nm_octant(rec, cx0, cy0, cz0);
+        unsigned om = nm_ordered_mask(rec.info & 255u, first);
+        bool at_root = true;
+        for (;;) {
+            if (om == 0) {
+                if (at_root) break;
+                const int c_prev = (int)((rec.info >> 8) & 7u);
+                const uint32_t parent = rec.parent;
+                rec = g.nodes[parent];
+                at_root = parent == 0u;
+                first = nm_octant(rec, cx0, cy0, cz0);
+                om = nm_ordered_mask(rec.info & 255u, first) & ~((2u << nm_perm(c_prev ^ first)) - 1u);
+                continue;
+            }
+            const int i = __builtin_ctz(om);
+            om &= om - 1;
+            const int c = first ^ nm_perm(i);
+            const uint32_t mask = rec.info & 255u;
+            const NmNode crec = g.nodes[rec.first + (uint32_t)nm_popc(mask & ((1u << c) - 1u))];
+            ++nodes_t;
+            bool any = false;
+            std::vector<char> want((size_t)n);
+            for (int l = 0; l < n; ++l) {
+                const float* ql = q + 3 * (base + l);
+                want[(size_t)l] = nm_box_lb2(crec, ql[0], ql[1], ql[2]) <= bd[(size_t)l * 8 + 7];
+                any |= want[(size_t)l] != 0;
+            }
+            if (!any) continue;
+            if ((crec.info & 255u) == 0u) {
+                verts_t += crec.end - crec.first;
+                for (uint32_t pp = crec.first; pp < crec.end; ++pp) {
+                    const float4 v = g.sverts[pp];
+                    for (int l = 0; l < n; ++l) {
+                        if (!want[(size_t)l]) continue;
+                        const float* ql = q + 3 * (base + l);
+                        const float d = nm_dist2(ql[0], ql[1], ql[2], v.x, v.y, v.z);
+                        float(&b8)[8] = *reinterpret_cast<float(*)[8]>(&bd[(size_t)l * 8]);
+                        int(&i8)[8] = *reinterpret_cast<int(*)[8]>(&bi[(size_t)l * 8]);
+                        if (nm_topk_accepts<8>(b8, i8, d, nm_as_int(v.w))) nm_topk_insert<8>(b8, i8, d, nm_as_int(v.w));
+                    }
+                }
+            } else {
+                rec = crec;
+                at_root = false;
+                first = nm_octant(rec, cx0, cy0, cz0);
+                om = nm_ordered_mask(rec.info & 255u, first);
+            }
+        }
+        for (int l = 0; l < n; ++l)
+            for (int k = 0; k < 8; ++k) {
+                const bool ok = bi[(size_t)l * 8 + k] != 0x7fffffff;
+                idx[(base + l) * 8 + k] = ok ? bi[(size_t)l * 8 + k] : -1;
+                d2[(base + l) * 8 + k] = ok ? bd[(size_t)l * 8 + k] : -1.0f;
+            }
+    }
+    out[0] = (double)nodes_t / (double)(packets ? packets : 1);
+    out[1] = (double)verts_t / (double)(packets ? packets : 1);
+    return 0;
+}
+
 int hc_compute_distance(void* p, const float* q, int64_t Q, const float* indicator, float w1, float* ds,
                         int64_t* idx, float* w, float* grad) {
     auto* h = (HostGridHandle*)p;

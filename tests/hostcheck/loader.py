@@ -37,6 +37,8 @@ def load():
         lib.hc_grid_level.argtypes = [C.c_void_p]
         lib.hc_grid_occupied.argtypes = [C.c_void_p]
         lib.hc_knn.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_int, i64p, f32p]
+        lib.hc_knn_stats.argtypes = [C.c_void_p, f32p, C.c_int64, C.POINTER(C.c_double)]
+        lib.hc_knn_packet.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_int, i64p, f32p, C.POINTER(C.c_double)]
         lib.hc_compute_distance.argtypes = [C.c_void_p, f32p, C.c_int64, f32p, C.c_float, f32p, i64p, f32p, f32p]
         lib.hc_linspace01.argtypes = [C.c_int, f32p]
         lib.hc_ray_setup.argtypes = [f32p, f32p, C.c_int64, C.c_float, f32p, f32p]
@@ -72,6 +74,22 @@ class HostGrid:
         d2 = np.empty((len(q), K), np.float32)
         assert self.lib.hc_knn(self.h, P(q), len(q), K, P(idx), P(d2)) == 0
         return idx, d2
+
+    def knn_stats(self, q):
+        """(node records tested, vertices scanned) per query, averaged."""
+        q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
+        out = (C.c_double * 2)()
+        self.lib.hc_knn_stats(self.h, P(q), len(q), out)
+        return out[0], out[1]
+
+    def knn_packet(self, q, width=64):
+        """Packet traversal emulation: (idx, d2, nodes per packet, vertices per packet)."""
+        q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
+        idx = np.empty((len(q), 8), np.int64)
+        d2 = np.empty((len(q), 8), np.float32)
+        out = (C.c_double * 2)()
+        assert self.lib.hc_knn_packet(self.h, P(q), len(q), width, P(idx), P(d2), out) == 0
+        return idx, d2, out[0], out[1]
 
     def compute_distance(self, q, indicator, w1):
         q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
