@@ -180,11 +180,12 @@ int nm_knn(nm_grid_t g, const float* q, int64_t Q, int K, int64_t* idx, float* d
 }
 
 static int nm_launch_distance(nm_grid_t g, const NmPointSrc& src, long long Q, const float* indicator, float w1,
-                              float* ds, int* idx32, long long* idx64, float* w, float* grad, hipStream_t stream) {
+                              float* ds, int* idx32, long long* idx64, float* w, float* grad, hipStream_t stream,
+                              float* radius = nullptr) {
     if (Q <= 0) return 0;
     NmProfScope prof(NM_K_DISTANCE, Q, stream);
     hipLaunchKernelGGL(nm_distance_kernel, dim3(nm_query_blocks(src, Q)), dim3(256), 0, stream, g->view, src, Q, g->verts,
-                       indicator, w1, ds, idx32, idx64, w, grad);
+                       indicator, w1, ds, idx32, idx64, w, grad, radius);
     NM_LAUNCH_CHECK();
     return 0;
 }
@@ -339,17 +340,19 @@ static int nm_check_field_args(nm_field_t f, nm_grid_t g, const nm_field_tables*
     return 0;
 }
 
+static const NmRecMap NM_COMPACT = {1, 0, 0, nullptr};
+
 static int nm_launch_geo(nm_field_t f, const float* table, const float* ds, const int* idx, const float* w,
                          const float* grad, long long P, bool nabla, float* sdf, int Pper, int stride, int off,
-                         float* nabla_out, hipStream_t stream) {
+                         float* nabla_out, hipStream_t stream, NmRecMap rmap = NM_COMPACT) {
     if (P <= 0) return 0;
     NmProfScope prof(nabla ? NM_K_GEO_NABLA : NM_K_GEO, P, stream);
     if (nabla) {
         hipLaunchKernelGGL((nm_geo_mlp_kernel<true, false>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo, table, ds,
-                           idx, w, grad, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr);
+                           idx, w, grad, rmap, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr);
     } else {
         hipLaunchKernelGGL((nm_geo_mlp_kernel<false, false>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->geo, table, ds,
-                           idx, w, grad, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr);
+                           idx, w, grad, rmap, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr);
     }
     NM_LAUNCH_CHECK();
     return 0;
@@ -413,7 +416,10 @@ int nm_field_color(nm_field_t f, const float* color_features, const float* ds, c
 struct NmWorkspace {
     float *dirn, *nf0, *nf, *d, *sdf, *dmid, *probe;
     float *rgb_mid, *nab_pts, *nab_mid;
-    NmScratch pts;  // K-NN outputs for up to R*N points
+    int* slot;                    // [R][N] generation position of the sample at each sorted position
+    float *radius, *bound, *bound_mid;  // [R][N] K-th-neighbour distance per slot; warm-start bounds
+    NmScratch slots;  // per-ray slot records (coarse + up-sampling passes), reused by the final pass
+    NmScratch pts;    // compact records of the mid-point pass
     size_t bytes;
 };
 static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) {
@@ -432,6 +438,12 @@ static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) 
     w.rgb_mid = (float*)take((size_t)R * N * 12);
     w.nab_pts = (float*)take((size_t)R * N * 12);
     w.nab_mid = (float*)take((size_t)R * N * 12);
+    w.slot = (int*)take((size_t)R * N * 4);
+    w.radius = (float*)take((size_t)R * N * 4);
+    w.bound = (float*)take((size_t)R * N * 4);
+    w.bound_mid = (float*)take((size_t)R * N * 4);
+    w.slots = nm_carve(p + o, R * N);
+    o += w.slots.bytes;
     w.pts = nm_carve(p + o, R * N);
     o += w.pts.bytes;
     w.bytes = o;
@@ -477,6 +489,9 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
         src.P = c->probe_grid;
         src.nearfar = ws.nf0;
         src.depth_out = nullptr;
+        src.bound = nullptr;
+        src.out_stride = 0;
+        src.out_off = 0;
         if (nm_launch_distance(g, src, (long long)R * c->probe_grid, t->indicator_vector, t->indicator_weight, ws.probe, nullptr, nullptr, nullptr, nullptr, stream)) return 1;
         hipLaunchKernelGGL(nm_rays_bounds_kernel, rgrid, rblock, 0, stream, ws.probe, (long long)R, c->probe_grid, c->probe_thresh, ws.nf0, ws.nf);
         NM_LAUNCH_CHECK();
@@ -490,14 +505,26 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
         hipLaunchKernelGGL(nm_rays_bypass_kernel, rgrid, rblock, 0, stream, (long long)R, c->near_bypass, c->far_bypass, ws.nf);
         NM_LAUNCH_CHECK();
     }
-    // coarse samples + SDF (renderer.py:193-207)
+    // coarse samples + SDF (renderer.py:193-207).  The K-NN records of the coarse and up-sampling
+    // passes are written to per-ray SLOTS (slot = position at which the sample was generated):
+    // the final pass over all N samples visits exactly these points again, so it reuses the
+    // records through the sort permutation instead of searching a second time (same input, same
+    // deterministic kernel => bit-identical record), and every later search is warm-started with
+    // the cached K-th-neighbour radius of the neighbouring sample on its ray.
+    const bool want_grad = c->calc_normal != 0;
     src.mode = 2;
     src.P = c->N_samples;
     src.nearfar = nf;
     src.depth_out = ws.d;
     src.doff = 0;
-    if (nm_launch_distance(g, src, (long long)R * c->N_samples, t->indicator_vector, t->indicator_weight, ws.pts.ds, ws.pts.idx, nullptr, ws.pts.w, nullptr, stream)) return 1;
-    if (nm_launch_geo(f, t->geometry_features, ws.pts.ds, ws.pts.idx, ws.pts.w, nullptr, (long long)R * c->N_samples, false, ws.sdf, c->N_samples, cap, 0, nullptr, stream)) return 1;
+    src.bound = nullptr;
+    src.out_stride = cap;
+    src.out_off = 0;
+    if (nm_launch_distance(g, src, (long long)R * c->N_samples, t->indicator_vector, t->indicator_weight, ws.slots.ds, ws.slots.idx, nullptr, ws.slots.w, want_grad ? ws.slots.grad : nullptr, stream, ws.radius)) return 1;
+    {
+        const NmRecMap rm = {c->N_samples, cap, 0, nullptr};
+        if (nm_launch_geo(f, t->geometry_features, ws.slots.ds, ws.slots.idx, ws.slots.w, nullptr, (long long)R * c->N_samples, false, ws.sdf, c->N_samples, cap, 0, nullptr, stream, rm)) return 1;
+    }
     if (dbg && dbg->sdf_coarse) {
         hipLaunchKernelGGL(nm_copy_strided_kernel, dim3(nm_blocks(R * c->N_samples, 256)), dim3(256), 0, stream, ws.sdf, (long long)R, c->N_samples, cap, dbg->sdf_coarse);
         NM_LAUNCH_CHECK();
@@ -507,31 +534,40 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     if (c->N_importance > 0) {
         const int n_new = c->N_importance / c->N_upsample_iters;
         for (int it = 0; it < c->N_upsample_iters; ++it) {
-            hipLaunchKernelGGL(nm_rays_upsample_kernel, rgrid, rblock, 0, stream, ws.d, ws.sdf, (long long)R, cap, n, pending, it, n_new);
+            hipLaunchKernelGGL(nm_rays_upsample_kernel, rgrid, rblock, 0, stream, ws.d, ws.sdf, ws.slot, ws.radius, ws.bound, (long long)R, cap, n, pending, it, n_new);
             NM_LAUNCH_CHECK();
             src.mode = 1;
             src.P = n_new;
             src.depth = ws.d;
             src.doff = n;
             src.depth_out = nullptr;
-            if (nm_launch_distance(g, src, (long long)R * n_new, t->indicator_vector, t->indicator_weight, ws.pts.ds, ws.pts.idx, nullptr, ws.pts.w, nullptr, stream)) return 1;
-            if (nm_launch_geo(f, t->geometry_features, ws.pts.ds, ws.pts.idx, ws.pts.w, nullptr, (long long)R * n_new, false, ws.sdf, n_new, cap, n, nullptr, stream)) return 1;
+            src.bound = ws.bound;
+            src.out_stride = cap;
+            src.out_off = n;
+            if (nm_launch_distance(g, src, (long long)R * n_new, t->indicator_vector, t->indicator_weight, ws.slots.ds, ws.slots.idx, nullptr, ws.slots.w, want_grad ? ws.slots.grad : nullptr, stream, ws.radius)) return 1;
+            const NmRecMap rm = {n_new, cap, n, nullptr};
+            if (nm_launch_geo(f, t->geometry_features, ws.slots.ds, ws.slots.idx, ws.slots.w, nullptr, (long long)R * n_new, false, ws.sdf, n_new, cap, n, nullptr, stream, rm)) return 1;
             n += n_new;
             pending = n_new;
         }
     }
-    hipLaunchKernelGGL(nm_rays_finalize_kernel, rgrid, rblock, 0, stream, ws.d, ws.sdf, (long long)R, cap, n, pending, ws.dmid);
+    hipLaunchKernelGGL(nm_rays_finalize_kernel, rgrid, rblock, 0, stream, ws.d, ws.sdf, ws.slot, ws.radius, (long long)R, cap, n, pending, ws.dmid, ws.bound_mid);
     NM_LAUNCH_CHECK();
-    // SDF (+ nablas) at all N sample points (renderer.py:264, 271-276)
-    src.mode = 1;
-    src.P = N;
-    src.depth = ws.d;
-    src.doff = 0;
-    if (nm_launch_distance(g, src, (long long)R * N, t->indicator_vector, t->indicator_weight, ws.pts.ds, ws.pts.idx, nullptr, ws.pts.w, c->calc_normal ? ws.pts.grad : nullptr, stream)) return 1;
-    if (nm_launch_geo(f, t->geometry_features, ws.pts.ds, ws.pts.idx, ws.pts.w, ws.pts.grad, (long long)R * N, c->calc_normal != 0, ws.sdf, N, cap, 0, c->calc_normal ? ws.nab_pts : nullptr, stream)) return 1;
+    // SDF (+ nablas) at all N sample points (renderer.py:264, 271-276): no new search.  Without
+    // normals the SDF values merged above ARE forward_density_only(pts) (same points, same kernel).
+    if (c->calc_normal) {
+        const NmRecMap rm = {N, cap, 0, ws.slot};
+        if (nm_launch_geo(f, t->geometry_features, ws.slots.ds, ws.slots.idx, ws.slots.w, ws.slots.grad, (long long)R * N, true, ws.sdf, N, cap, 0, ws.nab_pts, stream, rm)) return 1;
+    }
     // SDF + nabla + radiance at the N-1 mid-points (renderer.py:266-267, 279-282)
+    src.mode = 1;
     src.P = N - 1;
     src.depth = ws.dmid;
+    src.doff = 0;
+    src.depth_out = nullptr;
+    src.bound = ws.bound_mid;
+    src.out_stride = 0;
+    src.out_off = 0;
     if (nm_launch_distance(g, src, (long long)R * (N - 1), t->indicator_vector, t->indicator_weight, ws.pts.ds, ws.pts.idx, nullptr, ws.pts.w, ws.pts.grad, stream)) return 1;
     if (nm_launch_geo(f, t->geometry_features, ws.pts.ds, ws.pts.idx, ws.pts.w, ws.pts.grad, (long long)R * (N - 1), true, nullptr, 1, 1, 0, ws.nab_mid, stream)) return 1;
     if (nm_launch_col(f, t->color_features, ws.pts.ds, ws.pts.idx, ws.pts.w, ws.nab_mid, ws.dirn, N - 1, (long long)R * (N - 1), ws.rgb_mid, stream)) return 1;
@@ -625,7 +661,7 @@ int nm_selfcheck_field(nm_field_t f, nm_grid_t g, const nm_field_tables* t, cons
     const NmScratch s = nm_carve(scratch, P);
     if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx, nullptr, s.w, s.grad, stream)) return 1;
     hipLaunchKernelGGL((nm_geo_mlp_kernel<true, true>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo, t->geometry_features,
-                       s.ds, s.idx, s.w, s.grad, (long long)P, sdf, 1, 1, 0, nabla, valu_tmp);
+                       s.ds, s.idx, s.w, s.grad, NM_COMPACT, (long long)P, sdf, 1, 1, 0, nabla, valu_tmp);
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL((nm_col_mlp_kernel<true>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->col, t->color_features, s.ds,
                        s.idx, s.w, nabla, view_dirs, 1, (long long)P, rgb, valu_tmp);

@@ -164,12 +164,15 @@ NM_HD void nm_topk_insert(float (&bd)[K], int (&bi)[K], float d, int idx) {
 // Exact K-NN of (qx,qy,qz).  On return bd/bi hold the K best ascending by (d2, index);
 // unfilled slots (V < K) keep d2 = +INF, index = INT32_MAX.
 // STATS (host logic check only): stats[0] += node records tested, stats[1] += vertices scanned.
+// init_d2: every slot starts at this squared distance with index INT32_MAX; pass +INF for a cold
+// search, or a PROVEN upper bound of the K-th neighbour's squared distance for a warm start (at
+// least K real vertices then beat the placeholders, so none survives).
 template <int K, bool STATS = false>
 NM_HD void nm_knn_search(const NmGridView& g, float qx, float qy, float qz, float (&bd)[K], int (&bi)[K],
-                         long long* stats = nullptr) {
+                         long long* stats = nullptr, float init_d2 = NM_INF_F) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        bd[k] = NM_INF_F;
+        bd[k] = init_d2;
         bi[k] = 0x7fffffff;
     }
     NmNode rec = g.nodes[0];

@@ -22,7 +22,28 @@ struct NmPointSrc {
     const float* nearfar;  // [R][2]
     float* depth_out;
     int dstride, doff;
+    // warm start (modes 1,2; optional): bound[r*dstride + doff + p] = upper bound of the distance
+    // from the point to its K-th nearest vertex (see nm_ray_upsample)
+    const float* bound;
+    // where the per-point outputs go: record index = q (compact) if out_stride == 0,
+    // else r*out_stride + out_off + p (per-ray slots, so later stages can address them by slot)
+    int out_stride, out_off;
 };
+
+__device__ __forceinline__ long long nm_out_index(const NmPointSrc& s, long long q) {
+    if (s.mode == 0 || s.out_stride == 0) return q;
+    const long long r = q / s.P;
+    return r * s.out_stride + s.out_off + (q - r * s.P);
+}
+
+// squared warm-start bound of point q (+INF when there is none); inflated so that it stays an
+// upper bound under fp32 rounding of the positions and of the candidate distances
+__device__ __forceinline__ float nm_init_bound(const NmPointSrc& s, long long q) {
+    if (s.mode == 0 || !s.bound) return NM_INF_F;
+    const long long r = q / s.P;
+    const float b = s.bound[r * s.dstride + s.doff + (q - r * s.P)] * 1.0001f + 1e-5f;
+    return b * b;
+}
 
 __device__ __forceinline__ void nm_fetch_point(const NmPointSrc& s, long long q, float& x, float& y, float& z) {
     if (s.mode == 0) {
@@ -94,10 +115,11 @@ __device__ __forceinline__ float nm_wave_max(float v) {
 
 template <int K>
 __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float qx, float qy, float qz, bool active,
-                                                     float rx, float ry, float rz, float (&bd)[K], int (&bi)[K]) {
+                                                     float rx, float ry, float rz, float (&bd)[K], int (&bi)[K],
+                                                     float init_d2) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        bd[k] = NM_INF_F;
+        bd[k] = init_d2;
         bi[k] = 0x7fffffff;
     }
     NmNode rec = nm_ld_node(g.nodes, 0);
@@ -151,7 +173,7 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
 // (e.g. randomly scattered points through the point-wise API).
 template <int K>
 __device__ __forceinline__ void nm_knn_wave(const NmGridView& g, float qx, float qy, float qz, bool active,
-                                            float (&bd)[K], int (&bi)[K]) {
+                                            float (&bd)[K], int (&bi)[K], float init_d2 = NM_INF_F) {
     // inactive lanes borrow an active lane's position so that they do not stretch the box
     const unsigned long long act = __ballot(active);
     if (act == 0ull) return;
@@ -164,9 +186,9 @@ __device__ __forceinline__ void nm_knn_wave(const NmGridView& g, float qx, float
     const float ext = nm_uniform_f(fmaxf(fmaxf(hix - lox, hiy - loy), hiz - loz));
     if (ext <= g.coop_extent) {
         nm_knn_search_packet<K>(g, qx, qy, qz, active, nm_uniform_f(0.5f * (lox + hix)), nm_uniform_f(0.5f * (loy + hiy)),
-                                nm_uniform_f(0.5f * (loz + hiz)), bd, bi);
+                                nm_uniform_f(0.5f * (loz + hiz)), bd, bi, init_d2);
     } else if (active) {
-        nm_knn_search<K>(g, qx, qy, qz, bd, bi);
+        nm_knn_search<K>(g, qx, qy, qz, bd, bi, nullptr, init_d2);
     }
 }
 
@@ -225,33 +247,39 @@ __global__ __launch_bounds__(256) void nm_distance_kernel(NmGridView g, NmPointS
                                                           const float* __restrict__ indicator, float w1,
                                                           float* __restrict__ ds_out, int* __restrict__ idx32_out,
                                                           long long* __restrict__ idx64_out,
-                                                          float* __restrict__ w_out, float* __restrict__ grad_out) {
+                                                          float* __restrict__ w_out, float* __restrict__ grad_out,
+                                                          float* __restrict__ radius_out) {
     long long q;
     const bool active = nm_lane_query(src, Q, q);
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (active) nm_fetch_point(src, q, x, y, z);
+    float x = 0.f, y = 0.f, z = 0.f, init = NM_INF_F;
+    if (active) {
+        nm_fetch_point(src, q, x, y, z);
+        init = nm_init_bound(src, q);
+    }
     float bd[8], wk[8], gr[3];
     int bi[8];
-    nm_knn_wave<8>(g, x, y, z, active, bd, bi);
+    nm_knn_wave<8>(g, x, y, z, active, bd, bi, init);
     if (!active) return;
     const float ds = nm_projected_distance8(x, y, z, bd, bi, verts, indicator, w1, wk, grad_out ? gr : nullptr);
-    if (ds_out) ds_out[q] = ds;
+    const long long o = nm_out_index(src, q);
+    if (ds_out) ds_out[o] = ds;
+    if (radius_out) radius_out[o] = nm_sqrt(bd[7]);
     if (idx32_out) {
-        *reinterpret_cast<int4*>(idx32_out + q * 8) = make_int4(bi[0], bi[1], bi[2], bi[3]);
-        *reinterpret_cast<int4*>(idx32_out + q * 8 + 4) = make_int4(bi[4], bi[5], bi[6], bi[7]);
+        *reinterpret_cast<int4*>(idx32_out + o * 8) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+        *reinterpret_cast<int4*>(idx32_out + o * 8 + 4) = make_int4(bi[4], bi[5], bi[6], bi[7]);
     }
     if (idx64_out) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) idx64_out[q * 8 + k] = (long long)bi[k];
+        for (int k = 0; k < 8; ++k) idx64_out[o * 8 + k] = (long long)bi[k];
     }
     if (w_out) {
-        *reinterpret_cast<float4*>(w_out + q * 8) = make_float4(wk[0], wk[1], wk[2], wk[3]);
-        *reinterpret_cast<float4*>(w_out + q * 8 + 4) = make_float4(wk[4], wk[5], wk[6], wk[7]);
+        *reinterpret_cast<float4*>(w_out + o * 8) = make_float4(wk[0], wk[1], wk[2], wk[3]);
+        *reinterpret_cast<float4*>(w_out + o * 8 + 4) = make_float4(wk[4], wk[5], wk[6], wk[7]);
     }
     if (grad_out) {
-        grad_out[q * 3] = gr[0];
-        grad_out[q * 3 + 1] = gr[1];
-        grad_out[q * 3 + 2] = gr[2];
+        grad_out[o * 3] = gr[0];
+        grad_out[o * 3 + 1] = gr[1];
+        grad_out[o * 3 + 2] = gr[2];
     }
 }
 
@@ -278,26 +306,38 @@ __global__ void nm_rays_bypass_kernel(long long R, float near_bypass, float far_
     if (far_bypass >= 0.f) nearfar[2 * r + 1] = far_bypass;
 }
 
-// merge the m samples appended by the previous iteration, then draw n_new new ones
-__global__ void nm_rays_upsample_kernel(float* __restrict__ d, float* __restrict__ sdf, long long R, int cap, int n,
-                                        int m, int it, int n_new) {
+// merge the m samples appended by the previous iteration, then draw n_new new ones (+ their
+// warm-start bounds from the cached K-th-neighbour radius of the neighbouring samples)
+__global__ void nm_rays_upsample_kernel(float* __restrict__ d, float* __restrict__ sdf, int* __restrict__ slot,
+                                        const float* __restrict__ radius, float* __restrict__ bound, long long R,
+                                        int cap, int n, int m, int it, int n_new) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     float* dr = d + r * cap;
     float* sr = sdf + r * cap;
-    if (m > 0) nm_ray_merge(dr, sr, n - m, m);
+    int* sl = slot + r * cap;
+    if (m > 0) nm_ray_merge(dr, sr, n - m, m, sl);
+    else for (int j = 0; j < n; ++j) sl[j] = j;
     float w[NM_MAX_SAMPLES], cdf[NM_MAX_SAMPLES];
-    nm_ray_upsample(dr, sr, n, it, n_new, dr + n, w, cdf);
+    nm_ray_upsample(dr, sr, n, it, n_new, dr + n, w, cdf, sl, radius + r * cap, bound + r * cap + n);
 }
 
-// final merge + mid-point depths (renderer.py:255-258, :266)
-__global__ void nm_rays_finalize_kernel(float* __restrict__ d, float* __restrict__ sdf, long long R, int cap, int n,
-                                        int m, float* __restrict__ d_mid) {
+// final merge + mid-point depths (renderer.py:255-258, :266) + warm-start bounds of the mid-points
+__global__ void nm_rays_finalize_kernel(float* __restrict__ d, float* __restrict__ sdf, int* __restrict__ slot,
+                                        const float* __restrict__ radius, long long R, int cap, int n, int m,
+                                        float* __restrict__ d_mid, float* __restrict__ bound_mid) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     float* dr = d + r * cap;
-    if (m > 0) nm_ray_merge(dr, sdf + r * cap, n - m, m);
-    for (int j = 0; j + 1 < n; ++j) d_mid[r * cap + j] = nm_mul(0.5f, nm_add(dr[j + 1], dr[j]));
+    int* sl = slot + r * cap;
+    if (m > 0) nm_ray_merge(dr, sdf + r * cap, n - m, m, sl);
+    else for (int j = 0; j < n; ++j) sl[j] = j;
+    const float* rad = radius + r * cap;
+    for (int j = 0; j + 1 < n; ++j) {
+        const float dm = nm_mul(0.5f, nm_add(dr[j + 1], dr[j]));
+        d_mid[r * cap + j] = dm;
+        bound_mid[r * cap + j] = fminf(rad[sl[j]] + fabsf(dm - dr[j]), rad[sl[j + 1]] + fabsf(dr[j + 1] - dm));
+    }
 }
 
 __global__ void nm_rays_composite_kernel(const float* __restrict__ sdf, const float* __restrict__ d, long long R,

@@ -38,6 +38,22 @@ struct NmLayer {
     int Kpad;        // multiple of 16
 };
 
+// Which K-NN record (ds / idx / w / grad produced by nm_distance_kernel) belongs to point q:
+// compact (record q) when stride == 0; otherwise ray r = q / P, sample p = q % P and the record
+// lives in ray r's slot array: r*stride + (slot ? slot[r*stride + off + p] : off + p).
+// The slot indirection lets the final 128-sample pass reuse the records of the coarse and
+// up-sampling passes (same points, hence bit-identical records) instead of searching again.
+struct NmRecMap {
+    int P, stride, off;
+    const int* slot;
+};
+__device__ __forceinline__ long long nm_rec_index(const NmRecMap& m, long long q) {
+    if (m.stride == 0) return q;
+    const long long r = q / m.P;
+    const long long p = q - r * m.P;
+    return r * m.stride + (m.slot ? (long long)m.slot[r * m.stride + m.off + p] : m.off + p);
+}
+
 struct NmGeoParams {
     NmLayer layer[NM_MAX_LAYERS];
     int D;
@@ -56,17 +72,22 @@ struct NmColParams {
     int d_emb, in_dim;
 };
 
-// softplus(beta=100, threshold=20) and its derivative exactly as torch computes them:
-// forward: x*beta > 20 ? x : log1p(exp(x*beta))/beta ; backward: x*beta > 20 ? 1 : z/(z+1), z=exp(x*beta)
+// softplus(beta=100, threshold=20) and its derivative (torch: x*beta > 20 ? x : log1p(exp(x*beta))/beta;
+// backward x*beta > 20 ? 1 : z/(z+1), z = exp(x*beta)) on the hardware transcendental units:
+// z = 2^(t*log2 e) (v_exp_f32), log1p(z) = log2(1+z)*ln 2 (v_log_f32) with the series z - z^2/2
+// below 2^-10, z/(z+1) through v_rcp_f32.  A dozen instructions instead of ~150 for the libm
+// expf/log1pf pair; absolute error vs float64 2.5e-8 (libm fp32: 1.6e-8), measured in
+// tests/test_hostlogic.py::test_fast_softplus_formula.  The epilogue of every geometry layer
+// evaluates this 16 K times per workgroup, so its cost is what decides whether the kernel is
+// MFMA-bound.
 __device__ __forceinline__ float nm_softplus100(float x, float* grad) {
-    const float xb = x * 100.0f;
-    if (xb > 20.0f) {
-        if (grad) *grad = 1.0f;
-        return x;
-    }
-    const float z = expf(xb);
-    if (grad) *grad = __fdiv_rn(z, z + 1.0f);
-    return __fdiv_rn(log1pf(z), 100.0f);
+    const float t = x * 100.0f;
+    const float z = __builtin_amdgcn_exp2f(fminf(t, 21.0f) * 1.44269504f);
+    const float u = 1.0f + z;
+    const float l = (z < 0.0009765625f) ? z * (1.0f - 0.5f * z) : __builtin_amdgcn_logf(u) * 0.69314718f;
+    const bool lin = t > 20.0f;
+    if (grad) *grad = lin ? 1.0f : z * __builtin_amdgcn_rcpf(u);
+    return lin ? x : l * 0.01f;
 }
 
 // One dense layer on the LDS tile: act[64][K] -> act[64][256] (in place).
@@ -87,19 +108,31 @@ __device__ __forceinline__ void nm_mlp_layer(float* act, const float* __restrict
     const float* b1p = W + (size_t)(n0 + 32 + li) * Kpad + 8 * h;
     const int nJ = Kpad >> 4;
     const int nJ1 = k_hi >> 4;
+    // operands of step J+1 are fetched while the 16-32 MFMAs of step J run
+    float4 nb00 = *reinterpret_cast<const float4*>(b0p), nb01 = *reinterpret_cast<const float4*>(b0p + 4);
+    float4 nb10 = *reinterpret_cast<const float4*>(b1p), nb11 = *reinterpret_cast<const float4*>(b1p + 4);
+    float4 na00 = *reinterpret_cast<const float4*>(a0p), na01 = *reinterpret_cast<const float4*>(a0p + 4);
+    float4 na10 = *reinterpret_cast<const float4*>(a1p), na11 = *reinterpret_cast<const float4*>(a1p + 4);
     for (int J = 0; J < nJ; ++J) {
-        const float4 b00 = *reinterpret_cast<const float4*>(b0p + 16 * J);
-        const float4 b01 = *reinterpret_cast<const float4*>(b0p + 16 * J + 4);
-        const float4 b10 = *reinterpret_cast<const float4*>(b1p + 16 * J);
-        const float4 b11 = *reinterpret_cast<const float4*>(b1p + 16 * J + 4);
-        const float4 a00 = *reinterpret_cast<const float4*>(a0p + 16 * J);
-        const float4 a01 = *reinterpret_cast<const float4*>(a0p + 16 * J + 4);
+        const float4 b00 = nb00, b01 = nb01, b10 = nb10, b11 = nb11;
+        const float4 a00 = na00, a01 = na01, a10 = na10, a11 = na11;
+        if (J + 1 < nJ) {
+            const int o = 16 * (J + 1);
+            nb00 = *reinterpret_cast<const float4*>(b0p + o);
+            nb01 = *reinterpret_cast<const float4*>(b0p + o + 4);
+            nb10 = *reinterpret_cast<const float4*>(b1p + o);
+            nb11 = *reinterpret_cast<const float4*>(b1p + o + 4);
+            na00 = *reinterpret_cast<const float4*>(a0p + o);
+            na01 = *reinterpret_cast<const float4*>(a0p + o + 4);
+            if (J + 1 < nJ1) {
+                na10 = *reinterpret_cast<const float4*>(a1p + o);
+                na11 = *reinterpret_cast<const float4*>(a1p + o + 4);
+            }
+        }
         const float av0[8] = {a00.x, a00.y, a00.z, a00.w, a01.x, a01.y, a01.z, a01.w};
         const float bv0[8] = {b00.x, b00.y, b00.z, b00.w, b01.x, b01.y, b01.z, b01.w};
         const float bv1[8] = {b10.x, b10.y, b10.z, b10.w, b11.x, b11.y, b11.z, b11.w};
         if (J < nJ1) {
-            const float4 a10 = *reinterpret_cast<const float4*>(a1p + 16 * J);
-            const float4 a11 = *reinterpret_cast<const float4*>(a1p + 16 * J + 4);
             const float av1[8] = {a10.x, a10.y, a10.z, a10.w, a11.x, a11.y, a11.z, a11.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -229,7 +262,7 @@ template <bool NABLA, bool VALU_CHECK>
 __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, const float* __restrict__ table,
                                                             const float* __restrict__ ds, const int* __restrict__ idx,
                                                             const float* __restrict__ w, const float* __restrict__ grad,
-                                                            long long npts, float* __restrict__ sdf_out, int P,
+                                                            NmRecMap rmap, long long npts, float* __restrict__ sdf_out, int P,
                                                             int stride, int off, float* __restrict__ nabla_out,
                                                             float* __restrict__ valu_tmp) {
     __shared__ __attribute__((aligned(16))) float act[NM_ROWS * NM_LDS_STRIDE + NM_ROWS];
@@ -252,7 +285,8 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, con
             continue;
         }
         for (int c = prm.in_dim + j; c < Kpad0; c += 8) row[c] = 0.f;
-        const float dsv = ds[q];
+        const long long rq = nm_rec_index(rmap, q);
+        const float dsv = ds[rq];
         if (j == 0) {
             row[0] = dsv;
             if (NABLA) trow[0] = 1.0f;
@@ -272,8 +306,8 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, con
         int idx8[8];
         float w8[8];
         {
-            const int4 i0 = *reinterpret_cast<const int4*>(idx + q * 8), i1 = *reinterpret_cast<const int4*>(idx + q * 8 + 4);
-            const float4 w0 = *reinterpret_cast<const float4*>(w + q * 8), w1 = *reinterpret_cast<const float4*>(w + q * 8 + 4);
+            const int4 i0 = *reinterpret_cast<const int4*>(idx + rq * 8), i1 = *reinterpret_cast<const int4*>(idx + rq * 8 + 4);
+            const float4 w0 = *reinterpret_cast<const float4*>(w + rq * 8), w1 = *reinterpret_cast<const float4*>(w + rq * 8 + 4);
             idx8[0] = i0.x; idx8[1] = i0.y; idx8[2] = i0.z; idx8[3] = i0.w;
             idx8[4] = i1.x; idx8[5] = i1.y; idx8[6] = i1.z; idx8[7] = i1.w;
             w8[0] = w0.x; w8[1] = w0.y; w8[2] = w0.z; w8[3] = w0.w;
@@ -312,9 +346,10 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, con
             if (sdf_out) sdf_out[(q / P) * stride + off + (q % P)] = sdf;
             if (NABLA && nabla_out) {
                 const float dsdf = red[32 + threadIdx.x];
-                nabla_out[q * 3 + 0] = dsdf * grad[q * 3 + 0];
-                nabla_out[q * 3 + 1] = dsdf * grad[q * 3 + 1];
-                nabla_out[q * 3 + 2] = dsdf * grad[q * 3 + 2];
+                const long long rq = nm_rec_index(rmap, q);
+                nabla_out[q * 3 + 0] = dsdf * grad[rq * 3 + 0];
+                nabla_out[q * 3 + 1] = dsdf * grad[rq * 3 + 1];
+                nabla_out[q * 3 + 2] = dsdf * grad[rq * 3 + 2];
             }
         }
     }

@@ -90,8 +90,13 @@ NM_HD void nm_ray_bounds(const float* ds_probe, int stride, int G, float thresh,
 // One up-sampling iteration (renderer.py:209-245 + rend_util.py:276-319, det=True):
 // reads sorted d[0..n), sdf[0..n); writes n_new new depths to d_new[0..n_new).
 // w and cdf are caller-provided scratch of >= n floats.
+// If radius != nullptr: radius[slot] is the distance from an earlier sample (identified by
+// slot[j], the position it was generated at) to its K-th nearest vertex; bound_new[i] then receives
+// an upper bound of the K-th-neighbour distance of the i-th new sample: radius of the sample just
+// below it on the same ray + the depth gap (triangle inequality, the direction is a unit vector).
 NM_HD void nm_ray_upsample(const float* d, const float* sdf, int n, int it, int n_new, float* d_new,
-                           float* w, float* cdf) {
+                           float* w, float* cdf, const int* slot = nullptr, const float* radius = nullptr,
+                           float* bound_new = nullptr) {
     const float s = (float)(256 << it);
     float prev_dot = 0.f;
     double T = 1.0;      // cumprod accumulator (float64, rounded to fp32 per element like torch CPU)
@@ -128,24 +133,34 @@ NM_HD void nm_ray_upsample(const float* d, const float* sdf, int n, int it, int 
         float den = nm_sub(cdf[above], cdf[below]);
         if (den < 1e-5f) den = 1.0f;
         const float t = nm_div(nm_sub(u, cdf[below]), den);
-        d_new[i] = nm_add(d[below], nm_mul(t, nm_sub(d[above], d[below])));
+        const float dn = nm_add(d[below], nm_mul(t, nm_sub(d[above], d[below])));
+        d_new[i] = dn;
+        if (radius) {
+            const float rb = radius[slot[below]] + fabsf(dn - d[below]);
+            const float ra = radius[slot[above]] + fabsf(dn - d[above]);
+            bound_new[i] = fminf(rb, ra);
+        }
     }
 }
 
 // renderer.py:255-258: sorted d[0..n) + unsorted tail d[n..n+m) -> sorted d[0..n+m), sdf follows.
 // Stable (tail elements go after equal prefix elements); equal depths are equal points and the
 // field is deterministic per point, so the tie order cannot change any value.
-NM_HD void nm_ray_merge(float* d, float* sdf, int n, int m) {
+// slot (optional): slot[j] = generation position of the sample now at sorted position j; the
+// tail elements enter with their own position as slot id.
+NM_HD void nm_ray_merge(float* d, float* sdf, int n, int m, int* slot = nullptr) {
     for (int t = n; t < n + m; ++t) {
         const float dv = d[t], sv = sdf[t];
         int p = t;
         while (p > 0 && d[p - 1] > dv) {
             d[p] = d[p - 1];
             sdf[p] = sdf[p - 1];
+            if (slot) slot[p] = slot[p - 1];
             --p;
         }
         d[p] = dv;
         sdf[p] = sv;
+        if (slot) slot[p] = t;
     }
 }
 

@@ -32,7 +32,9 @@ class GridHandle:
     """Owns an nm_grid_t."""
 
     def __init__(self, vertices: torch.Tensor, leaf_level: int = 0):
+        import os
         lib = _lib.load()
+        leaf_level = int(os.environ.get("NEUMESH_LEAF_LEVEL", leaf_level))  # tuning knob; 0 = automatic
         if not vertices.is_cuda:
             raise _lib.NeuMeshHipError("MeshGrid needs a CUDA/HIP device tensor (no CPU fallback)")
         v = vertices.detach().to(torch.float32).contiguous()

@@ -59,6 +59,26 @@ int hc_knn(void* p, const float* q, int64_t Q, int K, int64_t* idx, float* d2) {
     return 0;
 }
 
+// warm-started search: bound[i] = upper bound of the distance from q[i] to its 8th nearest vertex
+// (inflated exactly as nm_init_bound does on the device)
+int hc_knn_warm(void* p, const float* q, int64_t Q, const float* bound, int64_t* idx, float* d2, double* out) {
+    const NmGridView v = nm_host_view(((HostGridHandle*)p)->g);
+    long long st[2] = {0, 0};
+    for (int64_t i = 0; i < Q; ++i) {
+        float bd[8];
+        int bi[8];
+        const float b = bound[i] * 1.0001f + 1e-5f;
+        nm_knn_search<8, true>(v, q[3 * i], q[3 * i + 1], q[3 * i + 2], bd, bi, st, b * b);
+        for (int k = 0; k < 8; ++k) {
+            idx[i * 8 + k] = bi[k] != 0x7fffffff ? bi[k] : -1;
+            d2[i * 8 + k] = bd[k];
+        }
+    }
+    out[0] = (double)st[0] / (double)(Q > 0 ? Q : 1);
+    out[1] = (double)st[1] / (double)(Q > 0 ? Q : 1);
+    return 0;
+}
+
 // average traversal cost per query: out[0] = node records tested, out[1] = vertices scanned
 int hc_knn_stats(void* p, const float* q, int64_t Q, double* out) {
     const NmGridView v = nm_host_view(((HostGridHandle*)p)->g);
@@ -192,6 +212,18 @@ void hc_ray_upsample(float* d, const float* sdf, int64_t R, int cap, int n, int 
 
 void hc_ray_merge(float* d, float* sdf, int64_t R, int cap, int n, int m) {
     for (int64_t r = 0; r < R; ++r) nm_ray_merge(d + r * cap, sdf + r * cap, n, m);
+}
+
+// up-sampling with slot tracking and warm-start bounds, as nm_rays_upsample_kernel does
+void hc_ray_upsample_slots(float* d, float* sdf, int* slot, const float* radius, float* bound, int64_t R, int cap, int n,
+                           int m, int it, int n_new) {
+    for (int64_t r = 0; r < R; ++r) {
+        float w[NM_MAX_SAMPLES], cdf[NM_MAX_SAMPLES];
+        int* sl = slot + r * cap;
+        if (m > 0) nm_ray_merge(d + r * cap, sdf + r * cap, n - m, m, sl);
+        else for (int j = 0; j < n; ++j) sl[j] = j;
+        nm_ray_upsample(d + r * cap, sdf + r * cap, n, it, n_new, d + r * cap + n, w, cdf, sl, radius + r * cap, bound + r * cap + n);
+    }
 }
 
 void hc_ray_composite(const float* sdf, const float* d, int64_t R, int N, float s, const float* rgb_mid,

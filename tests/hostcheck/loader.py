@@ -38,6 +38,8 @@ def load():
         lib.hc_grid_occupied.argtypes = [C.c_void_p]
         lib.hc_knn.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_int, i64p, f32p]
         lib.hc_knn_stats.argtypes = [C.c_void_p, f32p, C.c_int64, C.POINTER(C.c_double)]
+        lib.hc_knn_warm.argtypes = [C.c_void_p, f32p, C.c_int64, f32p, i64p, f32p, C.POINTER(C.c_double)]
+        lib.hc_ray_upsample_slots.argtypes = [f32p, f32p, C.POINTER(C.c_int32), f32p, f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         lib.hc_knn_packet.argtypes = [C.c_void_p, f32p, C.c_int64, C.c_int, i64p, f32p, C.POINTER(C.c_double)]
         lib.hc_compute_distance.argtypes = [C.c_void_p, f32p, C.c_int64, f32p, C.c_float, f32p, i64p, f32p, f32p]
         lib.hc_linspace01.argtypes = [C.c_int, f32p]
@@ -81,6 +83,15 @@ class HostGrid:
         out = (C.c_double * 2)()
         self.lib.hc_knn_stats(self.h, P(q), len(q), out)
         return out[0], out[1]
+
+    def knn_warm(self, q, bound):
+        q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
+        b = np.ascontiguousarray(bound, np.float32).reshape(-1)
+        idx = np.empty((len(q), 8), np.int64)
+        d2 = np.empty((len(q), 8), np.float32)
+        out = (C.c_double * 2)()
+        assert self.lib.hc_knn_warm(self.h, P(q), len(q), P(b), P(idx), P(d2), out) == 0
+        return idx, d2, out[0], out[1]
 
     def knn_packet(self, q, width=64):
         """Packet traversal emulation: (idx, d2, nodes per packet, vertices per packet)."""

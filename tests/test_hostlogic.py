@@ -146,3 +146,81 @@ def test_composite_matches_reference_fixture():
     np.testing.assert_allclose(acc, rf["mask_volume"], atol=2e-6)
     np.testing.assert_allclose(depth, rf["depth_volume"], atol=2e-5)   # d_all is recovered to ~1e-7 only
     np.testing.assert_allclose(nrm, rf["normals_volume"], atol=2e-6)
+
+
+def test_fast_softplus_formula():
+    """numpy emulation of nm_softplus100 (neumesh_amd/csrc/nm_mlp.h): exp2/log2-based softplus and
+    derivative vs float64 truth -- same error class as the libm fp32 form torch uses."""
+    from oracle.field import softplus100, softplus100_grad
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-0.3, 0.3, 400000), rng.uniform(-1e-3, 1e-3, 50000), rng.uniform(0.19, 0.21, 5000),
+                        np.array([-10.0, -1.0, 0.0, 0.2, 0.2000001, 5.0])]).astype(np.float32)
+    f = np.float32
+    t = x * f(100)
+    z = np.exp2(np.minimum(t, f(21)) * f(1.44269504)).astype(np.float32)
+    u = f(1) + z
+    lg = np.where(z < f(2 ** -10), z * (f(1) - f(0.5) * z), np.log2(u).astype(np.float32) * f(0.69314718)).astype(np.float32)
+    y = np.where(t > 20, x, lg * f(0.01)).astype(np.float32)
+    g = np.where(t > 20, f(1), z / u).astype(np.float32)
+    xd = x.astype(np.float64)
+    with np.errstate(over="ignore"):
+        yt = np.where(xd * 100 > 20, xd, np.log1p(np.exp(xd * 100)) / 100)
+        gt = np.where(xd * 100 > 20, 1.0, 1 / (1 + np.exp(-xd * 100)))
+    assert np.abs(y - yt).max() < 6e-8 and np.abs(g - gt).max() < 3e-7
+    assert np.abs(y - softplus100(x)).max() < 6e-8 and np.abs(g - softplus100_grad(x)).max() < 3e-7
+
+
+def test_warm_started_search_is_exact_and_cheaper():
+    """Warm start: bound = (distance of a neighbouring sample to its 8th vertex) + (gap between the two
+    samples) is a valid upper bound, so the warm search returns the same K-NN, visiting fewer nodes."""
+    mesh = common.scene_mesh(20000)
+    g = HostGrid(mesh.vertices)
+    rng = np.random.default_rng(4)
+    o = rng.uniform(-0.2, 0.2, (64, 3)).astype(np.float32) + np.array([2.0, 0, 0], np.float32)
+    dirs = orender.normalize((-o + 0.3 * rng.standard_normal((64, 3))).astype(np.float32))
+    t = np.sort(rng.uniform(1.0, 3.0, (64, 40)).astype(np.float32), axis=1)
+    pts = (o[:, None, :] + t[..., None] * dirs[:, None, :]).astype(np.float32)
+    ridx, rd2 = oknn.knn_bruteforce(pts.reshape(-1, 3), mesh.vertices, 8)
+    R = np.sqrt(rd2[:, 7]).reshape(64, 40)
+    gap = np.linalg.norm(pts[:, 1:] - pts[:, :-1], axis=-1)
+    bound = np.concatenate([np.full((64, 1), 1e9, np.float32), (R[:, :-1] + gap).astype(np.float32)], 1)   # from the previous sample
+    idx, d2, n_nodes, n_verts = g.knn_warm(pts.reshape(-1, 3), bound.reshape(-1))
+    assert np.array_equal(idx, ridx) and np.array_equal(d2, rd2)
+    cold = g.knn_stats(pts.reshape(-1, 3))
+    assert n_nodes < cold[0] and n_verts < 0.9 * cold[1]   # mostly saves vertex visits / top-K insertions
+
+
+def test_upsample_slot_tracking_and_bounds():
+    """nm_rays_upsample_kernel's bookkeeping: slot[j] always names the generation position of the
+    sample now at sorted position j, and the emitted warm-start bounds are valid upper bounds."""
+    import ctypes as C
+    lib = load()
+    rf = common.golden("render_v3000_dtu")
+    mesh = common.scene_mesh(3000)
+    orc = common.make_oracle(mesh, common.scene_state(mesh))
+    R, cap = len(rf["rays_o"]), 128
+    odir = orender.normalize(rf["rays_d"])
+    d = np.zeros((R, cap), np.float32); sdf = np.zeros((R, cap), np.float32)
+    slot = np.zeros((R, cap), np.int32); radius = np.zeros((R, cap), np.float32); bound = np.zeros((R, cap), np.float32)
+    gen_d = np.zeros((R, cap), np.float32)      # depth by generation position
+    d[:, :64], sdf[:, :64] = rf["d_coarse"], rf["sdf_coarse"]
+    gen_d[:, :64] = rf["d_coarse"]
+
+    def true_radius(dep):
+        pts = (rf["rays_o"][:, None, :] + dep[..., None] * odir[:, None, :]).astype(np.float32)
+        _, d2 = oknn.knn_bruteforce(pts.reshape(-1, 3), mesh.vertices, 8)
+        return np.sqrt(d2[:, 7]).reshape(dep.shape), pts
+    radius[:, :64], _ = true_radius(rf["d_coarse"])
+    n, pending = 64, 0
+    i32p = C.POINTER(C.c_int32)
+    for it in range(4):
+        lib.hc_ray_upsample_slots(P(d), P(sdf), slot.ctypes.data_as(i32p), P(radius), P(bound), R, cap, n, pending, it, 16)
+        assert np.array_equal(np.take_along_axis(gen_d, slot[:, :n].astype(np.int64), 1), d[:, :n])     # slots consistent
+        assert np.all(np.diff(d[:, :n], axis=1) >= 0)
+        new = d[:, n:n + 16].copy()
+        gen_d[:, n:n + 16] = new
+        rad_new, pts = true_radius(new)
+        assert np.all(bound[:, n:n + 16] * 1.0001 + 1e-5 >= rad_new)                                   # valid upper bounds
+        radius[:, n:n + 16] = rad_new
+        sdf[:, n:n + 16] = orc.forward_density_only(pts)[..., 0]
+        n += 16; pending = 16
