@@ -76,6 +76,7 @@ SIGNATURES = {
 }
 # test hook, not part of the public header
 _EXTRA = {
+    "nm_debug_phase_log": (C.c_int, [_P]),
     "nm_selfcheck_field": (C.c_int, [_P, _P, C.POINTER(FieldTables), _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P]),
 }
 
@@ -87,7 +88,7 @@ class NeuMeshHipError(RuntimeError):
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    return os.environ.get("NEUMESH_HIP_LIB", _build.LIB_PATH)   # override: experiments only
 
 
 def load(require_device: bool = True):

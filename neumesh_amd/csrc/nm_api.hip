@@ -179,13 +179,21 @@ int nm_knn(nm_grid_t g, const float* q, int64_t Q, int K, int64_t* idx, float* d
     return 0;
 }
 
+static const NmRecMap NM_COMPACT = {1, 0, 0, nullptr};
+
+struct NmGather {  // optional gather-interpolation outputs of the distance kernel
+    const float* geo_table; int gdim; float* fg;
+    const float* col_table; int cdim; float* ft;
+};
+static const NmGather NM_NO_GATHER = {nullptr, 0, nullptr, nullptr, 0, nullptr};
+
 static int nm_launch_distance(nm_grid_t g, const NmPointSrc& src, long long Q, const float* indicator, float w1,
                               float* ds, int* idx32, long long* idx64, float* w, float* grad, hipStream_t stream,
-                              float* radius = nullptr) {
+                              float* radius = nullptr, NmGather ga = NM_NO_GATHER) {
     if (Q <= 0) return 0;
     NmProfScope prof(NM_K_DISTANCE, Q, stream);
     hipLaunchKernelGGL(nm_distance_kernel, dim3(nm_query_blocks(src, Q)), dim3(256), 0, stream, g->view, src, Q, g->verts,
-                       indicator, w1, ds, idx32, idx64, w, grad, radius);
+                       indicator, w1, ds, idx32, idx64, w, grad, radius, ga.geo_table, ga.gdim, ga.fg, ga.col_table, ga.cdim, ga.ft);
     NM_LAUNCH_CHECK();
     return 0;
 }
@@ -310,24 +318,28 @@ int nm_field_destroy(nm_field_t f) {
     return 0;
 }
 
-// scratch layout for P points: ds | idx32[8] | w[8] | grad[3] | nabla[3] | valu_tmp (self-check only)
+// scratch layout for P points: ds | idx32[8] | w[8] | grad[3] | nabla[3] | fg[64] | ft[64]
 struct NmScratch {
     float* ds;
     int* idx;
     float* w;
     float* grad;
     float* nabla;
+    float* fg;  // interpolated geometry codes [P][geometry_dim]
+    float* ft;  // interpolated colour codes   [P][color_dim]
     size_t bytes;
 };
-static NmScratch nm_carve(void* base, long long P) {
+static NmScratch nm_carve(void* base, long long P, bool with_idx_w = true) {
     NmScratch s;
     char* p = (char*)base;
     size_t o = 0;
     s.ds = (float*)(p + o);    o += nm_align((size_t)P * 4);
-    s.idx = (int*)(p + o);     o += nm_align((size_t)P * 32);
-    s.w = (float*)(p + o);     o += nm_align((size_t)P * 32);
+    s.idx = (int*)(p + o);     o += nm_align(with_idx_w ? (size_t)P * 32 : 0);
+    s.w = (float*)(p + o);     o += nm_align(with_idx_w ? (size_t)P * 32 : 0);
     s.grad = (float*)(p + o);  o += nm_align((size_t)P * 12);
     s.nabla = (float*)(p + o); o += nm_align((size_t)P * 12);
+    s.fg = (float*)(p + o);    o += nm_align((size_t)P * 64 * 4);
+    s.ft = (float*)(p + o);    o += nm_align((size_t)P * 64 * 4);
     s.bytes = o;
     return s;
 }
@@ -340,30 +352,28 @@ static int nm_check_field_args(nm_field_t f, nm_grid_t g, const nm_field_tables*
     return 0;
 }
 
-static const NmRecMap NM_COMPACT = {1, 0, 0, nullptr};
-
-static int nm_launch_geo(nm_field_t f, const float* table, const float* ds, const int* idx, const float* w,
-                         const float* grad, long long P, bool nabla, float* sdf, int Pper, int stride, int off,
-                         float* nabla_out, hipStream_t stream, NmRecMap rmap = NM_COMPACT) {
+static int nm_launch_geo(nm_field_t f, const float* fg, const float* ds, const float* grad, long long P, bool nabla,
+                         float* sdf, int Pper, int stride, int off, float* nabla_out, hipStream_t stream,
+                         NmRecMap rmap = NM_COMPACT) {
     if (P <= 0) return 0;
     NmProfScope prof(nabla ? NM_K_GEO_NABLA : NM_K_GEO, P, stream);
     if (nabla) {
-        hipLaunchKernelGGL((nm_geo_mlp_kernel<true, false>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo, table, ds,
-                           idx, w, grad, rmap, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr);
+        hipLaunchKernelGGL((nm_geo_mlp_kernel<true, false>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo, fg, ds,
+                           grad, rmap, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr);
     } else {
-        hipLaunchKernelGGL((nm_geo_mlp_kernel<false, false>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->geo, table, ds,
-                           idx, w, grad, rmap, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr);
+        hipLaunchKernelGGL((nm_geo_mlp_kernel<false, false>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->geo, fg, ds,
+                           grad, rmap, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr);
     }
     NM_LAUNCH_CHECK();
     return 0;
 }
 
-static int nm_launch_col(nm_field_t f, const float* table, const float* ds, const int* idx, const float* w,
-                         const float* nabla, const float* dirs, int dir_div, long long P, float* rgb, hipStream_t stream) {
+static int nm_launch_col(nm_field_t f, const float* ft, const float* ds, const float* nabla, const float* dirs, int dir_div,
+                         long long P, float* rgb, hipStream_t stream) {
     if (P <= 0) return 0;
     NmProfScope prof(NM_K_COLOR, P, stream);
-    hipLaunchKernelGGL((nm_col_mlp_kernel<false>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->col, table, ds, idx, w,
-                       nabla, dirs, dir_div, P, rgb, (float*)nullptr);
+    hipLaunchKernelGGL((nm_col_mlp_kernel<false>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->col, ft, ds, nabla, dirs,
+                       dir_div, P, rgb, (float*)nullptr);
     NM_LAUNCH_CHECK();
     return 0;
 }
@@ -375,9 +385,10 @@ int nm_field_density(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const 
     if (P < 0 || (P > 0 && (!xyz || !sdf || !scratch))) return nm_fail("nm_field_density: bad arguments");
     if (P == 0) return 0;
     const NmScratch s = nm_carve(scratch, P);
-    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx, nullptr, s.w,
-                           nabla ? s.grad : nullptr, stream)) return 1;
-    return nm_launch_geo(f, t->geometry_features, s.ds, s.idx, s.w, s.grad, P, nabla != nullptr, sdf, 1, 1, 0, nabla, stream);
+    const NmGather ga = {t->geometry_features, f->geo.gdim, s.fg, nullptr, 0, nullptr};
+    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr,
+                           nabla ? s.grad : nullptr, stream, nullptr, ga)) return 1;
+    return nm_launch_geo(f, s.fg, s.ds, s.grad, P, nabla != nullptr, sdf, 1, 1, 0, nabla, stream);
 }
 
 int nm_field_forward(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const float* xyz, const float* view_dirs,
@@ -388,13 +399,13 @@ int nm_field_forward(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const 
     if (P < 0 || (P > 0 && (!xyz || !view_dirs || !sdf || !rgb || !scratch))) return nm_fail("nm_field_forward: bad arguments");
     if (P == 0) return 0;
     const NmScratch s = nm_carve(scratch, P);
-    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx,
-                           reinterpret_cast<long long*>(idx), s.w, s.grad, stream)) return 1;
+    const NmGather ga = {t->geometry_features, f->geo.gdim, s.fg, t->color_features, f->col.cdim, s.ft};
+    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr,
+                           reinterpret_cast<long long*>(idx), w, s.grad, stream, nullptr, ga)) return 1;
     float* nab = nabla ? nabla : s.nabla;
-    if (nm_launch_geo(f, t->geometry_features, s.ds, s.idx, s.w, s.grad, P, true, sdf, 1, 1, 0, nab, stream)) return 1;
-    if (nm_launch_col(f, t->color_features, s.ds, s.idx, s.w, nab, view_dirs, 1, P, rgb, stream)) return 1;
+    if (nm_launch_geo(f, s.fg, s.ds, s.grad, P, true, sdf, 1, 1, 0, nab, stream)) return 1;
+    if (nm_launch_col(f, s.ft, s.ds, nab, view_dirs, 1, P, rgb, stream)) return 1;
     if (ds) NM_HIP(hipMemcpyAsync(ds, s.ds, (size_t)P * 4, hipMemcpyDeviceToDevice, stream));
-    if (w) NM_HIP(hipMemcpyAsync(w, s.w, (size_t)P * 32, hipMemcpyDeviceToDevice, stream));
     return 0;
 }
 
@@ -406,10 +417,10 @@ int nm_field_color(nm_field_t f, const float* color_features, const float* ds, c
     if (f->col.use_nabla && !nabla && P > 0) return nm_fail("nm_field_color: nabla required (enable_nablas_input)");
     if (P == 0) return 0;
     const NmScratch s = nm_carve(scratch, P);
-    hipLaunchKernelGGL(nm_idx64_to_32_kernel, dim3(nm_blocks(P * 8, 256)), dim3(256), 0, stream,
-                       reinterpret_cast<const long long*>(idx), (long long)P * 8, s.idx);
+    hipLaunchKernelGGL(nm_interp_kernel, dim3(nm_blocks(P, 256)), dim3(256), 0, stream, color_features, f->col.cdim,
+                       reinterpret_cast<const long long*>(idx), (const int*)nullptr, w, (long long)P, s.ft);
     NM_LAUNCH_CHECK();
-    return nm_launch_col(f, color_features, ds, s.idx, w, nabla, view_dirs, 1, P, rgb, stream);
+    return nm_launch_col(f, s.ft, ds, nabla, view_dirs, 1, P, rgb, stream);
 }
 
 // ============================================================================== renderer
@@ -442,9 +453,9 @@ static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) 
     w.radius = (float*)take((size_t)R * N * 4);
     w.bound = (float*)take((size_t)R * N * 4);
     w.bound_mid = (float*)take((size_t)R * N * 4);
-    w.slots = nm_carve(p + o, R * N);
+    w.slots = nm_carve(p + o, R * N, false);
     o += w.slots.bytes;
-    w.pts = nm_carve(p + o, R * N);
+    w.pts = nm_carve(p + o, R * N, false);
     o += w.pts.bytes;
     w.bytes = o;
     return w;
@@ -512,6 +523,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     // deterministic kernel => bit-identical record), and every later search is warm-started with
     // the cached K-th-neighbour radius of the neighbouring sample on its ray.
     const bool want_grad = c->calc_normal != 0;
+    const NmGather ga_slots = {t->geometry_features, f->geo.gdim, ws.slots.fg, nullptr, 0, nullptr};
     src.mode = 2;
     src.P = c->N_samples;
     src.nearfar = nf;
@@ -520,10 +532,10 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     src.bound = nullptr;
     src.out_stride = cap;
     src.out_off = 0;
-    if (nm_launch_distance(g, src, (long long)R * c->N_samples, t->indicator_vector, t->indicator_weight, ws.slots.ds, ws.slots.idx, nullptr, ws.slots.w, want_grad ? ws.slots.grad : nullptr, stream, ws.radius)) return 1;
+    if (nm_launch_distance(g, src, (long long)R * c->N_samples, t->indicator_vector, t->indicator_weight, ws.slots.ds, nullptr, nullptr, nullptr, want_grad ? ws.slots.grad : nullptr, stream, ws.radius, ga_slots)) return 1;
     {
         const NmRecMap rm = {c->N_samples, cap, 0, nullptr};
-        if (nm_launch_geo(f, t->geometry_features, ws.slots.ds, ws.slots.idx, ws.slots.w, nullptr, (long long)R * c->N_samples, false, ws.sdf, c->N_samples, cap, 0, nullptr, stream, rm)) return 1;
+        if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, nullptr, (long long)R * c->N_samples, false, ws.sdf, c->N_samples, cap, 0, nullptr, stream, rm)) return 1;
     }
     if (dbg && dbg->sdf_coarse) {
         hipLaunchKernelGGL(nm_copy_strided_kernel, dim3(nm_blocks(R * c->N_samples, 256)), dim3(256), 0, stream, ws.sdf, (long long)R, c->N_samples, cap, dbg->sdf_coarse);
@@ -544,9 +556,9 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
             src.bound = ws.bound;
             src.out_stride = cap;
             src.out_off = n;
-            if (nm_launch_distance(g, src, (long long)R * n_new, t->indicator_vector, t->indicator_weight, ws.slots.ds, ws.slots.idx, nullptr, ws.slots.w, want_grad ? ws.slots.grad : nullptr, stream, ws.radius)) return 1;
+            if (nm_launch_distance(g, src, (long long)R * n_new, t->indicator_vector, t->indicator_weight, ws.slots.ds, nullptr, nullptr, nullptr, want_grad ? ws.slots.grad : nullptr, stream, ws.radius, ga_slots)) return 1;
             const NmRecMap rm = {n_new, cap, n, nullptr};
-            if (nm_launch_geo(f, t->geometry_features, ws.slots.ds, ws.slots.idx, ws.slots.w, nullptr, (long long)R * n_new, false, ws.sdf, n_new, cap, n, nullptr, stream, rm)) return 1;
+            if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, nullptr, (long long)R * n_new, false, ws.sdf, n_new, cap, n, nullptr, stream, rm)) return 1;
             n += n_new;
             pending = n_new;
         }
@@ -557,7 +569,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     // normals the SDF values merged above ARE forward_density_only(pts) (same points, same kernel).
     if (c->calc_normal) {
         const NmRecMap rm = {N, cap, 0, ws.slot};
-        if (nm_launch_geo(f, t->geometry_features, ws.slots.ds, ws.slots.idx, ws.slots.w, ws.slots.grad, (long long)R * N, true, ws.sdf, N, cap, 0, ws.nab_pts, stream, rm)) return 1;
+        if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, ws.slots.grad, (long long)R * N, true, ws.sdf, N, cap, 0, ws.nab_pts, stream, rm)) return 1;
     }
     // SDF + nabla + radiance at the N-1 mid-points (renderer.py:266-267, 279-282)
     src.mode = 1;
@@ -568,9 +580,12 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     src.bound = ws.bound_mid;
     src.out_stride = 0;
     src.out_off = 0;
-    if (nm_launch_distance(g, src, (long long)R * (N - 1), t->indicator_vector, t->indicator_weight, ws.pts.ds, ws.pts.idx, nullptr, ws.pts.w, ws.pts.grad, stream)) return 1;
-    if (nm_launch_geo(f, t->geometry_features, ws.pts.ds, ws.pts.idx, ws.pts.w, ws.pts.grad, (long long)R * (N - 1), true, nullptr, 1, 1, 0, ws.nab_mid, stream)) return 1;
-    if (nm_launch_col(f, t->color_features, ws.pts.ds, ws.pts.idx, ws.pts.w, ws.nab_mid, ws.dirn, N - 1, (long long)R * (N - 1), ws.rgb_mid, stream)) return 1;
+    {
+        const NmGather ga_mid = {t->geometry_features, f->geo.gdim, ws.pts.fg, t->color_features, f->col.cdim, ws.pts.ft};
+        if (nm_launch_distance(g, src, (long long)R * (N - 1), t->indicator_vector, t->indicator_weight, ws.pts.ds, nullptr, nullptr, nullptr, ws.pts.grad, stream, nullptr, ga_mid)) return 1;
+    }
+    if (nm_launch_geo(f, ws.pts.fg, ws.pts.ds, ws.pts.grad, (long long)R * (N - 1), true, nullptr, 1, 1, 0, ws.nab_mid, stream)) return 1;
+    if (nm_launch_col(f, ws.pts.ft, ws.pts.ds, ws.nab_mid, ws.dirn, N - 1, (long long)R * (N - 1), ws.rgb_mid, stream)) return 1;
     // alpha + compositing (renderer.py:278, 302-333)
     hipLaunchKernelGGL(nm_rays_composite_kernel, rgrid, rblock, 0, stream, ws.sdf, ws.d, (long long)R, cap, N, t->s, ws.rgb_mid,
                        c->calc_normal ? ws.nab_pts : (const float*)nullptr, c->white_bkgd, rgb, depth, acc, c->calc_normal ? normals : (float*)nullptr);
@@ -612,6 +627,13 @@ int nm_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* unit
     return 0;
 }
 
+// debug: install (or clear, with NULL) the device buffer the MLP kernels write phase timestamps to
+int nm_debug_phase_log(void* device_buf_32x16_i64) {
+    long long* p = (long long*)device_buf_32x16_i64;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_nm_phase_log), &p, sizeof(p)) != hipSuccess) return nm_fail("nm_debug_phase_log: hipMemcpyToSymbol failed");
+    return 0;
+}
+
 int nm_time_kernel(nm_field_t f, nm_grid_t g, const nm_field_tables* t, int which, const float* xyz, const float* view_dirs,
                    int64_t P, void* scratch, int iters, float* avg_ms, nm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -619,9 +641,10 @@ int nm_time_kernel(nm_field_t f, nm_grid_t g, const nm_field_tables* t, int whic
     if (!xyz || !scratch || !avg_ms || P < 1 || iters < 1) return nm_fail("nm_time_kernel: bad arguments");
     if (which == 3 && !view_dirs) return nm_fail("nm_time_kernel: view_dirs required for the colour kernel");
     const NmScratch s = nm_carve(scratch, P);
+    const NmGather ga = {t->geometry_features, f->geo.gdim, s.fg, t->color_features, f->col.cdim, s.ft};
     // inputs of the MLP kernels come from one K-NN pass
-    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx, nullptr, s.w, s.grad, stream)) return 1;
-    if (which == 3 && nm_launch_geo(f, t->geometry_features, s.ds, s.idx, s.w, s.grad, P, true, nullptr, 1, 1, 0, s.nabla, stream)) return 1;
+    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr, s.grad, stream, nullptr, ga)) return 1;
+    if (which == 3 && nm_launch_geo(f, s.fg, s.ds, s.grad, P, true, nullptr, 1, 1, 0, s.nabla, stream)) return 1;
     hipEvent_t e0, e1;
     NM_HIP(hipEventCreate(&e0));
     NM_HIP(hipEventCreate(&e1));
@@ -631,10 +654,10 @@ int nm_time_kernel(nm_field_t f, nm_grid_t g, const nm_field_tables* t, int whic
     for (int i = -1; i < iters && !rc; ++i) {  // i = -1: untimed warm-up
         if (i == 0) hipEventRecord(e0, stream);
         switch (which) {
-            case 0: rc = nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx, nullptr, s.w, s.grad, stream); break;
-            case 1: rc = nm_launch_geo(f, t->geometry_features, s.ds, s.idx, s.w, s.grad, P, false, sink, 1, 1, 0, nullptr, stream); break;
-            case 2: rc = nm_launch_geo(f, t->geometry_features, s.ds, s.idx, s.w, s.grad, P, true, nullptr, 1, 1, 0, sink, stream); break;
-            case 3: rc = nm_launch_col(f, t->color_features, s.ds, s.idx, s.w, s.nabla, view_dirs, 1, P, s.grad, stream); break;
+            case 0: rc = nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr, s.grad, stream, nullptr, ga); break;
+            case 1: rc = nm_launch_geo(f, s.fg, s.ds, s.grad, P, false, sink, 1, 1, 0, nullptr, stream); break;
+            case 2: rc = nm_launch_geo(f, s.fg, s.ds, s.grad, P, true, nullptr, 1, 1, 0, sink, stream); break;
+            case 3: rc = nm_launch_col(f, s.ft, s.ds, s.nabla, view_dirs, 1, P, s.grad, stream); break;
             default: rc = nm_fail("nm_time_kernel: which=%d", which);
         }
     }
@@ -659,12 +682,13 @@ int nm_selfcheck_field(nm_field_t f, nm_grid_t g, const nm_field_tables* t, cons
     if (nm_check_field_args(f, g, t, "nm_selfcheck_field")) return 1;
     if (!xyz || !view_dirs || !sdf || !nabla || !rgb || !scratch || !valu_tmp || P < 1) return nm_fail("nm_selfcheck_field: bad arguments");
     const NmScratch s = nm_carve(scratch, P);
-    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx, nullptr, s.w, s.grad, stream)) return 1;
-    hipLaunchKernelGGL((nm_geo_mlp_kernel<true, true>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo, t->geometry_features,
-                       s.ds, s.idx, s.w, s.grad, NM_COMPACT, (long long)P, sdf, 1, 1, 0, nabla, valu_tmp);
+    const NmGather ga = {t->geometry_features, f->geo.gdim, s.fg, t->color_features, f->col.cdim, s.ft};
+    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr, s.grad, stream, nullptr, ga)) return 1;
+    hipLaunchKernelGGL((nm_geo_mlp_kernel<true, true>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo, s.fg, s.ds, s.grad,
+                       NM_COMPACT, (long long)P, sdf, 1, 1, 0, nabla, valu_tmp);
     NM_LAUNCH_CHECK();
-    hipLaunchKernelGGL((nm_col_mlp_kernel<true>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->col, t->color_features, s.ds,
-                       s.idx, s.w, nabla, view_dirs, 1, (long long)P, rgb, valu_tmp);
+    hipLaunchKernelGGL((nm_col_mlp_kernel<true>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->col, s.ft, s.ds, nabla,
+                       view_dirs, 1, (long long)P, rgb, valu_tmp);
     NM_LAUNCH_CHECK();
     return 0;
 }

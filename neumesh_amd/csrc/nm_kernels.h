@@ -217,6 +217,61 @@ static inline unsigned nm_query_blocks(const NmPointSrc& s, long long Q) {
     return (unsigned)((waves + 3) / 4);  // 4 waves per 256-thread block
 }
 
+// ------------------------------------------------ gather + interpolate the per-vertex codes
+// interpolation(features, indices, weights) = sum_k features[idx_k] * w_k
+// (models/frameworks/neumesh/neumesh.py:11-13), done by the wave that just found the neighbours:
+// 8 lanes share one point, each lane owns a 16-byte chunk of the code vector (dim/4 chunks; chunks
+// beyond 8 loop), so every table row is fetched as one contiguous 128-byte segment and the result
+// is stored as a contiguous row.  k ascending, one rounding per multiply and per add.
+__device__ __forceinline__ void nm_gather_interp(const float* __restrict__ table, int dim, const int (&bi)[8],
+                                                 const float (&wk)[8], bool active, long long out_index,
+                                                 float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int grp = lane >> 3, sub = lane & 7;
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {
+        const int pl = it * 8 + grp;  // lane that owns the point this 8-lane group works on
+        const bool on = __shfl((int)active, pl) != 0;
+        const long long o = __shfl(out_index, pl);
+        int ii[8];
+        float ww[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            ii[k] = __shfl(bi[k], pl);
+            ww[k] = __shfl(wk[k], pl);
+        }
+        if (!on) continue;
+        for (int chunk = sub; chunk < (dim >> 2); chunk += 8) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 v = *reinterpret_cast<const float4*>(table + (size_t)ii[k] * dim + 4 * chunk);
+                a.x = __fadd_rn(a.x, __fmul_rn(v.x, ww[k]));
+                a.y = __fadd_rn(a.y, __fmul_rn(v.y, ww[k]));
+                a.z = __fadd_rn(a.z, __fmul_rn(v.z, ww[k]));
+                a.w = __fadd_rn(a.w, __fmul_rn(v.w, ww[k]));
+            }
+            *reinterpret_cast<float4*>(out + o * dim + 4 * chunk) = a;
+        }
+    }
+}
+
+// stand-alone form for callers that bring their own neighbours (NeuMesh.forward_color)
+__global__ __launch_bounds__(256) void nm_interp_kernel(const float* __restrict__ table, int dim,
+                                                        const long long* __restrict__ idx64, const int* __restrict__ idx32,
+                                                        const float* __restrict__ w, long long P, float* __restrict__ out) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = q < P;
+    int bi[8];
+    float wk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        bi[k] = active ? (idx64 ? (int)idx64[q * 8 + k] : idx32[q * 8 + k]) : 0;
+        wk[k] = active ? w[q * 8 + k] : 0.f;
+    }
+    nm_gather_interp(table, dim, bi, wk, active, q, out);
+}
+
 // ----------------------------------------------------------------------------- plain K-NN
 template <int K>
 __global__ __launch_bounds__(256) void nm_knn_kernel(NmGridView g, NmPointSrc src, long long Q, int Kout,
@@ -248,7 +303,9 @@ __global__ __launch_bounds__(256) void nm_distance_kernel(NmGridView g, NmPointS
                                                           float* __restrict__ ds_out, int* __restrict__ idx32_out,
                                                           long long* __restrict__ idx64_out,
                                                           float* __restrict__ w_out, float* __restrict__ grad_out,
-                                                          float* __restrict__ radius_out) {
+                                                          float* __restrict__ radius_out,
+                                                          const float* __restrict__ geo_table, int gdim, float* __restrict__ fg_out,
+                                                          const float* __restrict__ col_table, int cdim, float* __restrict__ ft_out) {
     long long q;
     const bool active = nm_lane_query(src, Q, q);
     float x = 0.f, y = 0.f, z = 0.f, init = NM_INF_F;
@@ -259,9 +316,21 @@ __global__ __launch_bounds__(256) void nm_distance_kernel(NmGridView g, NmPointS
     float bd[8], wk[8], gr[3];
     int bi[8];
     nm_knn_wave<8>(g, x, y, z, active, bd, bi, init);
+    float ds = 0.f;
+    long long o = 0;
+    if (active) {
+        ds = nm_projected_distance8(x, y, z, bd, bi, verts, indicator, w1, wk, grad_out ? gr : nullptr);
+        o = nm_out_index(src, q);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            bi[k] = 0;
+            wk[k] = 0.f;
+        }
+    }
+    if (fg_out) nm_gather_interp(geo_table, gdim, bi, wk, active, o, fg_out);
+    if (ft_out) nm_gather_interp(col_table, cdim, bi, wk, active, o, ft_out);
     if (!active) return;
-    const float ds = nm_projected_distance8(x, y, z, bd, bi, verts, indicator, w1, wk, grad_out ? gr : nullptr);
-    const long long o = nm_out_index(src, q);
     if (ds_out) ds_out[o] = ds;
     if (radius_out) radius_out[o] = nm_sqrt(bd[7]);
     if (idx32_out) {

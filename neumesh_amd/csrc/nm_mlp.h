@@ -32,6 +32,16 @@
 
 typedef float nm_f32x16 __attribute__((ext_vector_type(16)));
 
+// Debug hook (off unless nm_debug_phase_log() installed a buffer): workgroups 4096..4127 of an MLP
+// launch record the shader clock at their phase boundaries (slot 0 start, 1 after the prologue,
+// then after each layer's MFMA loop and after its epilogue, last = end), 16 stamps per workgroup.
+__device__ long long* g_nm_phase_log = nullptr;
+__device__ __forceinline__ void nm_phase_stamp(int slot) {
+    long long* log = g_nm_phase_log;
+    if (log && blockIdx.x >= 4096u && blockIdx.x < 4128u && threadIdx.x == 0 && slot < 16)
+        log[(blockIdx.x - 4096u) * 16 + slot] = (long long)clock64();
+}
+
 struct NmLayer {
     const float* W;  // packed [256][Kpad], zero padded
     const float* b;  // [256]
@@ -97,7 +107,7 @@ __device__ __forceinline__ float nm_softplus100(float x, float* grad) {
 // tangent pass, where only the d-embedding columns are live).
 template <int ACT, bool TANGENT>
 __device__ __forceinline__ void nm_mlp_layer(float* act, const float* __restrict__ W, const float* __restrict__ bias,
-                                             int Kpad, int k_hi) {
+                                             int Kpad, int k_hi, int stamp_slot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, h = lane >> 5;
     const int n0 = wave * 64;
@@ -150,6 +160,7 @@ __device__ __forceinline__ void nm_mlp_layer(float* act, const float* __restrict
         }
     }
     __syncthreads();  // every wave has finished reading the input tile
+    nm_phase_stamp(stamp_slot);
     const float bias0 = bias[n0 + li], bias1 = bias[n0 + 32 + li];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -187,6 +198,7 @@ __device__ __forceinline__ void nm_mlp_layer(float* act, const float* __restrict
         }
     }
     __syncthreads();
+    nm_phase_stamp(stamp_slot + 1);
 }
 
 // Same layer on the scalar ALUs (one output element per thread-iteration, plain fmaf chain in
@@ -219,19 +231,34 @@ __device__ void nm_mlp_layer_valu(float* act, float* tmp /*[64][256] global*/, c
     __syncthreads();
 }
 
-// sum_k features[idx_k][c*4..c*4+3] * w_k  (neumesh.py:11-13), k ascending
-__device__ __forceinline__ float4 nm_interp4(const float* __restrict__ table, int dim, const int* idx8, const float* w8, int chunk) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(table + (size_t)idx8[k] * dim + 4 * chunk);
-        const float wk = w8[k];
-        a.x = __fadd_rn(a.x, __fmul_rn(v.x, wk));
-        a.y = __fadd_rn(a.y, __fmul_rn(v.y, wk));
-        a.z = __fadd_rn(a.z, __fmul_rn(v.z, wk));
-        a.w = __fadd_rn(a.w, __fmul_rn(v.w, wk));
+// sin and cos for the positional encodings (models/base.py:52-70).  ocml's sincosf is a
+// full-range routine (~280 instructions with its large-argument path) and cost ~20 K cycles of
+// every workgroup's prologue; the encodings only see |x| < ~1e3 (codes * 2^b, ds * 2^7, view
+// directions * 2^3), so: three-term Cody-Waite reduction by pi/2 (fma) + the single-precision
+// minimax polynomials on [-pi/4, pi/4].  Max abs error vs float64 9.2e-8 for |x| <= 1e5 (libm
+// fp32: 7e-8), checked in tests/test_hostlogic.py::test_fast_sincos_formula; larger arguments
+// take the libm path.
+__device__ __forceinline__ void nm_sincos(float x, float* sn, float* cs) {
+    if (fabsf(x) > 1.0e5f) {
+        sincosf(x, sn, cs);
+        return;
     }
-    return a;
+    const float k = rintf(x * 0.63661977236758134f);
+    float r = fmaf(k, -1.57079637050628662109e+00f, x);
+    r = fmaf(k, 4.37113882867379288655e-08f, r);
+    r = fmaf(k, 1.71512451000588187280e-15f, r);
+    const int q = (int)k;
+    const float r2 = r * r;
+    float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(ps, r2, -1.6666654611e-1f);
+    const float s = fmaf(ps * r2, r, r);
+    float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(pc, r2, 4.166664568298827e-2f);
+    const float c = fmaf(pc * r2, r2, fmaf(r2, -0.5f, 1.0f));
+    const bool swap = (q & 1) != 0;
+    const float ss = swap ? c : s, cc = swap ? s : c;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
 }
 
 // writes x and its `bands` sin/cos bands for `dim`-wide feature vector chunk (4 values at
@@ -245,7 +272,7 @@ __device__ __forceinline__ void nm_embed4(float* row, int dim, int bands, int ch
         float f = 1.0f;
         for (int b = 0; b < bands; ++b) {
             float s, co;
-            sincosf(xs[e] * f, &s, &co);
+            nm_sincos(xs[e] * f, &s, &co);
             row[dim * (1 + 2 * b) + c] = s;
             row[dim * (2 + 2 * b) + c] = co;
             f *= 2.0f;
@@ -254,14 +281,13 @@ __device__ __forceinline__ void nm_embed4(float* row, int dim, int bands, int ch
 }
 
 // ------------------------------------------------------------------ geometry MLP kernel
-// Points q in [0, npts): inputs ds[q], idx[q][8], w[q][8] (from the K-NN/distance kernel) and,
-// with NABLA, grad[q][3] = d ds/d xyz.  Output sdf to sdf_out[(q / P) * stride + off + q % P]
+// Points q in [0, npts): inputs ds[rec], fg_rec[rec][gdim] (interpolated geometry code, from the
+// K-NN/distance kernel) and, with NABLA, grad[rec][3] = d ds/d xyz; rec = nm_rec_index(rmap, q).  Output sdf to sdf_out[(q / P) * stride + off + q % P]
 // (P = samples per ray of this call; P = 1, stride = 1 for flat outputs) and
 // nabla_out[q][3] = (d sdf/d ds) * grad[q].
 template <bool NABLA, bool VALU_CHECK>
-__global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, const float* __restrict__ table,
-                                                            const float* __restrict__ ds, const int* __restrict__ idx,
-                                                            const float* __restrict__ w, const float* __restrict__ grad,
+__global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, const float* __restrict__ fg_rec,
+                                                            const float* __restrict__ ds, const float* __restrict__ grad,
                                                             NmRecMap rmap, long long npts, float* __restrict__ sdf_out, int P,
                                                             int stride, int off, float* __restrict__ nabla_out,
                                                             float* __restrict__ valu_tmp) {
@@ -269,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, con
     float* red = act + NM_ROWS * NM_LDS_STRIDE;
     constexpr int PTS = NABLA ? 32 : 64;
     const long long base = (long long)blockIdx.x * PTS;
+    nm_phase_stamp(0);
     const int Kpad0 = prm.layer[0].Kpad;
     const int t_hi = ((prm.d_emb + 15) >> 4) << 4;  // live tangent columns, rounded to 16
 
@@ -295,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, con
         for (int b = j; b < prm.multires_d; b += 8) {
             const float f = (float)(1 << b);
             float s, co;
-            sincosf(dsv * f, &s, &co);
+            nm_sincos(dsv * f, &s, &co);
             row[1 + 2 * b] = s;
             row[2 + 2 * b] = co;
             if (NABLA) {
@@ -303,29 +330,23 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, con
                 trow[2 + 2 * b] = -f * s;
             }
         }
-        int idx8[8];
-        float w8[8];
-        {
-            const int4 i0 = *reinterpret_cast<const int4*>(idx + rq * 8), i1 = *reinterpret_cast<const int4*>(idx + rq * 8 + 4);
-            const float4 w0 = *reinterpret_cast<const float4*>(w + rq * 8), w1 = *reinterpret_cast<const float4*>(w + rq * 8 + 4);
-            idx8[0] = i0.x; idx8[1] = i0.y; idx8[2] = i0.z; idx8[3] = i0.w;
-            idx8[4] = i1.x; idx8[5] = i1.y; idx8[6] = i1.z; idx8[7] = i1.w;
-            w8[0] = w0.x; w8[1] = w0.y; w8[2] = w0.z; w8[3] = w0.w;
-            w8[4] = w1.x; w8[5] = w1.y; w8[6] = w1.z; w8[7] = w1.w;
-        }
+        // interpolated geometry code of the point: gathered by the K-NN kernel's epilogue
+        // (nm_gather_interp), so this is one coalesced 16-byte load instead of a dependent
+        // index -> 8-row gather chain in front of the MFMA phase
         for (int chunk = j; chunk < (prm.gdim >> 2); chunk += 8) {
-            const float4 fg = nm_interp4(table, prm.gdim, idx8, w8, chunk);
+            const float4 fg = *reinterpret_cast<const float4*>(fg_rec + rq * prm.gdim + 4 * chunk);
             nm_embed4(row + prm.d_emb, prm.gdim, prm.multires_fg, chunk, fg);
         }
     }
     __syncthreads();
+    nm_phase_stamp(1);
 
     // ---- hidden layers
     for (int l = 0; l < prm.D; ++l) {
         const NmLayer L = prm.layer[l];
         const int k_hi = (NABLA && l == 0) ? t_hi : L.Kpad;
         if (VALU_CHECK) nm_mlp_layer_valu<0, NABLA>(act, valu_tmp + (size_t)blockIdx.x * NM_ROWS * NM_W, L.W, L.b, L.Kpad);
-        else nm_mlp_layer<0, NABLA>(act, L.W, L.b, L.Kpad, k_hi);
+        else nm_mlp_layer<0, NABLA>(act, L.W, L.b, L.Kpad, k_hi, 2 + 2 * l);
     }
 
     // ---- density_linear (neumesh.py:101,218): 4 threads per row, interleaved columns
@@ -353,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, con
             }
         }
     }
+    nm_phase_stamp(15);
 }
 
 // ------------------------------------------------------------------ colour MLP kernel
@@ -360,14 +382,14 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, con
 // dirs: view direction of point q is dirs[(q / dir_div) * 3 ..] (dir_div = samples per ray when
 // every sample of a ray shares the ray direction, 1 for per-point directions).
 template <bool VALU_CHECK>
-__global__ __launch_bounds__(256, 2) void nm_col_mlp_kernel(NmColParams prm, const float* __restrict__ table,
-                                                            const float* __restrict__ ds, const int* __restrict__ idx,
-                                                            const float* __restrict__ w, const float* __restrict__ nabla,
+__global__ __launch_bounds__(256, 2) void nm_col_mlp_kernel(NmColParams prm, const float* __restrict__ ft_rec,
+                                                            const float* __restrict__ ds, const float* __restrict__ nabla,
                                                             const float* __restrict__ dirs, int dir_div, long long npts,
                                                             float* __restrict__ rgb_out, float* __restrict__ valu_tmp) {
     __shared__ __attribute__((aligned(16))) float act[NM_ROWS * NM_LDS_STRIDE + 3 * NM_ROWS];
     float* red = act + NM_ROWS * NM_LDS_STRIDE;
     const long long base = (long long)blockIdx.x * NM_ROWS;
+    nm_phase_stamp(0);
     const int Kpad0 = prm.layer[0].Kpad;
     const int o_d = prm.use_nabla ? 3 : 0;             // start of embed_d
     const int o_v = o_d + prm.d_emb;                   // start of embed_view
@@ -393,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void nm_col_mlp_kernel(NmColParams prm, con
         }
         for (int b = j; b < prm.multires_d; b += 8) {
             float s, co;
-            sincosf(dsv * (float)(1 << b), &s, &co);
+            nm_sincos(dsv * (float)(1 << b), &s, &co);
             row[o_d + 1 + 2 * b] = s;
             row[o_d + 2 + 2 * b] = co;
         }
@@ -407,32 +429,23 @@ __global__ __launch_bounds__(256, 2) void nm_col_mlp_kernel(NmColParams prm, con
             for (int e = j; e < 3 * prm.multires_view; e += 8) {
                 const int dim = e % 3, b = e / 3;
                 float s, co;
-                sincosf(dv[dim] * (float)(1 << b), &s, &co);
+                nm_sincos(dv[dim] * (float)(1 << b), &s, &co);
                 row[o_v + 3 + 6 * b + dim] = s;
                 row[o_v + 6 + 6 * b + dim] = co;
             }
         }
-        int idx8[8];
-        float w8[8];
-        {
-            const int4 i0 = *reinterpret_cast<const int4*>(idx + q * 8), i1 = *reinterpret_cast<const int4*>(idx + q * 8 + 4);
-            const float4 w0 = *reinterpret_cast<const float4*>(w + q * 8), w1 = *reinterpret_cast<const float4*>(w + q * 8 + 4);
-            idx8[0] = i0.x; idx8[1] = i0.y; idx8[2] = i0.z; idx8[3] = i0.w;
-            idx8[4] = i1.x; idx8[5] = i1.y; idx8[6] = i1.z; idx8[7] = i1.w;
-            w8[0] = w0.x; w8[1] = w0.y; w8[2] = w0.z; w8[3] = w0.w;
-            w8[4] = w1.x; w8[5] = w1.y; w8[6] = w1.z; w8[7] = w1.w;
-        }
         for (int chunk = j; chunk < (prm.cdim >> 2); chunk += 8) {
-            const float4 ft = nm_interp4(table, prm.cdim, idx8, w8, chunk);
+            const float4 ft = *reinterpret_cast<const float4*>(ft_rec + q * prm.cdim + 4 * chunk);
             nm_embed4(row + o_f, prm.cdim, prm.multires_ft, chunk, ft);
         }
     }
     __syncthreads();
+    nm_phase_stamp(1);
 
     for (int l = 0; l < prm.D; ++l) {
         const NmLayer L = prm.layer[l];
         if (VALU_CHECK) nm_mlp_layer_valu<1, false>(act, valu_tmp + (size_t)blockIdx.x * NM_ROWS * NM_W, L.W, L.b, L.Kpad);
-        else nm_mlp_layer<1, false>(act, L.W, L.b, L.Kpad, L.Kpad);
+        else nm_mlp_layer<1, false>(act, L.W, L.b, L.Kpad, L.Kpad, 2 + 2 * l);
     }
 
     {
@@ -463,4 +476,5 @@ __global__ __launch_bounds__(256, 2) void nm_col_mlp_kernel(NmColParams prm, con
             rgb_out[q * 3 + c] = __fdiv_rn(1.0f, 1.0f + expf(-z));
         }
     }
+    nm_phase_stamp(15);
 }

@@ -224,3 +224,36 @@ def test_upsample_slot_tracking_and_bounds():
         radius[:, n:n + 16] = rad_new
         sdf[:, n:n + 16] = orc.forward_density_only(pts)[..., 0]
         n += 16; pending = 16
+
+
+def test_fast_sincos_formula():
+    """numpy emulation of nm_sincos (neumesh_amd/csrc/nm_mlp.h): 3-term Cody-Waite reduction by pi/2
+    + minimax polynomials; same error class as libm's fp32 sin/cos over the encodings' range."""
+    f32 = np.float32
+
+    def fma(a, b, c):
+        return (np.asarray(a, np.float64) * np.float64(b) + np.asarray(c, np.float64)).astype(np.float32)
+
+    def sincos(x):
+        k = np.rint((x * f32(0.63661977236758134)).astype(np.float32)).astype(np.float32)
+        r = fma(k, f32(-1.57079637050628662109e+00), x)
+        r = fma(k, f32(4.37113882867379288655e-08), r)
+        r = fma(k, f32(1.71512451000588187280e-15), r)
+        q = k.astype(np.int64)
+        r2 = (r * r).astype(np.float32)
+        ps = fma(r2, f32(-1.9515295891e-4), np.full_like(r2, f32(8.3321608736e-3)))
+        ps = fma(ps, r2, np.full_like(r2, f32(-1.6666654611e-1)))
+        s = fma((ps * r2).astype(np.float32), r, r)
+        pc = fma(r2, f32(2.443315711809948e-5), np.full_like(r2, f32(-1.388731625493765e-3)))
+        pc = fma(pc, r2, np.full_like(r2, f32(4.166664568298827e-2)))
+        c = fma((pc * r2).astype(np.float32), r2, fma(r2, f32(-0.5), np.ones_like(r2)))
+        swap = (q & 1) == 1
+        ss, cc = np.where(swap, c, s), np.where(swap, s, c)
+        return np.where((q & 2) == 2, -ss, ss).astype(np.float32), np.where(((q + 1) & 2) == 2, -cc, cc).astype(np.float32)
+
+    rng = np.random.default_rng(0)
+    for hi in (8.0, 1300.0, 1.0e5):
+        x = rng.uniform(-hi, hi, 500000).astype(np.float32)
+        s, c = sincos(x)
+        assert np.abs(s - np.sin(x.astype(np.float64))).max() < 1.5e-7
+        assert np.abs(c - np.cos(x.astype(np.float64))).max() < 1.5e-7
