@@ -69,7 +69,7 @@ def frame_rays(frame, H, W):
     return synthetic.camera_rays(synthetic.orbit_pose(frame), synthetic.pinhole_intrinsics(H, W), H, W)
 
 
-def cpu_baseline(mesh, model, H, W, n_rays, gpu_rgb_frame0):
+def cpu_baseline(mesh, model, H, W, n_rays, gpu_rgb_frame0, rays0=None):
     """Oracle (CPU restatement of the reference) on a strided sample of frame 0's rays."""
     from oracle import compare, field as ofield, knn as oknn, render as orender
     state = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
@@ -77,7 +77,7 @@ def cpu_baseline(mesh, model, H, W, n_rays, gpu_rgb_frame0):
     from scipy.spatial import cKDTree
     tree = cKDTree(mesh.vertices.astype(np.float64))
     orc.knn_fn = lambda q, v, K: oknn.knn_kdtree(q, v, K, tree=tree)
-    o, d = frame_rays(0, H, W)
+    o, d = frame_rays(0, H, W) if rays0 is None else rays0   # the very rays the GPU rendered
     sel = np.linspace(0, H * W - 1, n_rays).astype(np.int64)
     cfg = orender.RenderConfig(calc_normal=True)
     orender.render_rays(orc, o[sel[:8]], d[sel[:8]], cfg)  # warm caches / thread pools
@@ -138,10 +138,11 @@ def main():
     cfg = make_render_cfg(calc_normal=True)
     n_rays = args.H * args.W
     total_steps = args.warmup + args.steps
+    from neumesh_amd import synthetic
+    from neumesh_amd.rays import make_rays
     rays = []
-    for s in range(total_steps):  # every rank renders its own frame of the orbit: inputs resident before timing
-        o, d = frame_rays(s * world + rank, args.H, args.W)
-        rays.append((torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)))
+    for s in range(total_steps):  # every rank builds the rays of ITS frame of the orbit on ITS GPU (nm_make_rays): resident before timing
+        rays.append(make_rays(synthetic.orbit_pose(s * world + rank), synthetic.pinhole_intrinsics(args.H, args.W), args.H, args.W, dev))
     tables = model.field_tables()
     model.field_handle()
     gathered = torch.empty((world * n_rays, 8), dtype=torch.float32, device=dev) if world > 1 else None
@@ -226,7 +227,8 @@ def main():
         }
         if world == 1 and args.cpu_rays > 0:
             try:
-                base, parity = cpu_baseline(mesh, model, args.H, args.W, args.cpu_rays, rgb0)
+                rays0 = (rays[0][0].cpu().numpy(), rays[0][1].cpu().numpy())
+                base, parity = cpu_baseline(mesh, model, args.H, args.W, args.cpu_rays, rgb0, rays0)
                 out["cpu_baseline"] = base
                 if parity:
                     out["parity_vs_oracle"] = parity

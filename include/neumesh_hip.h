@@ -165,6 +165,49 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
                    float* depth, float* acc, float* normals, const nm_render_debug* dbg,
                    void* workspace, nm_stream_t stream);
 
+/* ------------------------------------------------------------------ per-ray stages, one by one
+ * The stages nm_render_rays chains internally, exposed separately so that a caller whose FIELD is
+ * not a plain NeuMesh (the editing tools wrap it: editing/texture_neumesh/texture_neumesh.py:41-122)
+ * can run the reference's render_rayschunk (models/renderer.py:162-350) with its own model methods
+ * between them.  All arrays are device, fp32, ray-major; `cap` = row length of d / sdf / d_mid.
+ *   nm_rays_setup     renderer.py:153 + rend_util.py:179-199 -> dirn [R,3], near_far [R,2]
+ *   nm_rays_points    depth mode 2: near*(1-t)+far*t, t = linspace(0,1,P) (also stored to
+ *                     depth_out[r*cap + off + p] if non-NULL); mode 1: depth[r*cap + off + p];
+ *                     -> xyz [R,P,3] = o + d * dirn
+ *   nm_rays_bounds    renderer.py:88-102 from the probes' projected distances ds [R,G]
+ *   nm_rays_upsample  merge the m samples appended last time, then draw n_new new depths into
+ *                     d[:, n:n+n_new] (renderer.py:209-245,255-258; rend_util.py:276-319)
+ *   nm_rays_finalize  last merge + mid-point depths d_mid[:, :n-1] (renderer.py:266)
+ *   nm_rays_composite renderer.py:278,302-333 */
+int nm_rays_setup(const float* rays_o, const float* rays_d, int64_t R, float radius, float* dirn,
+                  float* near_far, nm_stream_t stream);
+int nm_rays_points(const float* rays_o, const float* dirn, int64_t R, int P, int mode,
+                   const float* near_far, const float* depth, int cap, int off, float* depth_out,
+                   float* xyz, nm_stream_t stream);
+int nm_rays_bounds(const float* ds_probe, int64_t R, int G, float thresh, const float* near_far_in,
+                   float* near_far_out, nm_stream_t stream);
+int nm_rays_upsample(float* d, float* sdf, int64_t R, int cap, int n, int m, int it, int n_new,
+                     nm_stream_t stream);
+int nm_rays_finalize(float* d, float* sdf, int64_t R, int cap, int n, int m, float* d_mid,
+                     nm_stream_t stream);
+int nm_rays_composite(const float* sdf, const float* d, int64_t R, int cap, int N, float s,
+                      const float* rgb_mid, const float* nablas, int white_bkgd, float* rgb,
+                      float* depth, float* acc, float* normals, nm_stream_t stream);
+
+/* ----------------------------------------------------------------------------- ray set-up
+ * rend_util.get_rays (utils/rend_util.py:123-176, pose-matrix branch, N_rays=-1) for the pixels
+ * [first_pixel, first_pixel+count) of an H x W image in row-major order: pixel (x = p % W,
+ * y = p / W) is lifted to z = 1 with the pin-hole intrinsics (utils/rend_util.py:95-118),
+ * normalised and rotated by c2w[:3,:3]; the origin is c2w[:3,3].  Each rank of a ray-sharded render
+ * generates its own pixel block on the device: no host->device ray traffic. */
+typedef struct nm_camera {
+    float c2w[12];            /* rows 0..2 of the camera-to-world matrix, row-major [3][4] */
+    float fx, fy, cx, cy, sk; /* intrinsics[0,0], [1,1], [0,2], [1,2], [0,1] */
+    int32_t H, W;
+} nm_camera;
+int nm_make_rays(const nm_camera* cam, int64_t first_pixel, int64_t count, float* rays_o,
+                 float* rays_d, nm_stream_t stream);
+
 /* -------------------------------------------------------------------------- instrumentation
  * Launches `iters` back-to-back passes of one internal kernel on `stream`, bracketed by HIP
  * events recorded on that same stream; returns the average duration in milliseconds.

@@ -22,6 +22,6 @@ def __getattr__(name):  # lazy: torch is imported only when the model classes ar
     }
     if name in table:
         return getattr(importlib.import_module(f".{table[name]}", __name__), name)
-    if name in ("frnn", "mesh_grid", "neumesh", "renderer", "framework", "ply", "sharded", "build", "_lib"):
+    if name in ("frnn", "mesh_grid", "neumesh", "renderer", "framework", "ply", "sharded", "rays", "build", "_lib"):
         return importlib.import_module(f".{name}", __name__)
     raise AttributeError(name)

@@ -43,6 +43,11 @@ class RenderCfg(C.Structure):
                 ("near_bypass", C.c_float), ("far_bypass", C.c_float)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("c2w", C.c_float * 12), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("sk", C.c_float), ("H", C.c_int32), ("W", C.c_int32)]
+
+
 class RenderDebug(C.Structure):
     _fields_ = [("near_far", C.c_void_p), ("d_all", C.c_void_p), ("sdf_all", C.c_void_p),
                 ("nablas_all", C.c_void_p), ("radiance", C.c_void_p), ("sdf_coarse", C.c_void_p)]
@@ -69,6 +74,13 @@ SIGNATURES = {
     "nm_render_workspace_bytes": (C.c_int64, [C.POINTER(RenderCfg), C.c_int64]),
     "nm_render_rays": (C.c_int, [_P, _P, C.POINTER(FieldTables), _P, _P, C.c_int64, C.POINTER(RenderCfg),
                                  _P, _P, _P, _P, C.POINTER(RenderDebug), _P, _P]),
+    "nm_rays_setup": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P, _P, _P]),
+    "nm_rays_points": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P]),
+    "nm_rays_bounds": (C.c_int, [_P, C.c_int64, C.c_int, C.c_float, _P, _P, _P]),
+    "nm_rays_upsample": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "nm_rays_finalize": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "nm_rays_composite": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
+    "nm_make_rays": (C.c_int, [C.POINTER(Camera), C.c_int64, C.c_int64, _P, _P, _P]),
     "nm_profile_enable": (C.c_int, [C.c_int]),
     "nm_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "nm_time_kernel": (C.c_int, [_P, _P, C.POINTER(FieldTables), C.c_int, _P, _P, C.c_int64, _P, C.c_int,

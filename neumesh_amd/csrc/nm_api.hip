@@ -600,6 +600,86 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     return 0;
 }
 
+// ==================================================================== per-ray stages (staged API)
+int nm_rays_setup(const float* rays_o, const float* rays_d, int64_t R, float radius, float* dirn, float* near_far, nm_stream_t stream_) {
+    if (R < 0 || (R > 0 && (!rays_o || !rays_d || !dirn || !near_far))) return nm_fail("nm_rays_setup: bad arguments");
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(nm_rays_setup_kernel, dim3(nm_blocks(R, 64)), dim3(64), 0, (hipStream_t)stream_, rays_o, rays_d, (long long)R, radius, dirn, near_far);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_rays_points(const float* rays_o, const float* dirn, int64_t R, int P, int mode, const float* near_far, const float* depth,
+                   int cap, int off, float* depth_out, float* xyz, nm_stream_t stream_) {
+    if (R < 0 || P < 1 || (mode != 1 && mode != 2)) return nm_fail("nm_rays_points: bad arguments");
+    if (R == 0) return 0;
+    if (!rays_o || !dirn || !xyz || (mode == 2 && !near_far) || (mode == 1 && !depth)) return nm_fail("nm_rays_points: NULL argument");
+    NmPointSrc src;
+    memset(&src, 0, sizeof(src));
+    src.mode = mode;
+    src.P = P;
+    src.rays_o = rays_o;
+    src.dirn = dirn;
+    src.depth = depth;
+    src.nearfar = near_far;
+    src.depth_out = depth_out;
+    src.dstride = cap;
+    src.doff = off;
+    hipLaunchKernelGGL(nm_rays_points_kernel, dim3(nm_blocks(R * P, 256)), dim3(256), 0, (hipStream_t)stream_, src, (long long)R * P, xyz);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_rays_bounds(const float* ds_probe, int64_t R, int G, float thresh, const float* near_far_in, float* near_far_out, nm_stream_t stream_) {
+    if (R < 0 || G < 2 || (R > 0 && (!ds_probe || !near_far_in || !near_far_out))) return nm_fail("nm_rays_bounds: bad arguments");
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(nm_rays_bounds_kernel, dim3(nm_blocks(R, 64)), dim3(64), 0, (hipStream_t)stream_, ds_probe, (long long)R, G, thresh, near_far_in, near_far_out);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_rays_upsample(float* d, float* sdf, int64_t R, int cap, int n, int m, int it, int n_new, nm_stream_t stream_) {
+    if (R < 0 || n < 2 || m < 0 || m > n || n + n_new > cap || cap > NM_MAX_SAMPLES || it < 0 || it > 20 || (R > 0 && (!d || !sdf))) return nm_fail("nm_rays_upsample: bad arguments");
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(nm_rays_upsample_kernel, dim3(nm_blocks(R, 64)), dim3(64), 0, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (float*)nullptr, (long long)R, cap, n, m, it, n_new);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_rays_finalize(float* d, float* sdf, int64_t R, int cap, int n, int m, float* d_mid, nm_stream_t stream_) {
+    if (R < 0 || n < 2 || n > cap || m < 0 || m > n || (R > 0 && (!d || !sdf || !d_mid))) return nm_fail("nm_rays_finalize: bad arguments");
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(nm_rays_finalize_kernel, dim3(nm_blocks(R, 64)), dim3(64), 0, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (long long)R, cap, n, m, d_mid, (float*)nullptr);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_rays_composite(const float* sdf, const float* d, int64_t R, int cap, int N, float s, const float* rgb_mid, const float* nablas,
+                      int white_bkgd, float* rgb, float* depth, float* acc, float* normals, nm_stream_t stream_) {
+    if (R < 0 || N < 2 || N > cap || N > NM_MAX_SAMPLES || (R > 0 && (!sdf || !d || !rgb_mid || !rgb || !depth || !acc))) return nm_fail("nm_rays_composite: bad arguments");
+    if (R == 0) return 0;
+    hipLaunchKernelGGL(nm_rays_composite_kernel, dim3(nm_blocks(R, 64)), dim3(64), 0, (hipStream_t)stream_, sdf, d, (long long)R, cap, N, s, rgb_mid, nablas, white_bkgd, rgb, depth, acc, normals);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+// ============================================================================== ray set-up
+int nm_make_rays(const nm_camera* cam, int64_t first_pixel, int64_t count, float* rays_o, float* rays_d, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!cam) return nm_fail("nm_make_rays: cam is NULL");
+    if (cam->H < 1 || cam->W < 1 || first_pixel < 0 || count < 0 || first_pixel + count > (int64_t)cam->H * cam->W)
+        return nm_fail("nm_make_rays: pixel range [%lld,+%lld) outside %dx%d", (long long)first_pixel, (long long)count, cam->H, cam->W);
+    if (count == 0) return 0;
+    if (!rays_o || !rays_d) return nm_fail("nm_make_rays: NULL output");
+    NmCamera c;
+    for (int i = 0; i < 12; ++i) c.r[i] = cam->c2w[i];
+    c.fx = cam->fx; c.fy = cam->fy; c.cx = cam->cx; c.cy = cam->cy; c.sk = cam->sk;
+    c.H = cam->H; c.W = cam->W;
+    hipLaunchKernelGGL(nm_make_rays_kernel, dim3(nm_blocks(count, 256)), dim3(256), 0, stream, c, (long long)first_pixel, (long long)count, rays_o, rays_d);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
 // ======================================================================== instrumentation
 int nm_profile_enable(int on) {
     for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }

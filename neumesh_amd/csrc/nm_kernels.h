@@ -384,11 +384,12 @@ __global__ void nm_rays_upsample_kernel(float* __restrict__ d, float* __restrict
     if (r >= R) return;
     float* dr = d + r * cap;
     float* sr = sdf + r * cap;
-    int* sl = slot + r * cap;
+    int* sl = slot ? slot + r * cap : nullptr;
     if (m > 0) nm_ray_merge(dr, sr, n - m, m, sl);
-    else for (int j = 0; j < n; ++j) sl[j] = j;
+    else if (sl) for (int j = 0; j < n; ++j) sl[j] = j;
     float w[NM_MAX_SAMPLES], cdf[NM_MAX_SAMPLES];
-    nm_ray_upsample(dr, sr, n, it, n_new, dr + n, w, cdf, sl, radius + r * cap, bound + r * cap + n);
+    nm_ray_upsample(dr, sr, n, it, n_new, dr + n, w, cdf, sl, (sl && radius) ? radius + r * cap : nullptr,
+                    bound ? bound + r * cap + n : nullptr);
 }
 
 // final merge + mid-point depths (renderer.py:255-258, :266) + warm-start bounds of the mid-points
@@ -398,15 +399,27 @@ __global__ void nm_rays_finalize_kernel(float* __restrict__ d, float* __restrict
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     float* dr = d + r * cap;
-    int* sl = slot + r * cap;
+    int* sl = slot ? slot + r * cap : nullptr;
     if (m > 0) nm_ray_merge(dr, sdf + r * cap, n - m, m, sl);
-    else for (int j = 0; j < n; ++j) sl[j] = j;
-    const float* rad = radius + r * cap;
+    else if (sl) for (int j = 0; j < n; ++j) sl[j] = j;
+    const float* rad = (sl && radius) ? radius + r * cap : nullptr;
     for (int j = 0; j + 1 < n; ++j) {
         const float dm = nm_mul(0.5f, nm_add(dr[j + 1], dr[j]));
         d_mid[r * cap + j] = dm;
-        bound_mid[r * cap + j] = fminf(rad[sl[j]] + fabsf(dm - dr[j]), rad[sl[j + 1]] + fabsf(dr[j + 1] - dm));
+        if (rad && bound_mid) bound_mid[r * cap + j] = fminf(rad[sl[j]] + fabsf(dm - dr[j]), rad[sl[j + 1]] + fabsf(dr[j + 1] - dm));
     }
+}
+
+// sample points of a ray batch as an explicit [R,P,3] array (staged renderer: the field is queried
+// through the model's Python methods between the per-ray stages)
+__global__ void nm_rays_points_kernel(NmPointSrc src, long long Q, float* __restrict__ xyz) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    float x, y, z;
+    nm_fetch_point(src, q, x, y, z);
+    xyz[3 * q] = x;
+    xyz[3 * q + 1] = y;
+    xyz[3 * q + 2] = z;
 }
 
 __global__ void nm_rays_composite_kernel(const float* __restrict__ sdf, const float* __restrict__ d, long long R,
@@ -420,6 +433,30 @@ __global__ void nm_rays_composite_kernel(const float* __restrict__ sdf, const fl
     nm_ray_composite(sdf + r * cap, d + r * cap, N, s, rgb_mid + r * (long long)(N - 1) * 3,
                      nablas ? nablas + r * (long long)N * 3 : nullptr, white_bkgd, rgb + 3 * r, depth + r, acc + r,
                      normals ? normals + 3 * r : nullptr, w);
+}
+
+// rend_util.get_rays for a contiguous pixel range (utils/rend_util.py:95-118,123-176)
+struct NmCamera {
+    float r[12];
+    float fx, fy, cx, cy, sk;
+    int H, W;
+};
+__global__ void nm_make_rays_kernel(NmCamera cam, long long first, long long count, float* __restrict__ rays_o,
+                                    float* __restrict__ rays_d) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const long long p = first + i;
+    const float y = (float)(p / cam.W), x = (float)(p - (p / cam.W) * cam.W);
+    // x_lift = (x - cx + cy*sk/fy - sk*y/fy) / fx * z,  y_lift = (y - cy) / fy * z,  z = 1
+    const float xl = nm_div(nm_sub(nm_add(nm_sub(x, cam.cx), nm_div(nm_mul(cam.cy, cam.sk), cam.fy)), nm_div(nm_mul(cam.sk, y), cam.fy)), cam.fx);
+    const float yl = nm_div(nm_sub(y, cam.cy), cam.fy);
+    const float n = nm_sqrt(nm_add(nm_add(nm_mul(xl, xl), nm_mul(yl, yl)), 1.0f));
+    const float dx = nm_div(xl, n), dy = nm_div(yl, n), dz = nm_div(1.0f, n);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        rays_d[3 * i + a] = nm_add(nm_add(nm_mul(cam.r[4 * a], dx), nm_mul(cam.r[4 * a + 1], dy)), nm_mul(cam.r[4 * a + 2], dz));
+        rays_o[3 * i + a] = cam.r[4 * a + 3];
+    }
 }
 
 // ------------------------------------------------------------------------------- utilities

@@ -130,6 +130,103 @@ def render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg: _lib.RenderCfg, raysc
     return out
 
 
+def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int, netchunk: int, detailed: bool = False,
+                       progress=None):
+    """render_rayschunk (models/renderer.py:162-350) for ANY object that offers the field methods the
+    reference's renderer calls -- compute_distance / forward_density_only / forward_with_nablas /
+    forward / forward_s -- e.g. the editing tools' TextureEditableNeuMesh wrapper
+    (editing/texture_neumesh/texture_neumesh.py:41-122).  Every per-ray stage runs as the same HIP
+    kernel the fused path uses (C ABI nm_rays_*); between the stages the field is queried through the
+    model's own methods, in chunks of `netchunk` points like train_util.batchify_query."""
+    lib = _lib.load()
+    dev = rays_o.device
+    rays_o = rays_o.detach().float().reshape(-1, 3).contiguous()
+    rays_d = rays_d.detach().float().reshape(-1, 3).contiguous()
+    Rall = rays_o.shape[0]
+    Ns, Ni, iters = cfg.N_samples, cfg.N_importance, cfg.N_upsample_iters
+    N = Ns + Ni
+
+    def query(fn, pts, *extra):  # pts [R,P,3] -> tuple of [R,P,...]
+        flat = pts.reshape(-1, 3)
+        ex = [e.reshape(-1, e.shape[-1]) for e in extra]
+        outs = []
+        for i in range(0, flat.shape[0], max(1, int(netchunk))):
+            o = fn(flat[i:i + netchunk], *[e[i:i + netchunk] for e in ex])
+            outs.append(o if isinstance(o, tuple) else (o,))
+        cols = [torch.cat([o[k] for o in outs], 0) for k in range(len(outs[0]))]
+        return [c.reshape(pts.shape[0], pts.shape[1], *c.shape[1:]) for c in cols]
+
+    chunks = []
+    rng = range(0, Rall, max(1, int(rayschunk)))
+    with torch.cuda.device(dev):
+        st = _lib.current_stream(dev)
+        for i in (rng if progress is None else progress(rng)):
+            ro, rd = rays_o[i:i + rayschunk].contiguous(), rays_d[i:i + rayschunk].contiguous()
+            R = ro.shape[0]
+            f32 = dict(dtype=torch.float32, device=dev)
+            dirn, nf0 = torch.empty((R, 3), **f32), torch.empty((R, 2), **f32)
+            _lib.check(lib.nm_rays_setup(_lib.ptr(ro), _lib.ptr(rd), R, cfg.obj_bounding_radius, _lib.ptr(dirn), _lib.ptr(nf0), st), "nm_rays_setup")
+            nf = nf0
+            if cfg.bounded_near_far:
+                G = cfg.probe_grid
+                pts = torch.empty((R, G, 3), **f32)
+                _lib.check(lib.nm_rays_points(_lib.ptr(ro), _lib.ptr(dirn), R, G, 2, _lib.ptr(nf0), None, G, 0, None, _lib.ptr(pts), st), "nm_rays_points")
+                ds = model.compute_distance(pts)[0].reshape(R, G).float().contiguous()   # ONE call, like renderer.py:86
+                nf = torch.empty((R, 2), **f32)
+                _lib.check(lib.nm_rays_bounds(_lib.ptr(ds), R, G, cfg.probe_thresh, _lib.ptr(nf0), _lib.ptr(nf), st), "nm_rays_bounds")
+            if cfg.near_bypass >= 0 or cfg.far_bypass >= 0:
+                nf = nf.clone()
+                if cfg.near_bypass >= 0:
+                    nf[:, 0] = cfg.near_bypass
+                if cfg.far_bypass >= 0:
+                    nf[:, 1] = cfg.far_bypass
+            d, sdf = torch.zeros((R, N), **f32), torch.zeros((R, N), **f32)
+            pts = torch.empty((R, Ns, 3), **f32)
+            _lib.check(lib.nm_rays_points(_lib.ptr(ro), _lib.ptr(dirn), R, Ns, 2, _lib.ptr(nf), None, N, 0, _lib.ptr(d), _lib.ptr(pts), st), "nm_rays_points")
+            sdf[:, :Ns] = query(model.forward_density_only, pts)[0].reshape(R, Ns)
+            n, pending = Ns, 0
+            if Ni > 0:
+                n_new = Ni // iters
+                for it in range(iters):
+                    _lib.check(lib.nm_rays_upsample(_lib.ptr(d), _lib.ptr(sdf), R, N, n, pending, it, n_new, st), "nm_rays_upsample")
+                    pts = torch.empty((R, n_new, 3), **f32)
+                    _lib.check(lib.nm_rays_points(_lib.ptr(ro), _lib.ptr(dirn), R, n_new, 1, None, _lib.ptr(d), N, n, None, _lib.ptr(pts), st), "nm_rays_points")
+                    sdf[:, n:n + n_new] = query(model.forward_density_only, pts)[0].reshape(R, n_new)
+                    n, pending = n + n_new, n_new
+            dmid = torch.zeros((R, N), **f32)
+            _lib.check(lib.nm_rays_finalize(_lib.ptr(d), _lib.ptr(sdf), R, N, n, pending, _lib.ptr(dmid), st), "nm_rays_finalize")
+            pts = torch.empty((R, N, 3), **f32)
+            _lib.check(lib.nm_rays_points(_lib.ptr(ro), _lib.ptr(dirn), R, N, 1, None, _lib.ptr(d), N, 0, None, _lib.ptr(pts), st), "nm_rays_points")
+            nablas = None
+            if cfg.calc_normal:
+                s_all, nablas = query(model.forward_with_nablas, pts)
+                nablas = nablas.float().contiguous()
+            else:
+                s_all = query(model.forward_density_only, pts)[0]
+            sdf = s_all.reshape(R, N).float().contiguous()
+            pm = torch.empty((R, N - 1, 3), **f32)
+            _lib.check(lib.nm_rays_points(_lib.ptr(ro), _lib.ptr(dirn), R, N - 1, 1, None, _lib.ptr(dmid), N, 0, None, _lib.ptr(pm), st), "nm_rays_points")
+            view = dirn[:, None, :].expand(R, N - 1, 3).contiguous()
+            _, radiance = query(lambda x, v: model.forward(x, v)[:2], pm, view)
+            radiance = radiance.float().contiguous()
+            rgb, depth, acc = torch.empty((R, 3), **f32), torch.empty((R,), **f32), torch.empty((R,), **f32)
+            normals = torch.empty((R, 3), **f32) if cfg.calc_normal else None
+            s_val = float(model.forward_s())
+            _lib.check(lib.nm_rays_composite(_lib.ptr(sdf), _lib.ptr(d), R, N, N, s_val, _lib.ptr(radiance), _lib.ptr(nablas), cfg.white_bkgd,
+                                             _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc), _lib.ptr(normals), st), "nm_rays_composite")
+            ret = OrderedDict(rgb=rgb, depth_volume=depth, mask_volume=acc)
+            if cfg.calc_normal:
+                ret["normals_volume"] = normals
+            if detailed:
+                cdf, alpha = sdf_to_alpha(sdf, s_val)
+                if cfg.calc_normal:
+                    ret["implicit_nablas"] = nablas
+                ret.update(implicit_surface=sdf, radiance=radiance, alpha=alpha, cdf=cdf, visibility_weights=alpha_to_w(alpha),
+                           d_final=0.5 * (d[:, 1:] + d[:, :-1]), d_all=d, near_far=nf)
+            chunks.append(ret)
+    return OrderedDict((k, torch.cat([c[k] for c in chunks], 0)) for k in chunks[0])
+
+
 def volume_render(rays_o, rays_d, model, obj_bounding_radius=1.0, batched=False, batched_info={},
                   calc_normal=False, use_view_dirs=True, rayschunk=65536, netchunk=1048576, white_bkgd=False,
                   near_bypass: Optional[float] = None, far_bypass: Optional[float] = None, detailed_output=True,
@@ -142,13 +239,13 @@ def volume_render(rays_o, rays_d, model, obj_bounding_radius=1.0, batched=False,
         lead = [B, -1]
     else:
         lead = [-1]
-    fused_ok = (isinstance(model, NeuMesh) and not torch.is_grad_enabled() and not perturb and not samples_output
-                and not random_color_direction and use_view_dirs)
-    if not fused_ok:
+    if torch.is_grad_enabled() or perturb or samples_output or random_color_direction or not use_view_dirs:
         raise NotImplementedError(
-            "neumesh_amd.volume_render: only the inference path the reference's render.py takes is implemented on the "
-            "HIP library (NeuMesh model, torch.no_grad(), perturb=False, no samples_output / random_color_direction). "
-            "Training / editing-wrapper renders are the next rows of SURVEY.md section 8(f).")
+            "neumesh_amd.volume_render implements the inference path of the reference's renderer (torch.no_grad(), "
+            "perturb=False, no samples_output / random_color_direction): what render.py and the editing renders call. "
+            "The training renderer (stratified sampling, autograd through the compositing) is the next row of "
+            "SURVEY.md section 8(f).")
+    fused = isinstance(model, NeuMesh)   # plain NeuMesh field: everything in one C call per chunk
     cfg = make_render_cfg(obj_bounding_radius, N_samples, N_importance, N_upsample_iters, bounded_near_far, calc_normal,
                           white_bkgd, near_bypass, far_bypass)
     progress = None
@@ -160,7 +257,10 @@ def volume_render(rays_o, rays_d, model, obj_bounding_radius=1.0, batched=False,
             progress = None
     flat_o = torch.reshape(rays_o, [-1, 3]).float()
     flat_d = torch.reshape(rays_d, [-1, 3]).float()
-    ret = render_rays_fused(model, flat_o, flat_d, cfg, rayschunk, detailed=detailed_output, progress=progress)
+    if fused:
+        ret = render_rays_fused(model, flat_o, flat_d, cfg, rayschunk, detailed=detailed_output, progress=progress)
+    else:   # wrapper model (editing tools): per-ray stages on HIP, field through the wrapper's methods
+        ret = render_rays_staged(model, flat_o, flat_d, cfg, rayschunk, netchunk, detailed=detailed_output, progress=progress)
     for k in list(ret.keys()):
         v = ret[k]
         ret[k] = v.reshape(*lead, *v.shape[1:]) if batched else v

@@ -64,3 +64,25 @@ def render_sharded(render_fn: Callable[[torch.Tensor, torch.Tensor], Dict[str, t
         a, b = shard_range(n, r, world)
         pieces.append(full[r * per: r * per + (b - a)])
     return unpack_outputs(torch.cat(pieces, dim=0), keys)
+
+
+def render_frame_sharded(render_fn, c2w, intrinsics, H: int, W: int, device, group=None) -> Dict[str, torch.Tensor]:
+    """One frame of an H x W camera: every rank builds ONLY its own pixel block's rays on its own GPU
+    (nm_make_rays, no host->device ray traffic), renders it and all-gathers the pixels."""
+    from .rays import make_rays
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = H * W
+    lo, hi = shard_range(n, rank, world)
+    ro, rd = make_rays(c2w, intrinsics, H, W, device, first_pixel=lo, count=hi - lo)
+    ret = render_fn(ro, rd)
+    if world == 1:
+        return ret
+    packed, keys = pack_outputs(ret)
+    per = -(-n // world)
+    buf = torch.zeros((per, packed.shape[1]), dtype=torch.float32, device=packed.device)
+    buf[: hi - lo] = packed
+    full = torch.empty((world * per, packed.shape[1]), dtype=torch.float32, device=packed.device)
+    dist.all_gather_into_tensor(full, buf, group=group)
+    pieces = [full[r * per: r * per + (shard_range(n, r, world)[1] - shard_range(n, r, world)[0])] for r in range(world)]
+    return unpack_outputs(torch.cat(pieces, dim=0), keys)

@@ -191,8 +191,28 @@ def gen_render_fixture(tag, V, H, W, frame, seed=0, white_bkgd=False, n_samples=
     return model
 
 
+def gen_rays_fixture():
+    """rend_util.get_rays of the reference (utils/rend_util.py:123-176) for a skewed pin-hole camera."""
+    import torch
+    harness._activate()
+    from utils import rend_util  # reference
+    H, W = 11, 17
+    c2w = synthetic.orbit_pose(7)
+    K = synthetic.pinhole_intrinsics(H, W, 0.9)
+    K[0, 1] = 0.37          # skew, so every term of lift() is exercised
+    K[1, 1] *= 1.1
+    ro, rd, sel = rend_util.get_rays(torch.from_numpy(c2w)[None], torch.from_numpy(K)[None], H, W, N_rays=-1)
+    o_o, o_d = orender.get_rays(c2w, K, H, W)
+    _check("rays.rays_d", o_d, rd[0].numpy(), 3e-7)
+    _check("rays.rays_o", o_o, ro[0].numpy(), 0.0)
+    assert np.array_equal(sel[0].numpy(), np.arange(H * W))
+    np.savez_compressed(os.path.join(GOLDEN, "rays_cam.npz"), c2w=c2w, intrinsics=K, H=np.int64(H), W=np.int64(W),
+                        rays_o=ro[0].numpy(), rays_d=rd[0].numpy())
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
+    gen_rays_fixture()
     model = gen_field_fixture("field_v3000", V=3000, Q=2048, seed=11)
     # one weights file shared by every fixture (reference ctor, torch.manual_seed(0))
     sd = {k: v.detach().numpy() for k, v in model.state_dict().items()

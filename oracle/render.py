@@ -5,6 +5,7 @@ Restates the reference's volumetric render inner loop:
 * cdf_Phi_s / sdf_to_alpha / alpha_to_w        models/renderer.py:13-24, :49-63
 * compute_bounded_near_far                     models/renderer.py:66-102
 * volume_render -> render_rayschunk            models/renderer.py:105-368 (:162-350)
+* get_rays / lift                              utils/rend_util.py:95-118, :123-176
 * near_far_from_sphere                         utils/rend_util.py:179-199
 * sample_pdf (det=True)                        utils/rend_util.py:276-319
 
@@ -39,6 +40,21 @@ def normalize(x: np.ndarray, eps: float = 1e-12) -> np.ndarray:
     """torch.nn.functional.normalize(x, dim=-1): x / max(||x||_2, eps)."""
     n = np.sqrt(np.sum(x * x, axis=-1, keepdims=True, dtype=F32))
     return (x / np.maximum(n, F32(eps))).astype(F32)
+
+
+def get_rays(c2w, intrinsics, H: int, W: int):
+    """utils/rend_util.py:123-176 (pose-matrix branch, N_rays=-1) with lift() :95-118, all pixels in
+    row-major order: x = column, y = row.  c2w [4,4], intrinsics [4,4] -> rays_o, rays_d [H*W,3]."""
+    c2w, k = np.asarray(c2w, F32), np.asarray(intrinsics, F32)
+    pix = np.arange(H * W)
+    x, y = (pix % W).astype(F32), (pix // W).astype(F32)
+    fx, fy, cx, cy, sk = k[0, 0], k[1, 1], k[0, 2], k[1, 2], k[0, 1]
+    x_lift = ((x - cx + cy * sk / fy - sk * y / fy) / fx).astype(F32)
+    y_lift = ((y - cy) / fy).astype(F32)
+    d = np.stack([x_lift, y_lift, np.ones_like(x_lift)], -1)
+    d = (d / np.sqrt(np.sum(d * d, axis=-1, keepdims=True, dtype=F32))).astype(F32)
+    d = np.stack([np.sum(c2w[a, :3] * d, axis=-1, dtype=F32) for a in range(3)], -1).astype(F32)
+    return np.broadcast_to(c2w[:3, 3], d.shape).copy(), d
 
 
 def near_far_from_sphere(rays_o, rays_d, r: float = 1.0):

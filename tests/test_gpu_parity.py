@@ -230,6 +230,19 @@ def test_autograd_path_matches_fused_path(small, cuda_device, torch_mod):
     np.testing.assert_allclose(nab_a.detach().cpu().numpy()[near], nab_f.cpu().numpy()[near], atol=1e-5)
 
 
+# ------------------------------------------------------------------------------ ray set-up
+def test_get_rays_kernel_matches_reference(cuda_device, torch_mod):
+    from neumesh_amd.rays import get_rays, make_rays
+    fx = common.golden("rays_cam")
+    H, W = int(fx["H"]), int(fx["W"])
+    ro, rd, sel = get_rays(_t(fx["c2w"], cuda_device)[None], _t(fx["intrinsics"], cuda_device)[None], H, W, N_rays=-1)
+    assert tuple(rd.shape) == (1, H * W, 3) and np.array_equal(sel[0].cpu().numpy(), np.arange(H * W))
+    np.testing.assert_allclose(rd[0].cpu().numpy(), fx["rays_d"], atol=3e-7)
+    assert np.array_equal(ro[0].cpu().numpy(), fx["rays_o"])
+    o2, d2 = make_rays(fx["c2w"], fx["intrinsics"], H, W, cuda_device, first_pixel=23, count=100)   # a rank's pixel block
+    assert torch_mod.equal(d2, rd[0, 23:123]) and torch_mod.equal(o2, ro[0, 23:123])
+
+
 # ----------------------------------------------------------------------------- renderer
 @pytest.mark.parametrize("tag", ["render_v3000_dtu", "render_v3000_lego"])
 def test_render_matches_reference_fixture(small, cuda_device, torch_mod, tag):
@@ -261,6 +274,53 @@ def test_render_matches_reference_fixture(small, cuda_device, torch_mod, tag):
     assert compare.psnr(e["rgb"], rf["rgb"]) > 100.0
     worst, unmatched = compare.depth_set_distance(e["d_all"], rf["d_all"])
     assert unmatched < 0.10 and worst < 5e-3                              # oracle/compare.py explains these two
+
+
+def test_wrapper_model_renders_through_staged_path(small, cuda_device, torch_mod):
+    """A model that only EXPOSES the five field methods (like the editing tools' wrapper,
+    editing/texture_neumesh/texture_neumesh.py:41-51) goes through the staged renderer (per-ray HIP
+    stages + the wrapper's methods) and must produce the fused renderer's pixels bit for bit; a wrapper
+    that edits the colour (texture swap) must change only the radiance."""
+    torch = torch_mod
+    from neumesh_amd.renderer import volume_render
+    _, _, model = small
+
+    class Wrapper:
+        def __init__(self, main, tint=None):
+            self.main, self.tint, self.calls = main, tint, []
+
+        def compute_distance(self, xyz):
+            self.calls.append(("compute_distance", tuple(xyz.shape)))
+            return self.main.compute_distance(xyz)
+
+        def forward_density_only(self, xyz):
+            return self.main.forward_density_only(xyz)
+
+        def forward_with_nablas(self, xyz):
+            return self.main.forward_with_nablas(xyz)
+
+        def forward_s(self):
+            return self.main.forward_s()
+
+        def forward(self, xyz, view_dirs):
+            sdf, nabla, ds, idx, w = self.main.forward(xyz, view_dirs, nablas_only=True, return_ds=True)
+            feats = self.main.color_features if self.tint is None else self.main.color_features * self.tint
+            return sdf, self.main.forward_color(ds, view_dirs, feats, indices=idx, weights=w, nabla=nabla)
+
+    rf = common.golden("render_v3000_dtu")
+    ro, rd = _t(rf["rays_o"], cuda_device), _t(rf["rays_d"], cuda_device)
+    kw = dict(calc_normal=True, perturb=False, N_samples=64, N_importance=64, rayschunk=40, detailed_output=True)
+    with torch.no_grad():
+        rgb_f, depth_f, ex_f = volume_render(ro, rd, model, **kw)
+        wrap = Wrapper(model)
+        rgb_w, depth_w, ex_w = volume_render(ro, rd, wrap, **{**kw, "netchunk": 1000})
+        rgb_t, _, ex_t = volume_render(ro, rd, Wrapper(model, tint=0.5), **kw)
+    assert ("compute_distance", (40, 256, 3)) in wrap.calls            # one probe call per ray chunk (renderer.py:86)
+    for k in ("rgb", "depth_volume", "mask_volume", "normals_volume", "d_all", "implicit_surface", "radiance", "implicit_nablas"):
+        assert torch.equal(ex_f[k], ex_w[k]), k
+    np.testing.assert_allclose(rgb_w.cpu().numpy(), rf["rgb"], atol=1e-4)
+    assert torch.equal(ex_t["implicit_surface"], ex_f["implicit_surface"]) and torch.equal(ex_t["d_all"], ex_f["d_all"])
+    assert float((rgb_t - rgb_f).abs().max()) > 1e-3                    # the colour edit is visible
 
 
 def test_render_frame_properties_dtu_scale(dtu_scale, cuda_device, torch_mod):

@@ -116,3 +116,21 @@ def test_sharded_render_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("OK" in o for o in outs), outs
+
+
+def test_get_rays_matches_reference_fixture_cpu():
+    """oracle restatement and the package's torch-op branch of get_rays vs the reference's output."""
+    torch = pytest.importorskip("torch")
+    from neumesh_amd.rays import get_rays
+    from oracle import render as orender
+    fx = common.golden("rays_cam")
+    H, W = int(fx["H"]), int(fx["W"])
+    o, d = orender.get_rays(fx["c2w"], fx["intrinsics"], H, W)
+    assert np.array_equal(o, fx["rays_o"]) and np.abs(d - fx["rays_d"]).max() <= 3e-7
+    ro, rd, sel = get_rays(torch.from_numpy(fx["c2w"])[None], torch.from_numpy(fx["intrinsics"])[None], H, W, N_rays=-1)
+    assert tuple(ro.shape) == (1, H * W, 3) and tuple(sel.shape) == (1, H * W)
+    np.testing.assert_allclose(rd[0].numpy(), fx["rays_d"], atol=3e-7)
+    np.testing.assert_allclose(ro[0].numpy(), fx["rays_o"], atol=0)
+    ro2, rd2, sel2 = get_rays(torch.from_numpy(fx["c2w"])[None], torch.from_numpy(fx["intrinsics"])[None], H, W, N_rays=50)
+    assert tuple(rd2.shape) == (1, 50, 3)
+    np.testing.assert_allclose(rd2[0].numpy(), fx["rays_d"][sel2[0].numpy()], atol=3e-7)
