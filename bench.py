@@ -35,6 +35,7 @@ FLOP_GEO = 353_280          # geometry MLP forward, per point (BASELINE.md secti
 FLOP_TANGENT = 271_360      # + forward-mode tangent (nabla)
 FLOP_COL = 500_736          # colour MLP
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 PEAK_HBM_GBS = 8000.0
 KNN_BYTES_PER_QUERY = 76    # 12 in + 8*4 idx + 8*4 w  
 
@@ -113,6 +114,8 @@ def main():
     ap.add_argument("--W", type=int, default=800)
     ap.add_argument("--V", type=int, default=140_000)
     ap.add_argument("--rayschunk", type=int, default=65536)
+    ap.add_argument("--mlp-precision", choices=["f16x2", "fp32"], default="f16x2",
+                    help="MLP arithmetic: split-half f16 MFMA (default; 22-bit operands, fp32 accumulation) or fp32 MFMA")
     ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU-baseline sample (0 disables)")
     args = ap.parse_args()
 
@@ -135,6 +138,7 @@ def main():
     lib = _lib.load()
 
     mesh, model = build_scene(args.V, dev)
+    model.mlp_precision = args.mlp_precision
     cfg = make_render_cfg(calc_normal=True)
     n_rays = args.H * args.W
     total_steps = args.warmup + args.steps
@@ -198,6 +202,7 @@ def main():
                 traffic = None
         rays_total = world * n_rays * args.steps
         value = rays_total / elapsed
+        split = args.mlp_precision == "f16x2"
         dom = max(("geo_mlp", "geo_mlp_tangent", "color_mlp"), key=lambda k: prof[k]["ms"])
         p = prof[dom]
         achieved = p["points"] * p["flop_per_point"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
@@ -208,15 +213,21 @@ def main():
             "metric": "rays/sec at 800x800x128 samples (DTU scan63 shape, synthetic scene S-DTU)",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_frame": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16x2-split (22-bit operands, fp32 accumulate; K-NN and per-ray stages fp32)" if split else "f32", "data": "synthetic",
             "config": {"workload": f"S-DTU V={args.V} {args.H}x{args.W} rays/frame/GPU, 64+64 samples, bounded_near_far (256 probes), "
                                    f"calc_normal, 639 K-NN queries + 383 geometry-MLP + 127 colour-MLP evals per ray",
                        "rayschunk": args.rayschunk, "parallelism": f"rays sharded: {world} GPU(s) x 1 frame per step, 1 all-gather of pixels"},
-            "roofline": {"bound": "mfma", "kernel": {"geo_mlp": "nm_geo_mlp_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_kernel<true>",
-                                                     "color_mlp": "nm_col_mlp_kernel"}[dom],
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": (traffic or {}).get({"geo_mlp": "nm_geo_mlp_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_kernel<true>",
-                                                          "color_mlp": "nm_col_mlp_kernel"}[dom], {}).get("hbm_bytes_per_launch") if traffic else None,
+            "roofline": {"bound": "mfma", "kernel": ({"geo_mlp": "nm_geo_mlp_h_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_h_kernel<true>",
+                                                      "color_mlp": "nm_col_mlp_h_kernel"} if split else
+                                                     {"geo_mlp": "nm_geo_mlp_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_kernel<true>",
+                                                      "color_mlp": "nm_col_mlp_kernel"})[dom],
+                         # split-half mode executes 3 f16 MFMA products per algorithmic fp32 product
+                         "achieved": achieved * (3.0 if split else 1.0), "peak": PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved * (3.0 if split else 1.0) / (PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS),
+                         "algorithmic_tflops": achieved, "algorithmic_vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "mfma_dtype": "f16 (x3 products per fp32 product, fp32 accumulate)" if split else "f32",
+                         "traffic": (traffic or {}).get({"geo_mlp": "geo_mlp", "geo_mlp_tangent": "geo_mlp_tangent", "color_mlp": "color_mlp"}[dom], {}).get("hbm_bytes_per_launch") if traffic else None,
                          "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" if traffic else None,
                          "avg_launch_ms": p["ms"] / max(p["launches"], 1), "launches": p["launches"],
                          "all_mlp_kernels_tflops": mlp_flop / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 1
+#define NM_ABI_VERSION 2
 #define NM_MAX_K 32
 
 typedef struct nm_grid_s* nm_grid_t;    /* spatial index over the mesh vertices */
@@ -93,6 +93,9 @@ typedef struct nm_field_desc {
     int32_t multires_d, multires_fg, multires_ft, multires_view; /* embedder bands, >= 0 */
     int32_t enable_nablas_input;
     int32_t use_view_dirs;     /* must be 1 */
+    int32_t mlp_precision;     /* 0: fp32 MFMA (reference numerics); 1: split-half f16 MFMA -- every
+                                  value carried as two fp16 halves (22 bits), 3 f16 MFMAs per product,
+                                  fp32 accumulation; |activations| must stay < 65504 */
     const float* geo_weight[8];   /* device; layer 0: [W, in_geo], others [W,W] */
     const float* geo_bias[8];     /* device [W] */
     const float* density_weight;  /* device [1,W] */

@@ -11,7 +11,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_K = 32
 
 
@@ -25,6 +25,7 @@ class FieldDesc(C.Structure):
                 ("geometry_dim", C.c_int32), ("color_dim", C.c_int32),
                 ("multires_d", C.c_int32), ("multires_fg", C.c_int32), ("multires_ft", C.c_int32),
                 ("multires_view", C.c_int32), ("enable_nablas_input", C.c_int32), ("use_view_dirs", C.c_int32),
+                ("mlp_precision", C.c_int32),
                 ("geo_weight", C.c_void_p * 8), ("geo_bias", C.c_void_p * 8),
                 ("density_weight", C.c_void_p), ("density_bias", C.c_void_p),
                 ("col_weight", C.c_void_p * 8), ("col_bias", C.c_void_p * 8),

@@ -15,6 +15,7 @@
 #include "nm_grid_build.h"
 #include "nm_kernels.h"
 #include "nm_mlp.h"
+#include "nm_mlp_f16.h"
 
 // ------------------------------------------------------------------------------ error state
 static thread_local std::string g_err;
@@ -84,6 +85,11 @@ struct nm_field_s {
     NmColParams col;
     float* blob = nullptr;  // packed weights
     size_t blob_floats = 0;
+    int precision = 0;       // 0 fp32, 1 split-half f16
+    NmGeoParamsH geo_h;
+    NmColParamsH col_h;
+    _Float16* blob_h = nullptr;  // split-half weights in fragment order
+    size_t blob_h_halves = 0;
 };
 
 extern "C" {
@@ -222,6 +228,7 @@ static int nm_field_validate(const nm_field_desc* d) {
     if (d->multires_d < 0 || d->multires_fg < 0 || d->multires_ft < 0 || d->multires_view < 0) return nm_fail("nm_field: negative multires (identity embedders) unsupported");
     if (d->multires_d > 16 || d->multires_view > 16) return nm_fail("nm_field: multires too large");
     if (!d->use_view_dirs) return nm_fail("nm_field: use_view_dirs=0 unsupported");
+    if (d->mlp_precision != 0 && d->mlp_precision != 1) return nm_fail("nm_field: mlp_precision=%d (0 = fp32, 1 = split-half f16)", d->mlp_precision);
     const int in_geo = 1 + 2 * d->multires_d + d->geometry_dim * (1 + 2 * d->multires_fg);
     const int in_col = (d->enable_nablas_input ? 3 : 0) + 1 + 2 * d->multires_d + 3 * (1 + 2 * d->multires_view) + d->color_dim * (1 + 2 * d->multires_ft);
     if (in_geo > 256 || in_col > 256) return nm_fail("nm_field: MLP input width %d/%d exceeds the 256-column LDS tile", in_geo, in_col);
@@ -289,6 +296,39 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
     f->col.d_emb = 1 + 2 * d->multires_d;
     f->col.in_dim = in_col;
     f->desc = *d;
+    f->precision = d->mlp_precision;
+    if (d->mlp_precision == 1) {
+        size_t need_h = 0;
+        for (int l = 0; l < d->D_density; ++l) need_h += (size_t)NM_W * nm_round16(l == 0 ? in_geo : NM_W) * 2;
+        for (int l = 0; l < d->D_color; ++l) need_h += (size_t)NM_W * nm_round16(l == 0 ? in_col : NM_W) * 2;
+        if (need_h > f->blob_h_halves) {
+            if (f->blob_h) hipFree(f->blob_h);
+            f->blob_h = nullptr;
+            NM_HIP(hipMalloc((void**)&f->blob_h, need_h * sizeof(_Float16)));
+            f->blob_h_halves = need_h;
+        }
+        _Float16* ph = f->blob_h;
+        memset(&f->geo_h, 0, sizeof(f->geo_h));
+        memset(&f->col_h, 0, sizeof(f->col_h));
+        auto pack_h = [&](const float* src, int in_dim, NmLayerH& L, const float* packed_bias) {
+            L.Kpad = nm_round16(in_dim);
+            L.W = ph;
+            L.b = packed_bias;
+            hipLaunchKernelGGL(nm_pack_weight_h_kernel, dim3(nm_blocks((long long)NM_W * L.Kpad, 256)), dim3(256), 0, stream, src, in_dim, L.Kpad, ph);
+            ph += (size_t)NM_W * L.Kpad * 2;
+        };
+        for (int l = 0; l < d->D_density; ++l) pack_h(d->geo_weight[l], l == 0 ? in_geo : NM_W, f->geo_h.layer[l], f->geo.layer[l].b);
+        for (int l = 0; l < d->D_color; ++l) pack_h(d->col_weight[l], l == 0 ? in_col : NM_W, f->col_h.layer[l], f->col.layer[l].b);
+        NM_LAUNCH_CHECK();
+        NM_HIP(hipStreamSynchronize(stream));
+        f->geo_h.D = f->geo.D; f->geo_h.wd = f->geo.wd; f->geo_h.bd = f->geo.bd;
+        f->geo_h.multires_d = f->geo.multires_d; f->geo_h.multires_fg = f->geo.multires_fg; f->geo_h.gdim = f->geo.gdim;
+        f->geo_h.d_emb = f->geo.d_emb; f->geo_h.in_dim = f->geo.in_dim;
+        f->col_h.D = f->col.D; f->col_h.wrgb = f->col.wrgb;
+        f->col_h.brgb[0] = f->col.brgb[0]; f->col_h.brgb[1] = f->col.brgb[1]; f->col_h.brgb[2] = f->col.brgb[2];
+        f->col_h.multires_d = f->col.multires_d; f->col_h.multires_ft = f->col.multires_ft; f->col_h.multires_view = f->col.multires_view;
+        f->col_h.cdim = f->col.cdim; f->col_h.use_nabla = f->col.use_nabla; f->col_h.d_emb = f->col.d_emb; f->col_h.in_dim = f->col.in_dim;
+    }
     return 0;
 }
 
@@ -314,6 +354,7 @@ int nm_field_update(nm_field_t f, const nm_field_desc* desc, nm_stream_t stream)
 int nm_field_destroy(nm_field_t f) {
     if (!f) return 0;
     if (f->blob) hipFree(f->blob);
+    if (f->blob_h) hipFree(f->blob_h);
     delete f;
     return 0;
 }
@@ -357,6 +398,12 @@ static int nm_launch_geo(nm_field_t f, const float* fg, const float* ds, const f
                          NmRecMap rmap = NM_COMPACT) {
     if (P <= 0) return 0;
     NmProfScope prof(nabla ? NM_K_GEO_NABLA : NM_K_GEO, P, stream);
+    if (f->precision == 1) {
+        if (nabla) hipLaunchKernelGGL((nm_geo_mlp_h_kernel<true>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out);
+        else hipLaunchKernelGGL((nm_geo_mlp_h_kernel<false>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out);
+        NM_LAUNCH_CHECK();
+        return 0;
+    }
     if (nabla) {
         hipLaunchKernelGGL((nm_geo_mlp_kernel<true, false>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo, fg, ds,
                            grad, rmap, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr);
@@ -372,6 +419,11 @@ static int nm_launch_col(nm_field_t f, const float* ft, const float* ds, const f
                          long long P, float* rgb, hipStream_t stream) {
     if (P <= 0) return 0;
     NmProfScope prof(NM_K_COLOR, P, stream);
+    if (f->precision == 1) {
+        hipLaunchKernelGGL(nm_col_mlp_h_kernel, dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->col_h, ft, ds, nabla, dirs, dir_div, P, rgb);
+        NM_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL((nm_col_mlp_kernel<false>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->col, ft, ds, nabla, dirs,
                        dir_div, P, rgb, (float*)nullptr);
     NM_LAUNCH_CHECK();

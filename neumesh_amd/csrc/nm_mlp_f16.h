@@ -1,0 +1,378 @@
+// nm_mlp_f16.h -- the same fused embed + MLP kernels as nm_mlp.h, on the f16 matrix pipe with
+// "split-half" operands (precision mode 1).
+//
+// Why: on gfx950 the fp32-input MFMA executes at the vector-FMA rate and does not overlap VALU work
+// (measured: one workgroup per CU 91-108 TFLOP/s, two 107-124; removing VALU work from a phase does
+// not shorten a workgroup's life), so ~125 of the 157 TFLOP/s are this path's ceiling.  The f16 MFMA
+// (v_mfma_f32_32x32x16_f16) has 16x the rate and its own pipe.
+//
+// How: every fp32 value a is carried as two halves  a = h1 + h2 * 2^-11,  h1 = rne16(a),
+// h2 = rne16((a - h1) * 2^11)  -- 22 significant bits, error <= 2^-22 |a| (fp32: 2^-24) -- and a
+// product as  a*b = h1a*h1b + 2^-11 (h1a*h2b + h2a*h1b)  (+ h2a*h2b*2^-22, dropped): 3 f16 MFMAs with
+// fp32 accumulation in two accumulators (main / 2^11-scaled), recombined in the epilogue.  The two
+// halves occupy exactly the 4 bytes of the fp32 value, so the LDS tile (64 rows x 256 columns) and
+// the packed weights keep their size; activations are split ONCE, by the epilogue that produces
+// them, so the K loop is pure operand loads + MFMA (12 MFMAs = 384 cycles per 16 k-values per wave,
+// against 2048 cycles for the fp32 form).
+//
+// Range: |values| must stay below 65504 (fp16); inputs below 2^-14 in magnitude go entirely into
+// the scaled half (no fp16 subnormals reach the matrix pipe).  The tangent rows (d h / d ds, seeded
+// with up to 2^7 * cos) are linear in their seed, so they are carried scaled by 2^-8 and the final
+// d sdf / d ds is multiplied back by 2^8 (exact), which keeps them far from the fp16 range limit.
+// An overflow shows up as a non-finite output.  nm_field_desc.mlp_precision selects
+// the mode; the fp32 kernels of nm_mlp.h remain the reference.
+#pragma once
+
+#include "nm_mlp.h"
+
+typedef _Float16 nm_h8 __attribute__((ext_vector_type(8)));
+
+#define NM_TANGENT_SCALE 0.00390625f  // 2^-8
+#define NM_H_STRIDE 264  // halves per tile row: 528 B = 33 16-byte slots -> conflict-free ds_read_b128
+#define NM_H_PLANE (NM_ROWS * NM_H_STRIDE)
+
+struct NmLayerH {
+    const _Float16* W;  // packed fragments: [col tile 8][k-step Kpad/16][plane 2][lane 64][8 halves]
+    const float* b;     // [256] fp32
+    int Kpad;
+};
+
+struct NmGeoParamsH {
+    NmLayerH layer[NM_MAX_LAYERS];
+    int D;
+    const float* wd;
+    float bd;
+    int multires_d, multires_fg, gdim;
+    int d_emb, in_dim;
+};
+
+struct NmColParamsH {
+    NmLayerH layer[NM_MAX_LAYERS];
+    int D;
+    const float* wrgb;
+    float brgb[3];
+    int multires_d, multires_ft, multires_view, cdim, use_nabla;
+    int d_emb, in_dim;
+};
+
+// a -> (h1, h2): a ~= h1 + h2 / 2048
+__device__ __forceinline__ void nm_split_half(float a, _Float16* h1, _Float16* h2) {
+    const _Float16 p = fabsf(a) < 6.2e-5f ? (_Float16)0.0f : (_Float16)a;
+    *h1 = p;
+    *h2 = (_Float16)((a - (float)p) * 2048.0f);
+}
+__device__ __forceinline__ void nm_store_split(_Float16* tile, int row, int col, float a) {
+    _Float16 h1, h2;
+    nm_split_half(a, &h1, &h2);
+    tile[row * NM_H_STRIDE + col] = h1;
+    tile[NM_H_PLANE + row * NM_H_STRIDE + col] = h2;
+}
+__device__ __forceinline__ float nm_load_split(const _Float16* tile, int row, int col) {
+    return fmaf((float)tile[NM_H_PLANE + row * NM_H_STRIDE + col], 1.0f / 2048.0f, (float)tile[row * NM_H_STRIDE + col]);
+}
+
+// weights: fp32 [256][in_dim] -> split halves in MFMA-fragment order (one 1 KiB block per
+// (column tile, k-step, plane): a wave's B operand load is 64 lanes x 16 contiguous bytes)
+__global__ void nm_pack_weight_h_kernel(const float* __restrict__ src, int in_dim, int Kpad, _Float16* __restrict__ dst) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (n, k)
+    if (e >= NM_W * Kpad) return;
+    const int n = e / Kpad, k = e - n * Kpad;
+    const float w = k < in_dim ? src[(size_t)n * in_dim + k] : 0.f;
+    _Float16 h1, h2;
+    nm_split_half(w, &h1, &h2);
+    const int ct = n >> 5, lane = (n & 31) | (((k >> 3) & 1) << 5), ks = k >> 4, el = k & 7;
+    const int KS = Kpad >> 4;
+    const size_t base = ((size_t)(ct * KS + ks) * 2) * 64 * 8;
+    dst[base + (size_t)lane * 8 + el] = h1;
+    dst[base + 64 * 8 + (size_t)lane * 8 + el] = h2;
+}
+
+// One dense layer on the split-half LDS tile (in place), see the header comment.
+template <int ACT, bool TANGENT>
+__device__ __forceinline__ void nm_mlp_layer_h(_Float16* tile, const _Float16* __restrict__ W, const float* __restrict__ bias,
+                                               int Kpad, int stamp_slot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int n0 = wave * 64;
+    const int KS = Kpad >> 4;
+    nm_f32x16 hi00 = {0}, hi01 = {0}, hi10 = {0}, hi11 = {0};
+    nm_f32x16 lo00 = {0}, lo01 = {0}, lo10 = {0}, lo11 = {0};
+    const _Float16* a0p = tile + li * NM_H_STRIDE + 8 * h;
+    const _Float16* a1p = tile + (32 + li) * NM_H_STRIDE + 8 * h;
+    const nm_h8* b0p = reinterpret_cast<const nm_h8*>(W) + (size_t)(wave * 2) * KS * 2 * 64 + lane;       // column tile 2*wave
+    const nm_h8* b1p = reinterpret_cast<const nm_h8*>(W) + (size_t)(wave * 2 + 1) * KS * 2 * 64 + lane;   // column tile 2*wave+1
+    nm_h8 nb0a = b0p[0], nb0b = b0p[64], nb1a = b1p[0], nb1b = b1p[64];
+    nm_h8 na0a = *reinterpret_cast<const nm_h8*>(a0p), na0b = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
+    nm_h8 na1a = *reinterpret_cast<const nm_h8*>(a1p), na1b = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE);
+    for (int ks = 0; ks < KS; ++ks) {
+        const nm_h8 b0a = nb0a, b0b = nb0b, b1a = nb1a, b1b = nb1b;
+        const nm_h8 a0a = na0a, a0b = na0b, a1a = na1a, a1b = na1b;
+        if (ks + 1 < KS) {
+            const int o = (ks + 1) * 128;
+            nb0a = b0p[o];
+            nb0b = b0p[o + 64];
+            nb1a = b1p[o];
+            nb1b = b1p[o + 64];
+            const int oa = (ks + 1) * 16;
+            na0a = *reinterpret_cast<const nm_h8*>(a0p + oa);
+            na0b = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
+            na1a = *reinterpret_cast<const nm_h8*>(a1p + oa);
+            na1b = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE + oa);
+        }
+        hi00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, b0a, hi00, 0, 0, 0);
+        hi01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, b1a, hi01, 0, 0, 0);
+        hi10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, b0a, hi10, 0, 0, 0);
+        hi11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, b1a, hi11, 0, 0, 0);
+        lo00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, b0b, lo00, 0, 0, 0);
+        lo01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, b1b, lo01, 0, 0, 0);
+        lo10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, b0b, lo10, 0, 0, 0);
+        lo11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, b1b, lo11, 0, 0, 0);
+        lo00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0b, b0a, lo00, 0, 0, 0);
+        lo01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0b, b1a, lo01, 0, 0, 0);
+        lo10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1b, b0a, lo10, 0, 0, 0);
+        lo11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1b, b1a, lo11, 0, 0, 0);
+    }
+    __syncthreads();  // every wave has finished reading the input tile
+    nm_phase_stamp(stamp_slot);
+    const float bias0 = bias[n0 + li], bias1 = bias[n0 + 32 + li];
+    const float sc = 1.0f / 2048.0f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;  // MFMA 32x32 C/D layout
+        const float z00 = fmaf(lo00[reg], sc, hi00[reg]) + bias0, z01 = fmaf(lo01[reg], sc, hi01[reg]) + bias1;
+        if (TANGENT) {
+            float g0, g1, y0, y1;
+            if (ACT == 0) {
+                y0 = nm_softplus100(z00, &g0);
+                y1 = nm_softplus100(z01, &g1);
+            } else {
+                y0 = fmaxf(z00, 0.f); g0 = z00 > 0.f ? 1.f : 0.f;
+                y1 = fmaxf(z01, 0.f); g1 = z01 > 0.f ? 1.f : 0.f;
+            }
+            nm_store_split(tile, row, n0 + li, y0);
+            nm_store_split(tile, row, n0 + 32 + li, y1);
+            nm_store_split(tile, 32 + row, n0 + li, fmaf(lo10[reg], sc, hi10[reg]) * g0);
+            nm_store_split(tile, 32 + row, n0 + 32 + li, fmaf(lo11[reg], sc, hi11[reg]) * g1);
+        } else {
+            const float z10 = fmaf(lo10[reg], sc, hi10[reg]) + bias0, z11 = fmaf(lo11[reg], sc, hi11[reg]) + bias1;
+            if (ACT == 0) {
+                nm_store_split(tile, row, n0 + li, nm_softplus100(z00, nullptr));
+                nm_store_split(tile, row, n0 + 32 + li, nm_softplus100(z01, nullptr));
+                nm_store_split(tile, 32 + row, n0 + li, nm_softplus100(z10, nullptr));
+                nm_store_split(tile, 32 + row, n0 + 32 + li, nm_softplus100(z11, nullptr));
+            } else {
+                nm_store_split(tile, row, n0 + li, fmaxf(z00, 0.f));
+                nm_store_split(tile, row, n0 + 32 + li, fmaxf(z01, 0.f));
+                nm_store_split(tile, 32 + row, n0 + li, fmaxf(z10, 0.f));
+                nm_store_split(tile, 32 + row, n0 + 32 + li, fmaxf(z11, 0.f));
+            }
+        }
+    }
+    __syncthreads();
+    nm_phase_stamp(stamp_slot + 1);
+}
+
+// x and its sin/cos bands for 4 consecutive feature dims, written split into the tile row
+__device__ __forceinline__ void nm_embed4_h(_Float16* tile, int row, int col0, int dim, int bands, int chunk, float4 x) {
+    const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * chunk + e;
+        nm_store_split(tile, row, col0 + c, xs[e]);
+        float f = 1.0f;
+        for (int b = 0; b < bands; ++b) {
+            float s, co;
+            nm_sincos(xs[e] * f, &s, &co);
+            nm_store_split(tile, row, col0 + dim * (1 + 2 * b) + c, s);
+            nm_store_split(tile, row, col0 + dim * (2 + 2 * b) + c, co);
+            f *= 2.0f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ geometry MLP (split-half)
+template <bool NABLA>
+__global__ __launch_bounds__(256, 2) void nm_geo_mlp_h_kernel(NmGeoParamsH prm, const float* __restrict__ fg_rec,
+                                                              const float* __restrict__ ds, const float* __restrict__ grad,
+                                                              NmRecMap rmap, long long npts, float* __restrict__ sdf_out, int P,
+                                                              int stride, int off, float* __restrict__ nabla_out) {
+    __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE + 2 * NM_ROWS];
+    float* red = reinterpret_cast<float*>(tile + 2 * NM_H_PLANE);
+    constexpr int PTS = NABLA ? 32 : 64;
+    const long long base = (long long)blockIdx.x * PTS;
+    nm_phase_stamp(0);
+    const int Kpad0 = prm.layer[0].Kpad;
+    for (int task = threadIdx.x; task < PTS * 8; task += 256) {
+        const int p = task >> 3, j = task & 7;
+        const long long q = base + p;
+        if (q >= npts) {
+            for (int c = j; c < Kpad0; c += 8) {
+                tile[p * NM_H_STRIDE + c] = (_Float16)0.0f;
+                tile[NM_H_PLANE + p * NM_H_STRIDE + c] = (_Float16)0.0f;
+                if (NABLA) {
+                    tile[(32 + p) * NM_H_STRIDE + c] = (_Float16)0.0f;
+                    tile[NM_H_PLANE + (32 + p) * NM_H_STRIDE + c] = (_Float16)0.0f;
+                }
+            }
+            continue;
+        }
+        for (int c = prm.in_dim + j; c < Kpad0; c += 8) {
+            tile[p * NM_H_STRIDE + c] = (_Float16)0.0f;
+            tile[NM_H_PLANE + p * NM_H_STRIDE + c] = (_Float16)0.0f;
+        }
+        const long long rq = nm_rec_index(rmap, q);
+        const float dsv = ds[rq];
+        if (j == 0) {
+            nm_store_split(tile, p, 0, dsv);
+            if (NABLA) nm_store_split(tile, 32 + p, 0, NM_TANGENT_SCALE);
+        }
+        if (NABLA)
+            for (int c = prm.d_emb + j; c < Kpad0; c += 8) {
+                tile[(32 + p) * NM_H_STRIDE + c] = (_Float16)0.0f;
+                tile[NM_H_PLANE + (32 + p) * NM_H_STRIDE + c] = (_Float16)0.0f;
+            }
+        for (int b = j; b < prm.multires_d; b += 8) {
+            const float f = (float)(1 << b);
+            float s, co;
+            nm_sincos(dsv * f, &s, &co);
+            nm_store_split(tile, p, 1 + 2 * b, s);
+            nm_store_split(tile, p, 2 + 2 * b, co);
+            if (NABLA) {
+                nm_store_split(tile, 32 + p, 1 + 2 * b, (NM_TANGENT_SCALE * f) * co);
+                nm_store_split(tile, 32 + p, 2 + 2 * b, -(NM_TANGENT_SCALE * f) * s);
+            }
+        }
+        for (int chunk = j; chunk < (prm.gdim >> 2); chunk += 8) {
+            const float4 fg = *reinterpret_cast<const float4*>(fg_rec + rq * prm.gdim + 4 * chunk);
+            nm_embed4_h(tile, p, prm.d_emb, prm.gdim, prm.multires_fg, chunk, fg);
+        }
+    }
+    __syncthreads();
+    nm_phase_stamp(1);
+    for (int l = 0; l < prm.D; ++l) {
+        const NmLayerH L = prm.layer[l];
+        nm_mlp_layer_h<0, NABLA>(tile, L.W, L.b, L.Kpad, 2 + 2 * l);
+    }
+    {
+        const int row = threadIdx.x >> 2, q4 = threadIdx.x & 3;
+        float s = 0.f;
+        for (int m = 0; m < 64; ++m) s = fmaf(nm_load_split(tile, row, q4 + 4 * m), prm.wd[q4 + 4 * m], s);
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        if (q4 == 0) red[row] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < PTS) {
+        const long long q = base + threadIdx.x;
+        if (q < npts) {
+            const float sdf = red[threadIdx.x] + prm.bd;
+            if (sdf_out) sdf_out[(q / P) * stride + off + (q % P)] = sdf;
+            if (NABLA && nabla_out) {
+                const float dsdf = red[32 + threadIdx.x] * (1.0f / NM_TANGENT_SCALE);
+                const long long rq = nm_rec_index(rmap, q);
+                nabla_out[q * 3 + 0] = dsdf * grad[rq * 3 + 0];
+                nabla_out[q * 3 + 1] = dsdf * grad[rq * 3 + 1];
+                nabla_out[q * 3 + 2] = dsdf * grad[rq * 3 + 2];
+            }
+        }
+    }
+    nm_phase_stamp(15);
+}
+
+// ------------------------------------------------------------------ colour MLP (split-half)
+__global__ __launch_bounds__(256, 2) void nm_col_mlp_h_kernel(NmColParamsH prm, const float* __restrict__ ft_rec,
+                                                              const float* __restrict__ ds, const float* __restrict__ nabla,
+                                                              const float* __restrict__ dirs, int dir_div, long long npts,
+                                                              float* __restrict__ rgb_out) {
+    __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE + 6 * NM_ROWS];
+    float* red = reinterpret_cast<float*>(tile + 2 * NM_H_PLANE);
+    const long long base = (long long)blockIdx.x * NM_ROWS;
+    nm_phase_stamp(0);
+    const int Kpad0 = prm.layer[0].Kpad;
+    const int o_d = prm.use_nabla ? 3 : 0;
+    const int o_v = o_d + prm.d_emb;
+    const int o_f = o_v + 3 * (1 + 2 * prm.multires_view);
+    for (int task = threadIdx.x; task < NM_ROWS * 8; task += 256) {
+        const int p = task >> 3, j = task & 7;
+        const long long q = base + p;
+        if (q >= npts) {
+            for (int c = j; c < Kpad0; c += 8) {
+                tile[p * NM_H_STRIDE + c] = (_Float16)0.0f;
+                tile[NM_H_PLANE + p * NM_H_STRIDE + c] = (_Float16)0.0f;
+            }
+            continue;
+        }
+        for (int c = prm.in_dim + j; c < Kpad0; c += 8) {
+            tile[p * NM_H_STRIDE + c] = (_Float16)0.0f;
+            tile[NM_H_PLANE + p * NM_H_STRIDE + c] = (_Float16)0.0f;
+        }
+        const float dsv = ds[q];
+        if (j == 0) {
+            nm_store_split(tile, p, o_d, dsv);
+            if (prm.use_nabla) {
+                nm_store_split(tile, p, 0, nabla[q * 3 + 0]);
+                nm_store_split(tile, p, 1, nabla[q * 3 + 1]);
+                nm_store_split(tile, p, 2, nabla[q * 3 + 2]);
+            }
+        }
+        for (int b = j; b < prm.multires_d; b += 8) {
+            float s, co;
+            nm_sincos(dsv * (float)(1 << b), &s, &co);
+            nm_store_split(tile, p, o_d + 1 + 2 * b, s);
+            nm_store_split(tile, p, o_d + 2 + 2 * b, co);
+        }
+        {
+            const float* dv = dirs + (q / dir_div) * 3;
+            if (j == 1) {
+                nm_store_split(tile, p, o_v, dv[0]);
+                nm_store_split(tile, p, o_v + 1, dv[1]);
+                nm_store_split(tile, p, o_v + 2, dv[2]);
+            }
+            for (int e = j; e < 3 * prm.multires_view; e += 8) {
+                const int dim = e % 3, b = e / 3;
+                float s, co;
+                nm_sincos(dv[dim] * (float)(1 << b), &s, &co);
+                nm_store_split(tile, p, o_v + 3 + 6 * b + dim, s);
+                nm_store_split(tile, p, o_v + 6 + 6 * b + dim, co);
+            }
+        }
+        for (int chunk = j; chunk < (prm.cdim >> 2); chunk += 8) {
+            const float4 ft = *reinterpret_cast<const float4*>(ft_rec + q * prm.cdim + 4 * chunk);
+            nm_embed4_h(tile, p, o_f, prm.cdim, prm.multires_ft, chunk, ft);
+        }
+    }
+    __syncthreads();
+    nm_phase_stamp(1);
+    for (int l = 0; l < prm.D; ++l) {
+        const NmLayerH L = prm.layer[l];
+        nm_mlp_layer_h<1, false>(tile, L.W, L.b, L.Kpad, 2 + 2 * l);
+    }
+    {
+        const int row = threadIdx.x >> 2, q4 = threadIdx.x & 3;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int m = 0; m < 64; ++m) {
+            const float av = nm_load_split(tile, row, q4 + 4 * m);
+            s0 = fmaf(av, prm.wrgb[q4 + 4 * m], s0);
+            s1 = fmaf(av, prm.wrgb[256 + q4 + 4 * m], s1);
+            s2 = fmaf(av, prm.wrgb[512 + q4 + 4 * m], s2);
+        }
+        s0 += __shfl_xor(s0, 1); s0 += __shfl_xor(s0, 2);
+        s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
+        s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
+        if (q4 == 0) {
+            red[3 * row] = s0;
+            red[3 * row + 1] = s1;
+            red[3 * row + 2] = s2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NM_ROWS * 3) {
+        const int p = threadIdx.x / 3, c = threadIdx.x % 3;
+        const long long q = base + p;
+        if (q < npts) {
+            const float z = red[threadIdx.x] + prm.brgb[c];
+            rgb_out[q * 3 + c] = __fdiv_rn(1.0f, 1.0f + expf(-z));
+        }
+    }
+    nm_phase_stamp(15);
+}

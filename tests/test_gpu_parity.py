@@ -164,9 +164,11 @@ def test_compute_distance_matches_reference(small, cuda_device, torch_mod):
     assert torch_mod.equal(ds, ds2)
 
 
-def test_field_methods_match_reference(small, cuda_device, torch_mod):
+@pytest.mark.parametrize("precision", ["f16x2", "fp32"])
+def test_field_methods_match_reference(small, cuda_device, torch_mod, precision):
     torch = torch_mod
     _, _, model = small
+    model.mlp_precision = precision     # both MLP arithmetic modes must meet the same bars
     fx = common.golden("field_v3000")
     q, dirs = _t(fx["q"], cuda_device), _t(fx["dirs"], cuda_device)
     tol_nab = 5e-6 + 2e-4 * np.abs(fx["ds"])   # fp32 sensitivity of the 2^7-band d-embedding, see oracle/gen_golden.py
@@ -184,6 +186,7 @@ def test_field_methods_match_reference(small, cuda_device, torch_mod):
     assert torch.equal(rgb, rgb2)
     assert np.array_equal(idx.cpu().numpy(), fx["idx"])
     assert abs(float(model.forward_s()) - float(fx["s"])) < 1e-3
+    model.mlp_precision = "f16x2"
 
 
 def test_mfma_tile_code_equals_scalar_alu_reference(small, cuda_device, torch_mod):
@@ -193,6 +196,7 @@ def test_mfma_tile_code_equals_scalar_alu_reference(small, cuda_device, torch_mo
     from neumesh_amd import _lib
     lib = _lib.load()
     _, _, model = small
+    model.mlp_precision = "fp32"      # this test is about the fp32 MFMA tile code
     fx = common.golden("field_v3000")
     q, dirs = _t(fx["q"], cuda_device), _t(fx["dirs"], cuda_device)
     P = q.shape[0]
@@ -210,6 +214,15 @@ def test_mfma_tile_code_equals_scalar_alu_reference(small, cuda_device, torch_mo
     np.testing.assert_allclose(sdf_m[:, 0].cpu().numpy(), sdf.cpu().numpy(), atol=2e-6)
     np.testing.assert_allclose(rgb_m.cpu().numpy(), rgb.cpu().numpy(), atol=2e-6)
     np.testing.assert_allclose(nab_m.cpu().numpy()[near], nab.cpu().numpy()[near], atol=1e-5)
+    # and the split-half f16 kernels against the fp32 MFMA kernels on the same inputs
+    model.mlp_precision = "f16x2"
+    with torch.no_grad():
+        sdf_h, rgb_h = model.forward(q, dirs)
+        _, nab_h = model.forward_with_nablas(q)
+    assert bool(torch.isfinite(sdf_h).all() and torch.isfinite(rgb_h).all() and torch.isfinite(nab_h).all())
+    np.testing.assert_allclose(sdf_h.cpu().numpy(), sdf_m.cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(rgb_h.cpu().numpy(), rgb_m.cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(nab_h.cpu().numpy()[near], nab_m.cpu().numpy()[near], atol=1e-5)
 
 
 def test_autograd_path_matches_fused_path(small, cuda_device, torch_mod):
@@ -244,11 +257,13 @@ def test_get_rays_kernel_matches_reference(cuda_device, torch_mod):
 
 
 # ----------------------------------------------------------------------------- renderer
+@pytest.mark.parametrize("precision", ["f16x2", "fp32"])
 @pytest.mark.parametrize("tag", ["render_v3000_dtu", "render_v3000_lego"])
-def test_render_matches_reference_fixture(small, cuda_device, torch_mod, tag):
+def test_render_matches_reference_fixture(small, cuda_device, torch_mod, tag, precision):
     torch = torch_mod
     from neumesh_amd import SingleRenderer
     _, _, model = small
+    model.mlp_precision = precision
     rf = common.golden(tag)
     ns = int(rf["N_samples"])
     renderer = SingleRenderer(model)
@@ -274,6 +289,7 @@ def test_render_matches_reference_fixture(small, cuda_device, torch_mod, tag):
     assert compare.psnr(e["rgb"], rf["rgb"]) > 100.0
     worst, unmatched = compare.depth_set_distance(e["d_all"], rf["d_all"])
     assert unmatched < 0.10 and worst < 5e-3                              # oracle/compare.py explains these two
+    model.mlp_precision = "f16x2"
 
 
 def test_wrapper_model_renders_through_staged_path(small, cuda_device, torch_mod):

@@ -16,8 +16,9 @@ def per_kernel(path, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
-        name = ("nm_geo_mlp_kernel<true>" if "nm_geo_mlp_kernel<true" in k else "nm_geo_mlp_kernel<false>" if "nm_geo_mlp_kernel<false" in k
-                else "nm_col_mlp_kernel" if "nm_col_mlp_kernel" in k else "nm_distance_kernel" if "nm_distance_kernel" in k else None)
+        name = ("geo_mlp_tangent" if ("nm_geo_mlp_kernel<true" in k or "nm_geo_mlp_h_kernel<true" in k)
+                else "geo_mlp" if ("nm_geo_mlp_kernel<false" in k or "nm_geo_mlp_h_kernel<false" in k)
+                else "color_mlp" if "nm_col_mlp" in k else "knn_distance" if "nm_distance_kernel" in k else None)
         if name:
             tot[name] += float(r["Counter_Value"])
             n[name] += 1
