@@ -13,7 +13,8 @@
 //       parent: index of the parent record (the traversal walks back up through it: no stack)
 //       info  : bits 0-7 child-occupancy mask, bits 8-10 the node's own child digit
 //       lo/hi : the node's TIGHT bounding box (fp32), already expanded by the rounding slack
-//       c     : box centre (orders the children near-first)
+//       ck*   : box centre as order-preserving integers; om_* : the occupancy mask pre-permuted into
+//               near-first visiting order for each of the 8 octants the query can lie in
 //     Children of a node are stored contiguously in child-digit order, so child c lives at
 //     first + popcount(mask & ((1 << c) - 1)).
 //     A mesh is a 2-D surface: inside a cell its vertices fill a thin slab, so the tight box
@@ -48,9 +49,13 @@ struct float4 { float x, y, z, w; };
 
 struct alignas(64) NmNode {  // 64 bytes
     uint32_t first, end, parent, info;
-    float lox, loy, loz, cx;
-    float hix, hiy, hiz, cy;
-    float cz, pad0, pad1, pad2;
+    float lox, loy, loz;
+    uint32_t ckx;             // box centre as order-preserving integer keys (nm_float_key)
+    float hix, hiy, hiz;
+    uint32_t cky;
+    uint32_t ckz;
+    uint32_t om_lo, om_hi;    // child masks in near-first visiting order for octant 0-3 / 4-7, one byte each
+    uint32_t pad;
 };
 
 struct NmGridView {
@@ -135,49 +140,58 @@ NM_HD float nm_box_lb2(const NmNode& n, float qx, float qy, float qz) {
     return (ax * ax + ay * ay + az * az) * 0.99999f;
 }
 
-NM_HD int nm_octant(const NmNode& n, float qx, float qy, float qz) {
-    return (qx >= n.cx ? 1 : 0) | (qy >= n.cy ? 2 : 0) | (qz >= n.cz ? 4 : 0);
+// float -> unsigned with the same ordering (negative floats: all bits flipped; others: sign set)
+NM_HD uint32_t nm_float_key(float f) {
+    const uint32_t u = (uint32_t)nm_as_int(f);
+    return u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u);
 }
 
-template <int K>
-NM_HD bool nm_topk_accepts(const float (&bd)[K], const int (&bi)[K], float d, int idx) {
-    return (d < bd[K - 1]) || (d == bd[K - 1] && idx < bi[K - 1]);
+// octant of the (key-converted) point relative to the node's box centre
+NM_HD int nm_octant(const NmNode& n, uint32_t kx, uint32_t ky, uint32_t kz) {
+    return (kx >= n.ckx ? 1 : 0) | (ky >= n.cky ? 2 : 0) | (kz >= n.ckz ? 4 : 0);
 }
 
-// insert (d, idx), known to be lexicographically smaller than the current last entry.
+// children still to visit (bit i = i-th child in near-first order) for a query in octant `first`
+NM_HD unsigned nm_visit_mask(const NmNode& n, int first) {
+    return ((first & 4 ? n.om_hi : n.om_lo) >> (8 * (first & 3))) & 255u;
+}
+
+// ---- top-K list as packed keys: (bits of d2) << 32 | index.  d2 >= 0, so the unsigned 64-bit
+// order of the keys IS the (d2, index) lexicographic order: one compare per test.
+NM_HD unsigned long long nm_key(float d2, int idx) {
+    return ((unsigned long long)(uint32_t)nm_as_int(d2) << 32) | (unsigned long long)(uint32_t)idx;
+}
+NM_HD float nm_key_d2(unsigned long long k) { return nm_as_float((int)(uint32_t)(k >> 32)); }
+NM_HD int nm_key_idx(unsigned long long k) { return (int)(uint32_t)k; }
+
+// insert `key`, known to be smaller than the current last entry; branch-free bubble
 template <int K>
-NM_HD void nm_topk_insert(float (&bd)[K], int (&bi)[K], float d, int idx) {
-    bd[K - 1] = d;
-    bi[K - 1] = idx;
+NM_HD void nm_topk_insert(unsigned long long (&kk)[K], unsigned long long key) {
+    kk[K - 1] = key;
 #pragma unroll
     for (int p = K - 1; p > 0; --p) {
-        const bool sw = (bd[p] < bd[p - 1]) || (bd[p] == bd[p - 1] && bi[p] < bi[p - 1]);
-        const float d0 = bd[p - 1], d1 = bd[p];
-        const int i0 = bi[p - 1], i1 = bi[p];
-        bd[p - 1] = sw ? d1 : d0;
-        bd[p] = sw ? d0 : d1;
-        bi[p - 1] = sw ? i1 : i0;
-        bi[p] = sw ? i0 : i1;
+        const unsigned long long a = kk[p - 1], b = kk[p];
+        const bool sw = b < a;
+        kk[p - 1] = sw ? b : a;
+        kk[p] = sw ? a : b;
     }
 }
 
-// Exact K-NN of (qx,qy,qz).  On return bd/bi hold the K best ascending by (d2, index);
-// unfilled slots (V < K) keep d2 = +INF, index = INT32_MAX.
-// STATS (host logic check only): stats[0] += node records tested, stats[1] += vertices scanned.
+// Exact K-NN of (qx,qy,qz).  On return kk holds the K best keys ascending ((d2, index) order);
+// unfilled slots (V < K) keep d2 = init, index = INT32_MAX.
 // init_d2: every slot starts at this squared distance with index INT32_MAX; pass +INF for a cold
 // search, or a PROVEN upper bound of the K-th neighbour's squared distance for a warm start (at
 // least K real vertices then beat the placeholders, so none survives).
+// STATS (host logic check only): stats[0] += node records tested, stats[1] += vertices scanned.
 template <int K, bool STATS = false>
-NM_HD void nm_knn_search(const NmGridView& g, float qx, float qy, float qz, float (&bd)[K], int (&bi)[K],
+NM_HD void nm_knn_search(const NmGridView& g, float qx, float qy, float qz, unsigned long long (&kk)[K],
                          long long* stats = nullptr, float init_d2 = NM_INF_F) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        bd[k] = init_d2;
-        bi[k] = 0x7fffffff;
-    }
+    for (int k = 0; k < K; ++k) kk[k] = nm_key(init_d2, 0x7fffffff);
+    const uint32_t kx = nm_float_key(qx), ky = nm_float_key(qy), kz = nm_float_key(qz);
     NmNode rec = g.nodes[0];
-    int first = nm_octant(rec, qx, qy, qz);
-    unsigned om = nm_ordered_mask(rec.info & 255u, first);  // children still to visit, near-first
+    int first = nm_octant(rec, kx, ky, kz);
+    unsigned om = nm_visit_mask(rec, first);  // children still to visit, near-first
     bool at_root = true;
     for (;;) {
         if (om == 0u) {
@@ -186,8 +200,8 @@ NM_HD void nm_knn_search(const NmGridView& g, float qx, float qy, float qz, floa
             const uint32_t parent = rec.parent;
             rec = g.nodes[parent];
             at_root = parent == 0u;
-            first = nm_octant(rec, qx, qy, qz);
-            om = nm_ordered_mask(rec.info & 255u, first) & ~((2u << nm_perm(c_prev ^ first)) - 1u);
+            first = nm_octant(rec, kx, ky, kz);
+            om = nm_visit_mask(rec, first) & ~((2u << nm_perm(c_prev ^ first)) - 1u);
             continue;
         }
         const int i = nm_ctz(om);
@@ -196,20 +210,19 @@ NM_HD void nm_knn_search(const NmGridView& g, float qx, float qy, float qz, floa
         const uint32_t mask = rec.info & 255u;
         const NmNode crec = g.nodes[rec.first + (uint32_t)nm_popc(mask & ((1u << c) - 1u))];
         if (STATS) stats[0] += 1;
-        if (nm_box_lb2(crec, qx, qy, qz) > bd[K - 1]) continue;
+        if (nm_box_lb2(crec, qx, qy, qz) > nm_key_d2(kk[K - 1])) continue;
         if ((crec.info & 255u) == 0u) {  // leaf
             if (STATS) stats[1] += (long long)(crec.end - crec.first);
             for (uint32_t p = crec.first; p < crec.end; ++p) {
                 const float4 v = g.sverts[p];
-                const float d = nm_dist2(qx, qy, qz, v.x, v.y, v.z);
-                const int idx = nm_as_int(v.w);
-                if (nm_topk_accepts<K>(bd, bi, d, idx)) nm_topk_insert<K>(bd, bi, d, idx);
+                const unsigned long long key = nm_key(nm_dist2(qx, qy, qz, v.x, v.y, v.z), nm_as_int(v.w));
+                if (key < kk[K - 1]) nm_topk_insert<K>(kk, key);
             }
         } else {
             rec = crec;
             at_root = false;
-            first = nm_octant(rec, qx, qy, qz);
-            om = nm_ordered_mask(rec.info & 255u, first);
+            first = nm_octant(rec, kx, ky, kz);
+            om = nm_visit_mask(rec, first);
         }
     }
 }

@@ -179,9 +179,16 @@ static inline bool nm_build_host_grid(const float* verts, int64_t V, int leaf_le
             }
             r.lox = blo[0]; r.loy = blo[1]; r.loz = blo[2];
             r.hix = bhi[0]; r.hiy = bhi[1]; r.hiz = bhi[2];
-            r.cx = 0.5f * (blo[0] + bhi[0]);
-            r.cy = 0.5f * (blo[1] + bhi[1]);
-            r.cz = 0.5f * (blo[2] + bhi[2]);
+            r.ckx = nm_float_key(0.5f * (blo[0] + bhi[0]));
+            r.cky = nm_float_key(0.5f * (blo[1] + bhi[1]));
+            r.ckz = nm_float_key(0.5f * (blo[2] + bhi[2]));
+            r.om_lo = r.om_hi = 0;
+            for (int fo = 0; fo < 8; ++fo) {
+                const uint32_t om = nm_ordered_mask(mask, fo);
+                if (fo < 4) r.om_lo |= om << (8 * fo);
+                else r.om_hi |= om << (8 * (fo - 4));
+            }
+            r.pad = 0;
             g.nodes[(size_t)off[(size_t)l] + n] = r;
         }
     }

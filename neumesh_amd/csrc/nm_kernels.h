@@ -84,14 +84,12 @@ typedef unsigned nm_u32x4 __attribute__((ext_vector_type(4)));
 typedef float nm_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ NmNode nm_ld_node(const NmNode* base, uint32_t i) {
     const nm_u32x4 NM_CONSTANT* pu = (const nm_u32x4 NM_CONSTANT*)(base + i);
-    const nm_f32x4 NM_CONSTANT* pf = (const nm_f32x4 NM_CONSTANT*)(base + i);
-    const nm_u32x4 h = pu[0];
-    const nm_f32x4 a = pf[1], b = pf[2], c = pf[3];
+    const nm_u32x4 h = pu[0], a = pu[1], b = pu[2], c = pu[3];
     NmNode n;
     n.first = h.x; n.end = h.y; n.parent = h.z; n.info = h.w;
-    n.lox = a.x; n.loy = a.y; n.loz = a.z; n.cx = a.w;
-    n.hix = b.x; n.hiy = b.y; n.hiz = b.z; n.cy = b.w;
-    n.cz = c.x; n.pad0 = 0.f; n.pad1 = 0.f; n.pad2 = 0.f;
+    n.lox = __uint_as_float(a.x); n.loy = __uint_as_float(a.y); n.loz = __uint_as_float(a.z); n.ckx = a.w;
+    n.hix = __uint_as_float(b.x); n.hiy = __uint_as_float(b.y); n.hiz = __uint_as_float(b.z); n.cky = b.w;
+    n.ckz = c.x; n.om_lo = c.y; n.om_hi = c.z; n.pad = 0;
     return n;
 }
 __device__ __forceinline__ float4 nm_ld_vert(const float4* base, uint32_t i) {
@@ -115,16 +113,13 @@ __device__ __forceinline__ float nm_wave_max(float v) {
 
 template <int K>
 __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float qx, float qy, float qz, bool active,
-                                                     float rx, float ry, float rz, float (&bd)[K], int (&bi)[K],
-                                                     float init_d2) {
+                                                     float rx, float ry, float rz, unsigned long long (&kk)[K], float init_d2) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        bd[k] = init_d2;
-        bi[k] = 0x7fffffff;
-    }
+    for (int k = 0; k < K; ++k) kk[k] = nm_key(init_d2, 0x7fffffff);
+    const uint32_t kx = nm_float_key(rx), ky = nm_float_key(ry), kz = nm_float_key(rz);  // wave-uniform
     NmNode rec = nm_ld_node(g.nodes, 0);
-    int first = nm_octant(rec, rx, ry, rz);
-    unsigned om = nm_ordered_mask(rec.info & 255u, first);
+    int first = nm_octant(rec, kx, ky, kz);
+    unsigned om = nm_visit_mask(rec, first);
     bool at_root = true;
     for (;;) {
         if (om == 0u) {
@@ -133,8 +128,8 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
             const uint32_t parent = rec.parent;
             rec = nm_ld_node(g.nodes, parent);
             at_root = parent == 0u;
-            first = nm_octant(rec, rx, ry, rz);
-            om = nm_ordered_mask(rec.info & 255u, first) & ~((2u << nm_perm(c_prev ^ first)) - 1u);
+            first = nm_octant(rec, kx, ky, kz);
+            om = nm_visit_mask(rec, first) & ~((2u << nm_perm(c_prev ^ first)) - 1u);
             continue;
         }
         const int i = __builtin_ctz(om);
@@ -142,7 +137,7 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
         const int c = first ^ nm_perm(i);
         const uint32_t mask = rec.info & 255u;
         const NmNode crec = nm_ld_node(g.nodes, rec.first + (uint32_t)__popc(mask & ((1u << c) - 1u)));
-        const bool want = active && (nm_box_lb2(crec, qx, qy, qz) <= bd[K - 1]);
+        const bool want = active && (nm_box_lb2(crec, qx, qy, qz) <= nm_key_d2(kk[K - 1]));
         if (!__any(want)) continue;
         if ((crec.info & 255u) == 0u) {  // leaf: 4 vertices per step (the array is padded)
             for (uint32_t p = crec.first; p < crec.end; p += 4) {
@@ -152,17 +147,16 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (p + j < crec.end) {
-                        const float d = nm_dist2(qx, qy, qz, vv[j].x, vv[j].y, vv[j].z);
-                        const int idx = nm_as_int(vv[j].w);
-                        if (want && nm_topk_accepts<K>(bd, bi, d, idx)) nm_topk_insert<K>(bd, bi, d, idx);
+                        const unsigned long long key = nm_key(nm_dist2(qx, qy, qz, vv[j].x, vv[j].y, vv[j].z), nm_as_int(vv[j].w));
+                        if (want && key < kk[K - 1]) nm_topk_insert<K>(kk, key);
                     }
                 }
             }
         } else {
             rec = crec;
             at_root = false;
-            first = nm_octant(rec, rx, ry, rz);
-            om = nm_ordered_mask(rec.info & 255u, first);
+            first = nm_octant(rec, kx, ky, kz);
+            om = nm_visit_mask(rec, first);
         }
     }
 }
@@ -173,7 +167,7 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
 // (e.g. randomly scattered points through the point-wise API).
 template <int K>
 __device__ __forceinline__ void nm_knn_wave(const NmGridView& g, float qx, float qy, float qz, bool active,
-                                            float (&bd)[K], int (&bi)[K], float init_d2 = NM_INF_F) {
+                                            unsigned long long (&kk)[K], float init_d2 = NM_INF_F) {
     // inactive lanes borrow an active lane's position so that they do not stretch the box
     const unsigned long long act = __ballot(active);
     if (act == 0ull) return;
@@ -186,9 +180,9 @@ __device__ __forceinline__ void nm_knn_wave(const NmGridView& g, float qx, float
     const float ext = nm_uniform_f(fmaxf(fmaxf(hix - lox, hiy - loy), hiz - loz));
     if (ext <= g.coop_extent) {
         nm_knn_search_packet<K>(g, qx, qy, qz, active, nm_uniform_f(0.5f * (lox + hix)), nm_uniform_f(0.5f * (loy + hiy)),
-                                nm_uniform_f(0.5f * (loz + hiz)), bd, bi, init_d2);
+                                nm_uniform_f(0.5f * (loz + hiz)), kk, init_d2);
     } else if (active) {
-        nm_knn_search<K>(g, qx, qy, qz, bd, bi, nullptr, init_d2);
+        nm_knn_search<K>(g, qx, qy, qz, kk, nullptr, init_d2);
     }
 }
 
@@ -280,16 +274,16 @@ __global__ __launch_bounds__(256) void nm_knn_kernel(NmGridView g, NmPointSrc sr
     const bool active = nm_lane_query(src, Q, q);
     float x = 0.f, y = 0.f, z = 0.f;
     if (active) nm_fetch_point(src, q, x, y, z);
-    float bd[K];
-    int bi[K];
-    nm_knn_wave<K>(g, x, y, z, active, bd, bi);
+    unsigned long long kk[K];
+    nm_knn_wave<K>(g, x, y, z, active, kk);
     if (!active) return;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (k < Kout) {
-            const bool ok = bi[k] != 0x7fffffff;
-            idx_out[q * Kout + k] = ok ? (long long)bi[k] : -1ll;
-            d2_out[q * Kout + k] = ok ? bd[k] : -1.0f;
+            const int bi = nm_key_idx(kk[k]);
+            const bool ok = bi != 0x7fffffff;
+            idx_out[q * Kout + k] = ok ? (long long)bi : -1ll;
+            d2_out[q * Kout + k] = ok ? nm_key_d2(kk[k]) : -1.0f;
         }
     }
 }
@@ -315,7 +309,15 @@ __global__ __launch_bounds__(256) void nm_distance_kernel(NmGridView g, NmPointS
     }
     float bd[8], wk[8], gr[3];
     int bi[8];
-    nm_knn_wave<8>(g, x, y, z, active, bd, bi, init);
+    {
+        unsigned long long kk[8];
+        nm_knn_wave<8>(g, x, y, z, active, kk, init);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            bd[k] = nm_key_d2(kk[k]);
+            bi[k] = nm_key_idx(kk[k]);
+        }
+    }
     float ds = 0.f;
     long long o = 0;
     if (active) {

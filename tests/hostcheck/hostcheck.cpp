@@ -20,13 +20,12 @@ template <int K>
 static void knn_t(const NmGridView& v, const float* q, int64_t Q, int64_t* idx, float* d2) {
 #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t i = 0; i < Q; ++i) {
-        float bd[K];
-        int bi[K];
-        nm_knn_search<K>(v, q[3 * i], q[3 * i + 1], q[3 * i + 2], bd, bi);
+        unsigned long long kk[K];
+        nm_knn_search<K>(v, q[3 * i], q[3 * i + 1], q[3 * i + 2], kk);
         for (int k = 0; k < K; ++k) {
-            const bool ok = bi[k] != 0x7fffffff;
-            idx[i * K + k] = ok ? bi[k] : -1;
-            d2[i * K + k] = ok ? bd[k] : -1.0f;
+            const bool ok = nm_key_idx(kk[k]) != 0x7fffffff;
+            idx[i * K + k] = ok ? nm_key_idx(kk[k]) : -1;
+            d2[i * K + k] = ok ? nm_key_d2(kk[k]) : -1.0f;
         }
     }
 }
@@ -65,13 +64,12 @@ int hc_knn_warm(void* p, const float* q, int64_t Q, const float* bound, int64_t*
     const NmGridView v = nm_host_view(((HostGridHandle*)p)->g);
     long long st[2] = {0, 0};
     for (int64_t i = 0; i < Q; ++i) {
-        float bd[8];
-        int bi[8];
+        unsigned long long kk[8];
         const float b = bound[i] * 1.0001f + 1e-5f;
-        nm_knn_search<8, true>(v, q[3 * i], q[3 * i + 1], q[3 * i + 2], bd, bi, st, b * b);
+        nm_knn_search<8, true>(v, q[3 * i], q[3 * i + 1], q[3 * i + 2], kk, st, b * b);
         for (int k = 0; k < 8; ++k) {
-            idx[i * 8 + k] = bi[k] != 0x7fffffff ? bi[k] : -1;
-            d2[i * 8 + k] = bd[k];
+            idx[i * 8 + k] = nm_key_idx(kk[k]) != 0x7fffffff ? nm_key_idx(kk[k]) : -1;
+            d2[i * 8 + k] = nm_key_d2(kk[k]);
         }
     }
     out[0] = (double)st[0] / (double)(Q > 0 ? Q : 1);
@@ -84,9 +82,8 @@ int hc_knn_stats(void* p, const float* q, int64_t Q, double* out) {
     const NmGridView v = nm_host_view(((HostGridHandle*)p)->g);
     long long st[2] = {0, 0};
     for (int64_t i = 0; i < Q; ++i) {
-        float bd[8];
-        int bi[8];
-        nm_knn_search<8, true>(v, q[3 * i], q[3 * i + 1], q[3 * i + 2], bd, bi, st);
+        unsigned long long kk[8];
+        nm_knn_search<8, true>(v, q[3 * i], q[3 * i + 1], q[3 * i + 2], kk, st);
     }
     out[0] = (double)st[0] / (double)(Q > 0 ? Q : 1);
     out[1] = (double)st[1] / (double)(Q > 0 ? Q : 1);
@@ -100,18 +97,18 @@ int hc_knn_stats(void* p, const float* q, int64_t Q, double* out) {
 int hc_knn_packet(void* p, const float* q, int64_t Q, int Wd, int64_t* idx, float* d2, double* out) {
     const NmGridView g = nm_host_view(((HostGridHandle*)p)->g);
     long long nodes_t = 0, verts_t = 0, packets = 0;
-    std::vector<float> bd((size_t)Wd * 8);
-    std::vector<int> bi((size_t)Wd * 8);
+    std::vector<unsigned long long> kk((size_t)Wd * 8);
     for (int64_t base = 0; base < Q; base += Wd) {
         const int n = (int)std::min<int64_t>(Wd, Q - base);
         ++packets;
-        for (int l = 0; l < n * 8; ++l) { bd[(size_t)l] = NM_INF_F; bi[(size_t)l] = 0x7fffffff; }
+        for (int l = 0; l < n * 8; ++l) kk[(size_t)l] = nm_key(NM_INF_F, 0x7fffffff);
         float cx0 = 0, cy0 = 0, cz0 = 0;
         for (int l = 0; l < n; ++l) { cx0 += q[3 * (base + l)]; cy0 += q[3 * (base + l) + 1]; cz0 += q[3 * (base + l) + 2]; }
         cx0 /= n; cy0 /= n; cz0 /= n;
+        const uint32_t kx = nm_float_key(cx0), ky = nm_float_key(cy0), kz = nm_float_key(cz0);
         NmNode rec = g.nodes[0];
-        int first = nm_octant(rec, cx0, cy0, cz0);
-        unsigned om = nm_ordered_mask(rec.info & 255u, first);
+        int first = nm_octant(rec, kx, ky, kz);
+        unsigned om = nm_visit_mask(rec, first);
         bool at_root = true;
         for (;;) {
             if (om == 0) {
@@ -120,8 +117,8 @@ int hc_knn_packet(void* p, const float* q, int64_t Q, int Wd, int64_t* idx, floa
                 const uint32_t parent = rec.parent;
                 rec = g.nodes[parent];
                 at_root = parent == 0u;
-                first = nm_octant(rec, cx0, cy0, cz0);
-                om = nm_ordered_mask(rec.info & 255u, first) & ~((2u << nm_perm(c_prev ^ first)) - 1u);
+                first = nm_octant(rec, kx, ky, kz);
+                om = nm_visit_mask(rec, first) & ~((2u << nm_perm(c_prev ^ first)) - 1u);
                 continue;
             }
             const int i = __builtin_ctz(om);
@@ -134,7 +131,7 @@ int hc_knn_packet(void* p, const float* q, int64_t Q, int Wd, int64_t* idx, floa
             std::vector<char> want((size_t)n);
             for (int l = 0; l < n; ++l) {
                 const float* ql = q + 3 * (base + l);
-                want[(size_t)l] = nm_box_lb2(crec, ql[0], ql[1], ql[2]) <= bd[(size_t)l * 8 + 7];
+                want[(size_t)l] = nm_box_lb2(crec, ql[0], ql[1], ql[2]) <= nm_key_d2(kk[(size_t)l * 8 + 7]);
                 any |= want[(size_t)l] != 0;
             }
             if (!any) continue;
@@ -145,24 +142,24 @@ int hc_knn_packet(void* p, const float* q, int64_t Q, int Wd, int64_t* idx, floa
                     for (int l = 0; l < n; ++l) {
                         if (!want[(size_t)l]) continue;
                         const float* ql = q + 3 * (base + l);
-                        const float d = nm_dist2(ql[0], ql[1], ql[2], v.x, v.y, v.z);
-                        float(&b8)[8] = *reinterpret_cast<float(*)[8]>(&bd[(size_t)l * 8]);
-                        int(&i8)[8] = *reinterpret_cast<int(*)[8]>(&bi[(size_t)l * 8]);
-                        if (nm_topk_accepts<8>(b8, i8, d, nm_as_int(v.w))) nm_topk_insert<8>(b8, i8, d, nm_as_int(v.w));
+                        const unsigned long long key = nm_key(nm_dist2(ql[0], ql[1], ql[2], v.x, v.y, v.z), nm_as_int(v.w));
+                        unsigned long long(&k8)[8] = *reinterpret_cast<unsigned long long(*)[8]>(&kk[(size_t)l * 8]);
+                        if (key < k8[7]) nm_topk_insert<8>(k8, key);
                     }
                 }
             } else {
                 rec = crec;
                 at_root = false;
-                first = nm_octant(rec, cx0, cy0, cz0);
-                om = nm_ordered_mask(rec.info & 255u, first);
+                first = nm_octant(rec, kx, ky, kz);
+                om = nm_visit_mask(rec, first);
             }
         }
         for (int l = 0; l < n; ++l)
             for (int k = 0; k < 8; ++k) {
-                const bool ok = bi[(size_t)l * 8 + k] != 0x7fffffff;
-                idx[(base + l) * 8 + k] = ok ? bi[(size_t)l * 8 + k] : -1;
-                d2[(base + l) * 8 + k] = ok ? bd[(size_t)l * 8 + k] : -1.0f;
+                const unsigned long long key = kk[(size_t)l * 8 + k];
+                const bool ok = nm_key_idx(key) != 0x7fffffff;
+                idx[(base + l) * 8 + k] = ok ? nm_key_idx(key) : -1;
+                d2[(base + l) * 8 + k] = ok ? nm_key_d2(key) : -1.0f;
             }
     }
     out[0] = (double)nodes_t / (double)(packets ? packets : 1);
@@ -178,7 +175,12 @@ int hc_compute_distance(void* p, const float* q, int64_t Q, const float* indicat
     for (int64_t i = 0; i < Q; ++i) {
         float bd[8], wk[8], g[3];
         int bi[8];
-        nm_knn_search<8>(v, q[3 * i], q[3 * i + 1], q[3 * i + 2], bd, bi);
+        unsigned long long kk[8];
+        nm_knn_search<8>(v, q[3 * i], q[3 * i + 1], q[3 * i + 2], kk);
+        for (int k = 0; k < 8; ++k) {
+            bd[k] = nm_key_d2(kk[k]);
+            bi[k] = nm_key_idx(kk[k]);
+        }
         ds[i] = nm_projected_distance8(q[3 * i], q[3 * i + 1], q[3 * i + 2], bd, bi, h->verts.data(), indicator, w1, wk, g);
         for (int k = 0; k < 8; ++k) {
             idx[i * 8 + k] = bi[k];
