@@ -481,6 +481,7 @@ struct NmWorkspace {
     float *rgb_mid, *nab_pts, *nab_mid;
     int* slot;                    // [R][N] generation position of the sample at each sorted position
     float *radius, *bound, *bound_mid;  // [R][N] K-th-neighbour distance per slot; warm-start bounds
+    unsigned short* order;        // depth-bucket lane assignment of one up-sampling pass
     NmScratch slots;  // per-ray slot records (coarse + up-sampling passes), reused by the final pass
     NmScratch pts;    // compact records of the mid-point pass
     size_t bytes;
@@ -505,6 +506,7 @@ static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) 
     w.radius = (float*)take((size_t)R * N * 4);
     w.bound = (float*)take((size_t)R * N * 4);
     w.bound_mid = (float*)take((size_t)R * N * 4);
+    w.order = (unsigned short*)take((size_t)((R + 63) / 64) * 64 * (size_t)(c->N_importance > 0 ? c->N_importance / c->N_upsample_iters : 1) * 2);
     w.slots = nm_carve(p + o, R * N, false);
     o += w.slots.bytes;
     w.pts = nm_carve(p + o, R * N, false);
@@ -608,6 +610,14 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
             src.bound = ws.bound;
             src.out_stride = cap;
             src.out_off = n;
+            src.order = nullptr;
+            if (64 * n_new <= 4096 && 64 * n_new <= 65536) {  // LDS sort capacity / 16-bit ids
+                int np2 = 64;
+                while (np2 < 64 * n_new) np2 <<= 1;
+                hipLaunchKernelGGL(nm_rays_order_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), (size_t)np2 * 8, stream, ws.d, (long long)R, cap, n, n_new, np2, ws.order);
+                NM_LAUNCH_CHECK();
+                src.order = ws.order;
+            }
             if (nm_launch_distance(g, src, (long long)R * n_new, t->indicator_vector, t->indicator_weight, ws.slots.ds, nullptr, nullptr, nullptr, want_grad ? ws.slots.grad : nullptr, stream, ws.radius, ga_slots)) return 1;
             const NmRecMap rm = {n_new, cap, n, nullptr};
             if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, nullptr, (long long)R * n_new, false, ws.sdf, n_new, cap, n, nullptr, stream, rm)) return 1;
@@ -624,6 +634,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
         if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, ws.slots.grad, (long long)R * N, true, ws.sdf, N, cap, 0, ws.nab_pts, stream, rm)) return 1;
     }
     // SDF + nabla + radiance at the N-1 mid-points (renderer.py:266-267, 279-282)
+    src.order = nullptr;
     src.mode = 1;
     src.P = N - 1;
     src.depth = ws.dmid;
