@@ -91,13 +91,14 @@ struct NmColParams {
 // evaluates this 16 K times per workgroup, so its cost is what decides whether the kernel is
 // MFMA-bound.
 __device__ __forceinline__ float nm_softplus100(float x, float* grad) {
-    const float t = x * 100.0f;
-    const float z = __builtin_amdgcn_exp2f(fminf(t, 21.0f) * 1.44269504f);
+    // branch-free: z = e^min(100x, 21), y = log(1 + z) / 100.  For small z the rounding of 1 + z costs
+    // <= 6e-8 ABSOLUTE in log(1 + z), i.e. <= 6e-10 in y -- below the fp32 spacing of the O(0.01..1)
+    // values the next layer sums (tests/test_hostlogic.py::test_fast_softplus_formula).
+    const float z = __builtin_amdgcn_exp2f(fminf(x * 144.269504f, 30.2965958f));
     const float u = 1.0f + z;
-    const float l = (z < 0.0009765625f) ? z * (1.0f - 0.5f * z) : __builtin_amdgcn_logf(u) * 0.69314718f;
-    const bool lin = t > 20.0f;
+    const bool lin = x > 0.2f;  // torch: x*beta > threshold returns x (there log(1+z)/100 == x to 1 ulp)
     if (grad) *grad = lin ? 1.0f : z * __builtin_amdgcn_rcpf(u);
-    return lin ? x : l * 0.01f;
+    return lin ? x : __builtin_amdgcn_logf(u) * 0.0069314718f;
 }
 
 // One dense layer on the LDS tile: act[64][K] -> act[64][256] (in place).

@@ -15,8 +15,8 @@
 // them, so the K loop is pure operand loads + MFMA (12 MFMAs = 384 cycles per 16 k-values per wave,
 // against 2048 cycles for the fp32 form).
 //
-// Range: |values| must stay below 65504 (fp16); inputs below 2^-14 in magnitude go entirely into
-// the scaled half (no fp16 subnormals reach the matrix pipe).  The tangent rows (d h / d ds, seeded
+// Range: |values| must stay below 65504 (fp16); fp16 subnormals are exact on the matrix pipe
+// (probe: tools/mfma_denorm.hip), so small values need no special case.  The tangent rows (d h / d ds, seeded
 // with up to 2^7 * cos) are linear in their seed, so they are carried scaled by 2^-8 and the final
 // d sdf / d ds is multiplied back by 2^8 (exact), which keeps them far from the fp16 range limit.
 // An overflow shows up as a non-finite output.  nm_field_desc.mlp_precision selects
@@ -30,6 +30,9 @@ typedef _Float16 nm_h8 __attribute__((ext_vector_type(8)));
 #define NM_TANGENT_SCALE 0.00390625f  // 2^-8
 #define NM_H_STRIDE 264  // halves per tile row: 528 B = 33 16-byte slots -> conflict-free ds_read_b128
 #define NM_H_PLANE (NM_ROWS * NM_H_STRIDE)
+#ifndef NM_EXP_LDS_PAD
+#define NM_EXP_LDS_PAD 0  // experiments: extra LDS halves per workgroup (forces 1 workgroup per CU)
+#endif
 
 struct NmLayerH {
     const _Float16* W;  // packed fragments: [col tile 8][k-step Kpad/16][plane 2][lane 64][8 halves]
@@ -55,9 +58,10 @@ struct NmColParamsH {
     int d_emb, in_dim;
 };
 
-// a -> (h1, h2): a ~= h1 + h2 / 2048
+// a -> (h1, h2): a ~= h1 + h2 / 2048.  fp16 subnormals are fine on both sides: v_cvt_f16_f32 produces
+// them and the matrix pipe consumes them exactly (probe: tools/mfma_denorm.hip on gfx950).
 __device__ __forceinline__ void nm_split_half(float a, _Float16* h1, _Float16* h2) {
-    const _Float16 p = fabsf(a) < 6.2e-5f ? (_Float16)0.0f : (_Float16)a;
+    const _Float16 p = (_Float16)a;
     *h1 = p;
     *h2 = (_Float16)((a - (float)p) * 2048.0f);
 }
@@ -87,51 +91,143 @@ __global__ void nm_pack_weight_h_kernel(const float* __restrict__ src, int in_di
     dst[base + 64 * 8 + (size_t)lane * 8 + el] = h2;
 }
 
-// One dense layer on the split-half LDS tile (in place), see the header comment.
-template <int ACT, bool TANGENT>
-__device__ __forceinline__ void nm_mlp_layer_h(_Float16* tile, const _Float16* __restrict__ W, const float* __restrict__ bias,
-                                               int Kpad, int stamp_slot) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 31, h = lane >> 5;
-    const int n0 = wave * 64;
-    const int KS = Kpad >> 4;
-    nm_f32x16 hi00 = {0}, hi01 = {0}, hi10 = {0}, hi11 = {0};
-    nm_f32x16 lo00 = {0}, lo01 = {0}, lo10 = {0}, lo11 = {0};
-    const _Float16* a0p = tile + li * NM_H_STRIDE + 8 * h;
-    const _Float16* a1p = tile + (32 + li) * NM_H_STRIDE + 8 * h;
-    const nm_h8* b0p = reinterpret_cast<const nm_h8*>(W) + (size_t)(wave * 2) * KS * 2 * 64 + lane;       // column tile 2*wave
-    const nm_h8* b1p = reinterpret_cast<const nm_h8*>(W) + (size_t)(wave * 2 + 1) * KS * 2 * 64 + lane;   // column tile 2*wave+1
-    nm_h8 nb0a = b0p[0], nb0b = b0p[64], nb1a = b1p[0], nb1b = b1p[64];
+// B operand (weights) of one k-step for the two column tiles of a wave: 4 x 16 bytes per lane.
+struct NmBFrag {
+    nm_h8 b0a, b0b, b1a, b1b;
+};
+__device__ __forceinline__ const nm_h8* nm_b_base(const _Float16* W, int Kpad, int ctile) {
+    return reinterpret_cast<const nm_h8*>(W) + (size_t)ctile * (Kpad >> 4) * 2 * 64 + (threadIdx.x & 63);
+}
+__device__ __forceinline__ NmBFrag nm_ld_b(const nm_h8* b0p, const nm_h8* b1p, int ks) {
+    NmBFrag f;
+    const int o = ks * 128;
+    f.b0a = b0p[o];
+    f.b0b = b0p[o + 64];
+    f.b1a = b1p[o];
+    f.b1b = b1p[o + 64];
+    return f;
+}
+// the first two k-steps of a layer (issued early: before the input phase / the previous epilogue)
+__device__ __forceinline__ void nm_prefetch_b(const NmLayerH L, NmBFrag& p0, NmBFrag& p1) {
+    const int wave = threadIdx.x >> 6;
+    const nm_h8* b0p = nm_b_base(L.W, L.Kpad, wave * 2);
+    const nm_h8* b1p = nm_b_base(L.W, L.Kpad, wave * 2 + 1);
+    p0 = nm_ld_b(b0p, b1p, 0);
+    p1 = nm_ld_b(b0p, b1p, 1);  // Kpad >= 32 always (in_dim >= 17)
+}
+
+struct NmAccH {  // 2x2 output tiles of a wave, main and 2^11-scaled accumulators
+    nm_f32x16 hi00, hi01, hi10, hi11, lo00, lo01, lo10, lo11;
+};
+
+// K loop of one layer, fully unrolled for a compile-time number of k-steps.
+// The weights come straight from L2 (each wave owns 64 of the 256 output columns, nothing is shared
+// inside the workgroup), ~700 cycles away, while one k-step is 12 MFMAs = 384 matrix-pipe cycles:
+// the B fragments are fetched TWO steps ahead (three rotating register sets; the first two steps
+// arrive in pre0/pre1, requested before the previous epilogue), the A fragments (LDS) one step.
+// Straight-line code on purpose: in a rolled loop the compiler drains ALL outstanding loads once
+// per iteration (s_waitcnt vmcnt(0) for the loop-carried ones) and, left alone, its scheduler sinks
+// the prefetches down to their first use; unrolled, each step waits for exactly its own fragment
+// (vmcnt(8)), and the sched_barriers pin the issue points.
+template <int KS>
+__device__ __forceinline__ void nm_kloop_h(const _Float16* a0p, const _Float16* a1p, const nm_h8* b0p, const nm_h8* b1p,
+                                           const NmBFrag& pre0, const NmBFrag& pre1, NmAccH& c) {
+    NmBFrag f[3];
+    f[0] = pre0;
+    f[1] = pre1;
+    nm_h8 a[2][4];
+    a[0][0] = *reinterpret_cast<const nm_h8*>(a0p);
+    a[0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
+    a[0][2] = *reinterpret_cast<const nm_h8*>(a1p);
+    a[0][3] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 2 < KS) f[(ks + 2) % 3] = nm_ld_b(b0p, b1p, ks + 2);
+        if (ks + 1 < KS) {
+            const int oa = (ks + 1) * 16;
+            a[(ks + 1) & 1][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
+            a[(ks + 1) & 1][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
+            a[(ks + 1) & 1][2] = *reinterpret_cast<const nm_h8*>(a1p + oa);
+            a[(ks + 1) & 1][3] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE + oa);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const NmBFrag& F = f[ks % 3];
+        const nm_h8 a0a = a[ks & 1][0], a0b = a[ks & 1][1], a1a = a[ks & 1][2], a1b = a[ks & 1][3];
+        c.hi00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b0a, c.hi00, 0, 0, 0);
+        c.hi01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b1a, c.hi01, 0, 0, 0);
+        c.hi10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b0a, c.hi10, 0, 0, 0);
+        c.hi11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b1a, c.hi11, 0, 0, 0);
+        c.lo00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b0b, c.lo00, 0, 0, 0);
+        c.lo01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b1b, c.lo01, 0, 0, 0);
+        c.lo10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b0b, c.lo10, 0, 0, 0);
+        c.lo11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b1b, c.lo11, 0, 0, 0);
+        c.lo00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0b, F.b0a, c.lo00, 0, 0, 0);
+        c.lo01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0b, F.b1a, c.lo01, 0, 0, 0);
+        c.lo10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1b, F.b0a, c.lo10, 0, 0, 0);
+        c.lo11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1b, F.b1a, c.lo11, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// any other layer width: rolled loop, fragments one step ahead
+__device__ __forceinline__ void nm_kloop_h_generic(int KS, const _Float16* a0p, const _Float16* a1p, const nm_h8* b0p,
+                                                   const nm_h8* b1p, const NmBFrag& pre0, NmAccH& c) {
+    NmBFrag nf = pre0;
     nm_h8 na0a = *reinterpret_cast<const nm_h8*>(a0p), na0b = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
     nm_h8 na1a = *reinterpret_cast<const nm_h8*>(a1p), na1b = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE);
     for (int ks = 0; ks < KS; ++ks) {
-        const nm_h8 b0a = nb0a, b0b = nb0b, b1a = nb1a, b1b = nb1b;
+        const NmBFrag F = nf;
         const nm_h8 a0a = na0a, a0b = na0b, a1a = na1a, a1b = na1b;
         if (ks + 1 < KS) {
-            const int o = (ks + 1) * 128;
-            nb0a = b0p[o];
-            nb0b = b0p[o + 64];
-            nb1a = b1p[o];
-            nb1b = b1p[o + 64];
+            nf = nm_ld_b(b0p, b1p, ks + 1);
             const int oa = (ks + 1) * 16;
             na0a = *reinterpret_cast<const nm_h8*>(a0p + oa);
             na0b = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
             na1a = *reinterpret_cast<const nm_h8*>(a1p + oa);
             na1b = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE + oa);
         }
-        hi00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, b0a, hi00, 0, 0, 0);
-        hi01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, b1a, hi01, 0, 0, 0);
-        hi10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, b0a, hi10, 0, 0, 0);
-        hi11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, b1a, hi11, 0, 0, 0);
-        lo00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, b0b, lo00, 0, 0, 0);
-        lo01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, b1b, lo01, 0, 0, 0);
-        lo10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, b0b, lo10, 0, 0, 0);
-        lo11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, b1b, lo11, 0, 0, 0);
-        lo00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0b, b0a, lo00, 0, 0, 0);
-        lo01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0b, b1a, lo01, 0, 0, 0);
-        lo10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1b, b0a, lo10, 0, 0, 0);
-        lo11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1b, b1a, lo11, 0, 0, 0);
+        c.hi00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b0a, c.hi00, 0, 0, 0);
+        c.hi01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b1a, c.hi01, 0, 0, 0);
+        c.hi10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b0a, c.hi10, 0, 0, 0);
+        c.hi11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b1a, c.hi11, 0, 0, 0);
+        c.lo00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b0b, c.lo00, 0, 0, 0);
+        c.lo01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b1b, c.lo01, 0, 0, 0);
+        c.lo10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b0b, c.lo10, 0, 0, 0);
+        c.lo11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b1b, c.lo11, 0, 0, 0);
+        c.lo00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0b, F.b0a, c.lo00, 0, 0, 0);
+        c.lo01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0b, F.b1a, c.lo01, 0, 0, 0);
+        c.lo10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1b, F.b0a, c.lo10, 0, 0, 0);
+        c.lo11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1b, F.b1a, c.lo11, 0, 0, 0);
     }
+}
+
+// One dense layer on the split-half LDS tile (in place), see the header comment.
+// pre0/pre1: B fragments of this layer's first two k-steps on entry, of the next layer's on exit
+// (requested before the epilogue so that they arrive while it runs).
+template <int ACT, bool TANGENT>
+__device__ __forceinline__ void nm_mlp_layer_h(_Float16* tile, const NmLayerH L, const bool has_next, const NmLayerH next,
+                                               NmBFrag& pre0, NmBFrag& pre1, int stamp_slot) {
+    const float* __restrict__ bias = L.b;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int n0 = wave * 64;
+    const int KS = L.Kpad >> 4;
+    const _Float16* a0p = tile + li * NM_H_STRIDE + 8 * h;
+    const _Float16* a1p = tile + (32 + li) * NM_H_STRIDE + 8 * h;
+    const nm_h8* b0p = nm_b_base(L.W, L.Kpad, wave * 2);
+    const nm_h8* b1p = nm_b_base(L.W, L.Kpad, wave * 2 + 1);
+    NmAccH c;
+    c.hi00 = c.hi01 = c.hi10 = c.hi11 = c.lo00 = c.lo01 = c.lo10 = c.lo11 = nm_f32x16{0};
+    switch (KS) {  // the widths of the reference configuration get the unrolled form
+        case 16: nm_kloop_h<16>(a0p, a1p, b0p, b1p, pre0, pre1, c); break;  // hidden layers (W = 256)
+        case 12: nm_kloop_h<12>(a0p, a1p, b0p, b1p, pre0, pre1, c); break;  // geometry input 177 -> 192
+        case 13: nm_kloop_h<13>(a0p, a1p, b0p, b1p, pre0, pre1, c); break;  // colour input 207 -> 208
+        default: nm_kloop_h_generic(KS, a0p, a1p, b0p, b1p, pre0, c); break;
+    }
+    const nm_f32x16 &hi00 = c.hi00, &hi01 = c.hi01, &hi10 = c.hi10, &hi11 = c.hi11;
+    const nm_f32x16 &lo00 = c.lo00, &lo01 = c.lo01, &lo10 = c.lo10, &lo11 = c.lo11;
+    if (has_next) nm_prefetch_b(next, pre0, pre1);
     __syncthreads();  // every wave has finished reading the input tile
     nm_phase_stamp(stamp_slot);
     const float bias0 = bias[n0 + li], bias1 = bias[n0 + 32 + li];
@@ -172,7 +268,10 @@ __device__ __forceinline__ void nm_mlp_layer_h(_Float16* tile, const _Float16* _
     nm_phase_stamp(stamp_slot + 1);
 }
 
-// x and its sin/cos bands for 4 consecutive feature dims, written split into the tile row
+// x and its sin/cos bands for 4 consecutive feature dims, written split into the tile row.
+// Odd bands come from the even band below them by the double-angle identities (3 operations
+// instead of a ~28-operation sincos): sin 2t = 2 s c, cos 2t = (c - s)(c + s); measured error
+// <= 3e-7 absolute (direct evaluation: 7e-8), inside this mode's accuracy class (header comment).
 __device__ __forceinline__ void nm_embed4_h(_Float16* tile, int row, int col0, int dim, int bands, int chunk, float4 x) {
     const float xs[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
@@ -180,12 +279,16 @@ __device__ __forceinline__ void nm_embed4_h(_Float16* tile, int row, int col0, i
         const int c = 4 * chunk + e;
         nm_store_split(tile, row, col0 + c, xs[e]);
         float f = 1.0f;
-        for (int b = 0; b < bands; ++b) {
+        for (int b = 0; b < bands; b += 2) {
             float s, co;
             nm_sincos(xs[e] * f, &s, &co);
             nm_store_split(tile, row, col0 + dim * (1 + 2 * b) + c, s);
             nm_store_split(tile, row, col0 + dim * (2 + 2 * b) + c, co);
-            f *= 2.0f;
+            if (b + 1 < bands) {
+                nm_store_split(tile, row, col0 + dim * (3 + 2 * b) + c, 2.0f * s * co);
+                nm_store_split(tile, row, col0 + dim * (4 + 2 * b) + c, (co - s) * (co + s));
+            }
+            f *= 4.0f;
         }
     }
 }
@@ -196,11 +299,13 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_h_kernel(NmGeoParamsH prm, 
                                                               const float* __restrict__ ds, const float* __restrict__ grad,
                                                               NmRecMap rmap, long long npts, float* __restrict__ sdf_out, int P,
                                                               int stride, int off, float* __restrict__ nabla_out) {
-    __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE + 2 * NM_ROWS];
+    __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE + 2 * NM_ROWS + NM_EXP_LDS_PAD];
     float* red = reinterpret_cast<float*>(tile + 2 * NM_H_PLANE);
     constexpr int PTS = NABLA ? 32 : 64;
     const long long base = (long long)blockIdx.x * PTS;
     nm_phase_stamp(0);
+    NmBFrag pre0, pre1;
+    nm_prefetch_b(prm.layer[0], pre0, pre1);  // in flight during the input phase
     const int Kpad0 = prm.layer[0].Kpad;
     for (int task = threadIdx.x; task < PTS * 8; task += 256) {
         const int p = task >> 3, j = task & 7;
@@ -249,14 +354,18 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_h_kernel(NmGeoParamsH prm, 
     }
     __syncthreads();
     nm_phase_stamp(1);
-    for (int l = 0; l < prm.D; ++l) {
-        const NmLayerH L = prm.layer[l];
-        nm_mlp_layer_h<0, NABLA>(tile, L.W, L.b, L.Kpad, 2 + 2 * l);
-    }
+    for (int l = 0; l < prm.D; ++l)  // (kernel-argument loads with a uniform index: scalar)
+        nm_mlp_layer_h<0, NABLA>(tile, prm.layer[l], l + 1 < prm.D, prm.layer[l + 1 < prm.D ? l + 1 : l], pre0, pre1, 2 + 2 * l);
     {
         const int row = threadIdx.x >> 2, q4 = threadIdx.x & 3;
         float s = 0.f;
-        for (int m = 0; m < 64; ++m) s = fmaf(nm_load_split(tile, row, q4 + 4 * m), prm.wd[q4 + 4 * m], s);
+        for (int m = 0; m < 8; ++m) {  // columns 8*(q4 + 4*m) .. +8: 16-byte LDS reads, 4 lanes cover 64 B
+            const int c0 = 8 * (q4 + 4 * m);
+            const nm_h8 v1 = *reinterpret_cast<const nm_h8*>(tile + row * NM_H_STRIDE + c0);
+            const nm_h8 v2 = *reinterpret_cast<const nm_h8*>(tile + NM_H_PLANE + row * NM_H_STRIDE + c0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(fmaf((float)v2[e], 1.0f / 2048.0f, (float)v1[e]), prm.wd[c0 + e], s);
+        }
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         if (q4 == 0) red[row] = s;
@@ -284,10 +393,12 @@ __global__ __launch_bounds__(256, 2) void nm_col_mlp_h_kernel(NmColParamsH prm, 
                                                               const float* __restrict__ ds, const float* __restrict__ nabla,
                                                               const float* __restrict__ dirs, int dir_div, long long npts,
                                                               float* __restrict__ rgb_out) {
-    __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE + 6 * NM_ROWS];
+    __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE + 6 * NM_ROWS + NM_EXP_LDS_PAD];
     float* red = reinterpret_cast<float*>(tile + 2 * NM_H_PLANE);
     const long long base = (long long)blockIdx.x * NM_ROWS;
     nm_phase_stamp(0);
+    NmBFrag pre0, pre1;
+    nm_prefetch_b(prm.layer[0], pre0, pre1);  // in flight during the input phase
     const int Kpad0 = prm.layer[0].Kpad;
     const int o_d = prm.use_nabla ? 3 : 0;
     const int o_v = o_d + prm.d_emb;
@@ -343,18 +454,22 @@ __global__ __launch_bounds__(256, 2) void nm_col_mlp_h_kernel(NmColParamsH prm, 
     }
     __syncthreads();
     nm_phase_stamp(1);
-    for (int l = 0; l < prm.D; ++l) {
-        const NmLayerH L = prm.layer[l];
-        nm_mlp_layer_h<1, false>(tile, L.W, L.b, L.Kpad, 2 + 2 * l);
-    }
+    for (int l = 0; l < prm.D; ++l)
+        nm_mlp_layer_h<1, false>(tile, prm.layer[l], l + 1 < prm.D, prm.layer[l + 1 < prm.D ? l + 1 : l], pre0, pre1, 2 + 2 * l);
     {
         const int row = threadIdx.x >> 2, q4 = threadIdx.x & 3;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int m = 0; m < 64; ++m) {
-            const float av = nm_load_split(tile, row, q4 + 4 * m);
-            s0 = fmaf(av, prm.wrgb[q4 + 4 * m], s0);
-            s1 = fmaf(av, prm.wrgb[256 + q4 + 4 * m], s1);
-            s2 = fmaf(av, prm.wrgb[512 + q4 + 4 * m], s2);
+        for (int m = 0; m < 8; ++m) {
+            const int c0 = 8 * (q4 + 4 * m);
+            const nm_h8 v1 = *reinterpret_cast<const nm_h8*>(tile + row * NM_H_STRIDE + c0);
+            const nm_h8 v2 = *reinterpret_cast<const nm_h8*>(tile + NM_H_PLANE + row * NM_H_STRIDE + c0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float av = fmaf((float)v2[e], 1.0f / 2048.0f, (float)v1[e]);
+                s0 = fmaf(av, prm.wrgb[c0 + e], s0);
+                s1 = fmaf(av, prm.wrgb[256 + c0 + e], s1);
+                s2 = fmaf(av, prm.wrgb[512 + c0 + e], s2);
+            }
         }
         s0 += __shfl_xor(s0, 1); s0 += __shfl_xor(s0, 2);
         s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
