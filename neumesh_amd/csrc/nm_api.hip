@@ -476,6 +476,20 @@ int nm_field_color(nm_field_t f, const float* color_features, const float* ds, c
 }
 
 // ============================================================================== renderer
+// the per-ray kernels keep 64 rays' rows in dynamic LDS (nm_ray_lds_bytes(cap) > 64 KiB for cap >= 110)
+static int nm_ray_lds_prepare(int cap, size_t* bytes) {
+    *bytes = nm_ray_lds_bytes(cap);
+    if (cap > NM_MAX_SAMPLES) return nm_fail("per-ray stages: %d samples per ray (limit %d)", cap, NM_MAX_SAMPLES);
+    if (*bytes > 160 * 1024) return nm_fail("per-ray stages: %d samples per ray need %zu bytes of LDS (limit 160 KiB)", cap, *bytes);
+    static size_t granted = 0;
+    if (*bytes > granted) {
+        NM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nm_rays_upsample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)*bytes));
+        NM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nm_rays_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)*bytes));
+        granted = *bytes;
+    }
+    return 0;
+}
+
 struct NmWorkspace {
     float *dirn, *nf0, *nf, *d, *sdf, *dmid, *probe;
     float *rgb_mid, *nab_pts, *nab_mid;
@@ -597,10 +611,12 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     }
     // hierarchical up-sampling (renderer.py:208-258)
     int n = c->N_samples, pending = 0;
+    size_t ray_lds = 0;
+    if (nm_ray_lds_prepare(cap, &ray_lds)) return 1;
     if (c->N_importance > 0) {
         const int n_new = c->N_importance / c->N_upsample_iters;
         for (int it = 0; it < c->N_upsample_iters; ++it) {
-            hipLaunchKernelGGL(nm_rays_upsample_kernel, rgrid, rblock, 0, stream, ws.d, ws.sdf, ws.slot, ws.radius, ws.bound, (long long)R, cap, n, pending, it, n_new);
+            hipLaunchKernelGGL(nm_rays_upsample_kernel, rgrid, rblock, ray_lds, stream, ws.d, ws.sdf, ws.slot, ws.radius, ws.bound, (long long)R, cap, n, pending, it, n_new);
             NM_LAUNCH_CHECK();
             src.mode = 1;
             src.P = n_new;
@@ -625,7 +641,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
             pending = n_new;
         }
     }
-    hipLaunchKernelGGL(nm_rays_finalize_kernel, rgrid, rblock, 0, stream, ws.d, ws.sdf, ws.slot, ws.radius, (long long)R, cap, n, pending, ws.dmid, ws.bound_mid);
+    hipLaunchKernelGGL(nm_rays_finalize_kernel, rgrid, rblock, ray_lds, stream, ws.d, ws.sdf, ws.slot, ws.radius, (long long)R, cap, n, pending, ws.dmid, ws.bound_mid);
     NM_LAUNCH_CHECK();
     // SDF (+ nablas) at all N sample points (renderer.py:264, 271-276): no new search.  Without
     // normals the SDF values merged above ARE forward_density_only(pts) (same points, same kernel).
@@ -704,7 +720,9 @@ int nm_rays_bounds(const float* ds_probe, int64_t R, int G, float thresh, const 
 int nm_rays_upsample(float* d, float* sdf, int64_t R, int cap, int n, int m, int it, int n_new, nm_stream_t stream_) {
     if (R < 0 || n < 2 || m < 0 || m > n || n + n_new > cap || cap > NM_MAX_SAMPLES || it < 0 || it > 20 || (R > 0 && (!d || !sdf))) return nm_fail("nm_rays_upsample: bad arguments");
     if (R == 0) return 0;
-    hipLaunchKernelGGL(nm_rays_upsample_kernel, dim3(nm_blocks(R, 64)), dim3(64), 0, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (float*)nullptr, (long long)R, cap, n, m, it, n_new);
+    size_t ray_lds = 0;
+    if (nm_ray_lds_prepare(cap, &ray_lds)) return 1;
+    hipLaunchKernelGGL(nm_rays_upsample_kernel, dim3(nm_blocks(R, 64)), dim3(64), ray_lds, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (float*)nullptr, (long long)R, cap, n, m, it, n_new);
     NM_LAUNCH_CHECK();
     return 0;
 }
@@ -712,7 +730,9 @@ int nm_rays_upsample(float* d, float* sdf, int64_t R, int cap, int n, int m, int
 int nm_rays_finalize(float* d, float* sdf, int64_t R, int cap, int n, int m, float* d_mid, nm_stream_t stream_) {
     if (R < 0 || n < 2 || n > cap || m < 0 || m > n || (R > 0 && (!d || !sdf || !d_mid))) return nm_fail("nm_rays_finalize: bad arguments");
     if (R == 0) return 0;
-    hipLaunchKernelGGL(nm_rays_finalize_kernel, dim3(nm_blocks(R, 64)), dim3(64), 0, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (long long)R, cap, n, m, d_mid, (float*)nullptr);
+    size_t ray_lds = 0;
+    if (nm_ray_lds_prepare(cap, &ray_lds)) return 1;
+    hipLaunchKernelGGL(nm_rays_finalize_kernel, dim3(nm_blocks(R, 64)), dim3(64), ray_lds, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (long long)R, cap, n, m, d_mid, (float*)nullptr);
     NM_LAUNCH_CHECK();
     return 0;
 }

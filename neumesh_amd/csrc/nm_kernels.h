@@ -33,30 +33,27 @@ struct NmPointSrc {
     const unsigned short* order;
 };
 
-__device__ __forceinline__ long long nm_out_index(const NmPointSrc& s, long long q) {
+// (r, p) = (ray, sample) of query q = r*P + p, as produced by nm_lane_query (mode 0: r = q, p = 0)
+__device__ __forceinline__ long long nm_out_index(const NmPointSrc& s, long long q, long long r, int p) {
     if (s.mode == 0 || s.out_stride == 0) return q;
-    const long long r = q / s.P;
-    return r * s.out_stride + s.out_off + (q - r * s.P);
+    return r * s.out_stride + s.out_off + p;
 }
 
 // squared warm-start bound of point q (+INF when there is none); inflated so that it stays an
 // upper bound under fp32 rounding of the positions and of the candidate distances
-__device__ __forceinline__ float nm_init_bound(const NmPointSrc& s, long long q) {
+__device__ __forceinline__ float nm_init_bound(const NmPointSrc& s, long long r, int p) {
     if (s.mode == 0 || !s.bound) return NM_INF_F;
-    const long long r = q / s.P;
-    const float b = s.bound[r * s.dstride + s.doff + (q - r * s.P)] * 1.0001f + 1e-5f;
+    const float b = s.bound[r * s.dstride + s.doff + p] * 1.0001f + 1e-5f;
     return b * b;
 }
 
-__device__ __forceinline__ void nm_fetch_point(const NmPointSrc& s, long long q, float& x, float& y, float& z) {
+__device__ __forceinline__ void nm_fetch_point(const NmPointSrc& s, long long r, int p, float& x, float& y, float& z) {
     if (s.mode == 0) {
-        x = s.xyz[q * 3];
-        y = s.xyz[q * 3 + 1];
-        z = s.xyz[q * 3 + 2];
+        x = s.xyz[r * 3];
+        y = s.xyz[r * 3 + 1];
+        z = s.xyz[r * 3 + 2];
         return;
     }
-    const long long r = q / s.P;
-    const int p = (int)(q - r * s.P);
     float d;
     if (s.mode == 1) {
         d = s.depth[r * s.dstride + s.doff + p];
@@ -193,27 +190,29 @@ __device__ __forceinline__ void nm_knn_wave(const NmGridView& g, float qx, float
 // 16 adjacent rays x 4 consecutive samples (the most compact 64-query footprint, see above);
 // importance samples, which are not regular in depth, go by depth buckets over 64 adjacent rays
 // (s.order); point-wise launches (mode 0) take 64 consecutive points.
-__device__ __forceinline__ bool nm_lane_query(const NmPointSrc& s, long long Q, long long& q) {
+__device__ __forceinline__ bool nm_lane_query(const NmPointSrc& s, long long Q, long long& q, long long& r, int& p) {
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (s.mode == 0) {
-        q = wave * 64 + lane;
+        q = r = wave * 64 + lane;
+        p = 0;
         return q < Q;
     }
-    const long long R = Q / s.P;
+    const long long R = Q / s.P;  // uniform
     if (s.order) {
         const long long grp = wave / s.P;
-        if (grp * 64 >= R) { q = 0; return false; }
-        const int id = (int)s.order[wave * 64 + lane];  // wave*64 == grp*64*P + (wave - grp*P)*64
-        const int rl = id / s.P;
-        const long long r = grp * 64 + rl;
-        q = r * s.P + (id - rl * s.P);
-        return rl < 64 && r < R;
+        if (grp * 64 >= R) { q = r = 0; p = 0; return false; }
+        const unsigned id = s.order[wave * 64 + lane];  // wave*64 == grp*64*P + (wave - grp*P)*64
+        const unsigned rl = id / (unsigned)s.P;
+        r = grp * 64 + rl;
+        p = (int)(id - rl * (unsigned)s.P);
+        q = r * s.P + p;
+        return rl < 64u && r < R;
     }
     const long long tiles_p = (s.P + 3) >> 2;
     const long long rb = wave / tiles_p, sb = wave - rb * tiles_p;
-    const long long r = rb * 16 + (lane >> 2);
-    const int p = (int)(sb * 4) + (lane & 3);
+    r = rb * 16 + (lane >> 2);
+    p = (int)(sb * 4) + (lane & 3);
     q = r * s.P + p;
     return r < R && p < s.P;
 }
@@ -284,10 +283,11 @@ __global__ __launch_bounds__(256) void nm_interp_kernel(const float* __restrict_
 template <int K>
 __global__ __launch_bounds__(256) void nm_knn_kernel(NmGridView g, NmPointSrc src, long long Q, int Kout,
                                                      long long* __restrict__ idx_out, float* __restrict__ d2_out) {
-    long long q;
-    const bool active = nm_lane_query(src, Q, q);
+    long long q, r;
+    int p;
+    const bool active = nm_lane_query(src, Q, q, r, p);
     float x = 0.f, y = 0.f, z = 0.f;
-    if (active) nm_fetch_point(src, q, x, y, z);
+    if (active) nm_fetch_point(src, r, p, x, y, z);
     unsigned long long kk[K];
     nm_knn_wave<K>(g, x, y, z, active, kk);
     if (!active) return;
@@ -314,12 +314,13 @@ __global__ __launch_bounds__(256) void nm_distance_kernel(NmGridView g, NmPointS
                                                           float* __restrict__ radius_out,
                                                           const float* __restrict__ geo_table, int gdim, float* __restrict__ fg_out,
                                                           const float* __restrict__ col_table, int cdim, float* __restrict__ ft_out) {
-    long long q;
-    const bool active = nm_lane_query(src, Q, q);
+    long long q, r;
+    int p;
+    const bool active = nm_lane_query(src, Q, q, r, p);
     float x = 0.f, y = 0.f, z = 0.f, init = NM_INF_F;
     if (active) {
-        nm_fetch_point(src, q, x, y, z);
-        init = nm_init_bound(src, q);
+        nm_fetch_point(src, r, p, x, y, z);
+        init = nm_init_bound(src, r, p);
     }
     float bd[8], wk[8], gr[3];
     int bi[8];
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(256) void nm_distance_kernel(NmGridView g, NmPointS
     long long o = 0;
     if (active) {
         ds = nm_projected_distance8(x, y, z, bd, bi, verts, indicator, w1, wk, grad_out ? gr : nullptr);
-        o = nm_out_index(src, q);
+        o = nm_out_index(src, q, r, p);
     } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -391,21 +392,116 @@ __global__ void nm_rays_bypass_kernel(long long R, float near_bypass, float far_
     if (far_bypass >= 0.f) nearfar[2 * r + 1] = far_bypass;
 }
 
+// Per-ray rows in LDS.  The up-sampling stages are serial per ray (ordered float64 scans, a data-
+// dependent insertion sort), one lane owns one ray -- run directly on the [R][cap] global arrays
+// every step of those loops is a dependent, uncoalesced global access (measured: 1.5-2.8 ms per
+// launch of 65536 rays).  So a 64-ray workgroup first copies its rows into LDS with coalesced
+// loads (row stride cap+1 words: lane-private rows fall into distinct banks), runs the unchanged
+// serial code there, and copies the results back.  Slots are bytes in LDS (cap <= 256).
+struct NmRayLds {
+    float* d;             // [64][cap + 1]
+    float* s;             // [64][cap + 1]  sdf, then weights / cdf (nm_ray_upsample aliases them)
+    unsigned char* slot;  // [64][cap + 4]
+    int S, SB;
+};
+__device__ __forceinline__ NmRayLds nm_ray_lds(float* base, int cap) {
+    NmRayLds l;
+    l.S = cap + 1;
+    l.SB = cap + 4;
+    l.d = base;
+    l.s = base + 64 * l.S;
+    l.slot = reinterpret_cast<unsigned char*>(base + 2 * 64 * l.S);
+    return l;
+}
+static inline size_t nm_ray_lds_bytes(int cap) { return (size_t)2 * 64 * (cap + 1) * 4 + (size_t)64 * (cap + 4); }
+
+// rows [0, n) of 64 rays: global -> LDS (slot == nullptr or first == true: identity slots)
+__device__ __forceinline__ void nm_ray_rows_load(const NmRayLds& l, const float* __restrict__ d, const float* __restrict__ sdf,
+                                                 const int* __restrict__ slot, bool identity, long long r0, long long R,
+                                                 int cap, int n) {
+    const int lane = threadIdx.x;
+    for (int rr = 0; rr < 64 && r0 + rr < R; ++rr) {
+        const long long g = (r0 + rr) * cap;
+        for (int j = lane; j < n; j += 64) {
+            l.d[rr * l.S + j] = d[g + j];
+            l.s[rr * l.S + j] = sdf[g + j];
+            if (slot) l.slot[rr * l.SB + j] = identity ? (unsigned char)j : (unsigned char)slot[g + j];
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void nm_ray_rows_store(const NmRayLds& l, float* __restrict__ d, float* __restrict__ sdf,
+                                                  int* __restrict__ slot, long long r0, long long R, int cap, int j0, int j1,
+                                                  bool with_sdf) {
+    const int lane = threadIdx.x;
+    __syncthreads();
+    for (int rr = 0; rr < 64 && r0 + rr < R; ++rr) {
+        const long long g = (r0 + rr) * cap;
+        for (int j = j0 + lane; j < j1; j += 64) {
+            d[g + j] = l.d[rr * l.S + j];
+            if (with_sdf) {
+                sdf[g + j] = l.s[rr * l.S + j];
+                if (slot) slot[g + j] = (int)l.slot[rr * l.SB + j];
+            }
+        }
+    }
+}
+
 // merge the m samples appended by the previous iteration, then draw n_new new ones (+ their
-// warm-start bounds from the cached K-th-neighbour radius of the neighbouring samples)
-__global__ void nm_rays_upsample_kernel(float* __restrict__ d, float* __restrict__ sdf, int* __restrict__ slot,
-                                        const float* __restrict__ radius, float* __restrict__ bound, long long R,
-                                        int cap, int n, int m, int it, int n_new) {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    float* dr = d + r * cap;
-    float* sr = sdf + r * cap;
-    int* sl = slot ? slot + r * cap : nullptr;
-    if (m > 0) nm_ray_merge(dr, sr, n - m, m, sl);
-    else if (sl) for (int j = 0; j < n; ++j) sl[j] = j;
-    float w[NM_MAX_SAMPLES], cdf[NM_MAX_SAMPLES];
-    nm_ray_upsample(dr, sr, n, it, n_new, dr + n, w, cdf, sl, (sl && radius) ? radius + r * cap : nullptr,
-                    bound ? bound + r * cap + n : nullptr);
+// warm-start bounds from the cached K-th-neighbour radius of the neighbouring samples).
+// Launch: 64 threads per block, nm_ray_lds_bytes(cap) dynamic LDS.
+__global__ __launch_bounds__(64) void nm_rays_upsample_kernel(float* __restrict__ d, float* __restrict__ sdf, int* __restrict__ slot,
+                                                              const float* __restrict__ radius, float* __restrict__ bound, long long R,
+                                                              int cap, int n, int m, int it, int n_new) {
+    extern __shared__ float nm_ray_smem[];
+    const NmRayLds l = nm_ray_lds(nm_ray_smem, cap);
+    const long long r0 = (long long)blockIdx.x * 64;
+    const long long r = r0 + threadIdx.x;
+    nm_ray_rows_load(l, d, sdf, slot, m == 0, r0, R, cap, n);
+    float* dr = l.d + threadIdx.x * l.S;
+    float* sr = l.s + threadIdx.x * l.S;
+    unsigned char* sl = slot ? l.slot + threadIdx.x * l.SB : nullptr;
+    if (r < R && m > 0) nm_ray_merge(dr, sr, n - m, m, sl);
+    if (m > 0 || slot) nm_ray_rows_store(l, d, sdf, slot, r0, R, cap, 0, n, true);  // merged rows (+ identity slots)
+    __syncthreads();
+    if (r < R)
+        nm_ray_upsample(dr, sr, n, it, n_new, dr + n, sr, sr, sl, (sl && radius) ? radius + r * cap : nullptr,
+                        bound ? bound + r * cap + n : nullptr);
+    nm_ray_rows_store(l, d, sdf, nullptr, r0, R, cap, n, n + n_new, false);  // the new depths
+}
+
+// final merge + mid-point depths (renderer.py:255-258, :266) + warm-start bounds of the mid-points
+__global__ __launch_bounds__(64) void nm_rays_finalize_kernel(float* __restrict__ d, float* __restrict__ sdf, int* __restrict__ slot,
+                                                              const float* __restrict__ radius, long long R, int cap, int n, int m,
+                                                              float* __restrict__ d_mid, float* __restrict__ bound_mid) {
+    extern __shared__ float nm_ray_smem[];
+    const NmRayLds l = nm_ray_lds(nm_ray_smem, cap);
+    const long long r0 = (long long)blockIdx.x * 64;
+    const long long r = r0 + threadIdx.x;
+    nm_ray_rows_load(l, d, sdf, slot, m == 0, r0, R, cap, n);
+    unsigned char* sl = slot ? l.slot + threadIdx.x * l.SB : nullptr;
+    if (r < R && m > 0) nm_ray_merge(l.d + threadIdx.x * l.S, l.s + threadIdx.x * l.S, n - m, m, sl);
+    if (m > 0 || slot) nm_ray_rows_store(l, d, sdf, slot, r0, R, cap, 0, n, true);
+    __syncthreads();
+    // the sdf rows are no longer needed in LDS: reuse them for the radius rows (coalesced loads)
+    const bool warm = slot && radius && bound_mid;
+    const int lane = threadIdx.x;
+    if (warm) {
+        for (int rr = 0; rr < 64 && r0 + rr < R; ++rr)
+            for (int j = lane; j < n; j += 64) l.s[rr * l.S + j] = radius[(r0 + rr) * cap + j];
+        __syncthreads();
+    }
+    for (int rr = 0; rr < 64 && r0 + rr < R; ++rr) {
+        const float* dr = l.d + rr * l.S;
+        const float* rad = l.s + rr * l.S;
+        const unsigned char* sr = l.slot + rr * l.SB;
+        const long long g = (r0 + rr) * cap;
+        for (int j = lane; j + 1 < n; j += 64) {
+            const float dm = nm_mul(0.5f, nm_add(dr[j + 1], dr[j]));
+            d_mid[g + j] = dm;
+            if (warm) bound_mid[g + j] = fminf(rad[sr[j]] + fabsf(dm - dr[j]), rad[sr[j + 1]] + fabsf(dr[j + 1] - dm));
+        }
+    }
 }
 
 // Depth-bucket assignment of the importance samples to waves.  The P new samples of a ray follow
@@ -446,31 +542,14 @@ __global__ __launch_bounds__(256) void nm_rays_order_kernel(const float* __restr
     for (int i = threadIdx.x; i < n; i += 256) order[grp * n + i] = (unsigned short)(nm_sort_keys[i] & 0xffffu);
 }
 
-// final merge + mid-point depths (renderer.py:255-258, :266) + warm-start bounds of the mid-points
-__global__ void nm_rays_finalize_kernel(float* __restrict__ d, float* __restrict__ sdf, int* __restrict__ slot,
-                                        const float* __restrict__ radius, long long R, int cap, int n, int m,
-                                        float* __restrict__ d_mid, float* __restrict__ bound_mid) {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    float* dr = d + r * cap;
-    int* sl = slot ? slot + r * cap : nullptr;
-    if (m > 0) nm_ray_merge(dr, sdf + r * cap, n - m, m, sl);
-    else if (sl) for (int j = 0; j < n; ++j) sl[j] = j;
-    const float* rad = (sl && radius) ? radius + r * cap : nullptr;
-    for (int j = 0; j + 1 < n; ++j) {
-        const float dm = nm_mul(0.5f, nm_add(dr[j + 1], dr[j]));
-        d_mid[r * cap + j] = dm;
-        if (rad && bound_mid) bound_mid[r * cap + j] = fminf(rad[sl[j]] + fabsf(dm - dr[j]), rad[sl[j + 1]] + fabsf(dr[j + 1] - dm));
-    }
-}
-
 // sample points of a ray batch as an explicit [R,P,3] array (staged renderer: the field is queried
 // through the model's Python methods between the per-ray stages)
 __global__ void nm_rays_points_kernel(NmPointSrc src, long long Q, float* __restrict__ xyz) {
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q) return;
     float x, y, z;
-    nm_fetch_point(src, q, x, y, z);
+    const long long r = q / src.P;
+    nm_fetch_point(src, r, (int)(q - r * src.P), x, y, z);
     xyz[3 * q] = x;
     xyz[3 * q + 1] = y;
     xyz[3 * q + 2] = z;

@@ -64,6 +64,33 @@ __device__ __forceinline__ long long nm_rec_index(const NmRecMap& m, long long q
     return r * m.stride + (m.slot ? (long long)m.slot[r * m.stride + m.off + p] : m.off + p);
 }
 
+// (q / P, q % P) for q = base + local, local < 2^16: one 64-bit division per workgroup (base is
+// uniform), a 32-bit one per use -- the 64-bit software division costs ~120 instructions per lane.
+struct NmDivBase {
+    long long r0;
+    unsigned p0, P;
+};
+__device__ __forceinline__ NmDivBase nm_div_base(long long base, int P) {
+    NmDivBase d;
+    d.P = (unsigned)P;
+    d.r0 = base / P;
+    d.p0 = (unsigned)(base - d.r0 * P);
+    return d;
+}
+__device__ __forceinline__ void nm_div_local(const NmDivBase& d, int local, long long& r, int& p) {
+    const unsigned t = d.p0 + (unsigned)local;
+    const unsigned dr = t / d.P;
+    r = d.r0 + dr;
+    p = (int)(t - dr * d.P);
+}
+__device__ __forceinline__ long long nm_rec_index_local(const NmRecMap& m, const NmDivBase& d, long long base, int local) {
+    if (m.stride == 0) return base + local;
+    long long r;
+    int p;
+    nm_div_local(d, local, r, p);
+    return r * m.stride + (m.slot ? (long long)m.slot[r * m.stride + m.off + p] : m.off + p);
+}
+
 struct NmGeoParams {
     NmLayer layer[NM_MAX_LAYERS];
     int D;
@@ -296,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, con
     float* red = act + NM_ROWS * NM_LDS_STRIDE;
     constexpr int PTS = NABLA ? 32 : 64;
     const long long base = (long long)blockIdx.x * PTS;
+    const NmDivBase rdiv = nm_div_base(base, rmap.stride ? rmap.P : 1), odiv = nm_div_base(base, P);
     nm_phase_stamp(0);
     const int Kpad0 = prm.layer[0].Kpad;
     const int t_hi = ((prm.d_emb + 15) >> 4) << 4;  // live tangent columns, rounded to 16
@@ -313,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, con
             continue;
         }
         for (int c = prm.in_dim + j; c < Kpad0; c += 8) row[c] = 0.f;
-        const long long rq = nm_rec_index(rmap, q);
+        const long long rq = nm_rec_index_local(rmap, rdiv, base, p);
         const float dsv = ds[rq];
         if (j == 0) {
             row[0] = dsv;
@@ -365,10 +393,15 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, con
         const long long q = base + threadIdx.x;
         if (q < npts) {
             const float sdf = red[threadIdx.x] + prm.bd;
-            if (sdf_out) sdf_out[(q / P) * stride + off + (q % P)] = sdf;
+            if (sdf_out) {
+                long long orow;
+                int op;
+                nm_div_local(odiv, (int)threadIdx.x, orow, op);
+                sdf_out[orow * stride + off + op] = sdf;
+            }
             if (NABLA && nabla_out) {
                 const float dsdf = red[32 + threadIdx.x];
-                const long long rq = nm_rec_index(rmap, q);
+                const long long rq = nm_rec_index_local(rmap, rdiv, base, (int)threadIdx.x);
                 nabla_out[q * 3 + 0] = dsdf * grad[rq * 3 + 0];
                 nabla_out[q * 3 + 1] = dsdf * grad[rq * 3 + 1];
                 nabla_out[q * 3 + 2] = dsdf * grad[rq * 3 + 2];
@@ -390,6 +423,7 @@ __global__ __launch_bounds__(256, 2) void nm_col_mlp_kernel(NmColParams prm, con
     __shared__ __attribute__((aligned(16))) float act[NM_ROWS * NM_LDS_STRIDE + 3 * NM_ROWS];
     float* red = act + NM_ROWS * NM_LDS_STRIDE;
     const long long base = (long long)blockIdx.x * NM_ROWS;
+    const NmDivBase ddiv = nm_div_base(base, dir_div);
     nm_phase_stamp(0);
     const int Kpad0 = prm.layer[0].Kpad;
     const int o_d = prm.use_nabla ? 3 : 0;             // start of embed_d
@@ -421,7 +455,10 @@ __global__ __launch_bounds__(256, 2) void nm_col_mlp_kernel(NmColParams prm, con
             row[o_d + 2 + 2 * b] = co;
         }
         {
-            const float* dv = dirs + (q / dir_div) * 3;
+            long long ray;
+            int unused_p;
+            nm_div_local(ddiv, p, ray, unused_p);
+            const float* dv = dirs + ray * 3;
             if (j == 1) {
                 row[o_v] = dv[0];
                 row[o_v + 1] = dv[1];

@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_h_kernel(NmGeoParamsH prm, 
     float* red = reinterpret_cast<float*>(tile + 2 * NM_H_PLANE);
     constexpr int PTS = NABLA ? 32 : 64;
     const long long base = (long long)blockIdx.x * PTS;
+    const NmDivBase rdiv = nm_div_base(base, rmap.stride ? rmap.P : 1), odiv = nm_div_base(base, P);
     nm_phase_stamp(0);
     NmBFrag pre0, pre1;
     nm_prefetch_b(prm.layer[0], pre0, pre1);  // in flight during the input phase
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_h_kernel(NmGeoParamsH prm, 
             tile[p * NM_H_STRIDE + c] = (_Float16)0.0f;
             tile[NM_H_PLANE + p * NM_H_STRIDE + c] = (_Float16)0.0f;
         }
-        const long long rq = nm_rec_index(rmap, q);
+        const long long rq = nm_rec_index_local(rmap, rdiv, base, p);
         const float dsv = ds[rq];
         if (j == 0) {
             nm_store_split(tile, p, 0, dsv);
@@ -375,10 +376,15 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_h_kernel(NmGeoParamsH prm, 
         const long long q = base + threadIdx.x;
         if (q < npts) {
             const float sdf = red[threadIdx.x] + prm.bd;
-            if (sdf_out) sdf_out[(q / P) * stride + off + (q % P)] = sdf;
+            if (sdf_out) {
+                long long orow;
+                int op;
+                nm_div_local(odiv, (int)threadIdx.x, orow, op);
+                sdf_out[orow * stride + off + op] = sdf;
+            }
             if (NABLA && nabla_out) {
                 const float dsdf = red[32 + threadIdx.x] * (1.0f / NM_TANGENT_SCALE);
-                const long long rq = nm_rec_index(rmap, q);
+                const long long rq = nm_rec_index_local(rmap, rdiv, base, (int)threadIdx.x);
                 nabla_out[q * 3 + 0] = dsdf * grad[rq * 3 + 0];
                 nabla_out[q * 3 + 1] = dsdf * grad[rq * 3 + 1];
                 nabla_out[q * 3 + 2] = dsdf * grad[rq * 3 + 2];
@@ -396,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void nm_col_mlp_h_kernel(NmColParamsH prm, 
     __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE + 6 * NM_ROWS + NM_EXP_LDS_PAD];
     float* red = reinterpret_cast<float*>(tile + 2 * NM_H_PLANE);
     const long long base = (long long)blockIdx.x * NM_ROWS;
+    const NmDivBase ddiv = nm_div_base(base, dir_div);
     nm_phase_stamp(0);
     NmBFrag pre0, pre1;
     nm_prefetch_b(prm.layer[0], pre0, pre1);  // in flight during the input phase
@@ -433,7 +440,10 @@ __global__ __launch_bounds__(256, 2) void nm_col_mlp_h_kernel(NmColParamsH prm, 
             nm_store_split(tile, p, o_d + 2 + 2 * b, co);
         }
         {
-            const float* dv = dirs + (q / dir_div) * 3;
+            long long ray;
+            int unused_p;
+            nm_div_local(ddiv, p, ray, unused_p);
+            const float* dv = dirs + ray * 3;
             if (j == 1) {
                 nm_store_split(tile, p, o_v, dv[0]);
                 nm_store_split(tile, p, o_v + 1, dv[1]);

@@ -89,22 +89,26 @@ NM_HD void nm_ray_bounds(const float* ds_probe, int stride, int G, float thresh,
 
 // One up-sampling iteration (renderer.py:209-245 + rend_util.py:276-319, det=True):
 // reads sorted d[0..n), sdf[0..n); writes n_new new depths to d_new[0..n_new).
-// w and cdf are caller-provided scratch of >= n floats.
+// w and cdf are caller-provided scratch of >= n floats; w may alias sdf and cdf may alias w (the
+// device kernel keeps a ray's arrays in LDS and reuses the sdf row for both).
 // If radius != nullptr: radius[slot] is the distance from an earlier sample (identified by
 // slot[j], the position it was generated at) to its K-th nearest vertex; bound_new[i] then receives
 // an upper bound of the K-th-neighbour distance of the i-th new sample: radius of the sample just
 // below it on the same ray + the depth gap (triangle inequality, the direction is a unit vector).
+template <class SlotT = int>
 NM_HD void nm_ray_upsample(const float* d, const float* sdf, int n, int it, int n_new, float* d_new,
-                           float* w, float* cdf, const int* slot = nullptr, const float* radius = nullptr,
+                           float* w, float* cdf, const SlotT* slot = nullptr, const float* radius = nullptr,
                            float* bound_new = nullptr) {
     const float s = (float)(256 << it);
     float prev_dot = 0.f;
     double T = 1.0;      // cumprod accumulator (float64, rounded to fp32 per element like torch CPU)
     double wsum = 0.0;
+    float d_j = d[0], s_j = sdf[0];
     for (int j = 0; j + 1 < n; ++j) {
-        const float dist = nm_sub(d[j + 1], d[j]);
-        const float mid = nm_mul(nm_add(sdf[j], sdf[j + 1]), 0.5f);
-        const float dot = nm_div(nm_sub(sdf[j + 1], sdf[j]), nm_add(dist, 1e-5f));
+        const float d_n = d[j + 1], s_n = sdf[j + 1];
+        const float dist = nm_sub(d_n, d_j);
+        const float mid = nm_mul(nm_add(s_j, s_n), 0.5f);
+        const float dot = nm_div(nm_sub(s_n, s_j), nm_add(dist, 1e-5f));
         float dv = fminf(prev_dot, dot);
         dv = fminf(fmaxf(dv, -10.0f), 0.0f);
         prev_dot = dot;
@@ -114,15 +118,20 @@ NM_HD void nm_ray_upsample(const float* d, const float* sdf, int n, int it, int 
         const float alpha = nm_div(nm_add(nm_sub(pc, nc), 1e-5f), nm_add(pc, 1e-5f));
         const float wj = nm_add(nm_mul(alpha, (float)T), 1e-5f);  // alpha_to_w, then sample_pdf's +1e-5
         T *= (double)nm_add(nm_sub(1.0f, alpha), 1e-10f);
-        w[j] = wj;
+        w[j] = wj;  // (sdf[j] is dead from here on)
         wsum += (double)wj;
+        d_j = d_n;
+        s_j = s_n;
     }
     const float sum = (float)wsum;
     double c = 0.0;
+    float w_j = n > 1 ? w[0] : 0.f;
     cdf[0] = 0.f;
     for (int j = 0; j + 1 < n; ++j) {
-        c += (double)nm_div(w[j], sum);
+        const float w_next = (j + 2 < n) ? w[j + 1] : 0.f;  // read before cdf[j + 1] may overwrite it
+        c += (double)nm_div(w_j, sum);
         cdf[j + 1] = (float)c;
+        w_j = w_next;
     }
     int lb = 0;  // searchsorted(cdf, u, right=False); u ascending => monotone lower bound
     for (int i = 0; i < n_new; ++i) {
@@ -136,8 +145,8 @@ NM_HD void nm_ray_upsample(const float* d, const float* sdf, int n, int it, int 
         const float dn = nm_add(d[below], nm_mul(t, nm_sub(d[above], d[below])));
         d_new[i] = dn;
         if (radius) {
-            const float rb = radius[slot[below]] + fabsf(dn - d[below]);
-            const float ra = radius[slot[above]] + fabsf(dn - d[above]);
+            const float rb = radius[(int)slot[below]] + fabsf(dn - d[below]);
+            const float ra = radius[(int)slot[above]] + fabsf(dn - d[above]);
             bound_new[i] = fminf(rb, ra);
         }
     }
@@ -148,7 +157,8 @@ NM_HD void nm_ray_upsample(const float* d, const float* sdf, int n, int it, int 
 // field is deterministic per point, so the tie order cannot change any value.
 // slot (optional): slot[j] = generation position of the sample now at sorted position j; the
 // tail elements enter with their own position as slot id.
-NM_HD void nm_ray_merge(float* d, float* sdf, int n, int m, int* slot = nullptr) {
+template <class SlotT = int>
+NM_HD void nm_ray_merge(float* d, float* sdf, int n, int m, SlotT* slot = nullptr) {
     for (int t = n; t < n + m; ++t) {
         const float dv = d[t], sv = sdf[t];
         int p = t;
@@ -160,7 +170,7 @@ NM_HD void nm_ray_merge(float* d, float* sdf, int n, int m, int* slot = nullptr)
         }
         d[p] = dv;
         sdf[p] = sv;
-        if (slot) slot[p] = t;
+        if (slot) slot[p] = (SlotT)t;
     }
 }
 
