@@ -399,8 +399,8 @@ static int nm_launch_geo(nm_field_t f, const float* fg, const float* ds, const f
     if (P <= 0) return 0;
     NmProfScope prof(nabla ? NM_K_GEO_NABLA : NM_K_GEO, P, stream);
     if (f->precision == 1) {
-        if (nabla) hipLaunchKernelGGL((nm_geo_mlp_h_kernel<true>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out);
-        else hipLaunchKernelGGL((nm_geo_mlp_h_kernel<false>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out);
+        if (nabla) hipLaunchKernelGGL((nm_geo_mlp_h_kernel<true>), dim3(nm_blocks(P, 32)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out);
+        else hipLaunchKernelGGL((nm_geo_mlp_h_kernel<false>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out);
         NM_LAUNCH_CHECK();
         return 0;
     }
@@ -420,7 +420,7 @@ static int nm_launch_col(nm_field_t f, const float* ft, const float* ds, const f
     if (P <= 0) return 0;
     NmProfScope prof(NM_K_COLOR, P, stream);
     if (f->precision == 1) {
-        hipLaunchKernelGGL(nm_col_mlp_h_kernel, dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->col_h, ft, ds, nabla, dirs, dir_div, P, rgb);
+        hipLaunchKernelGGL(nm_col_mlp_h_kernel, dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h, ft, ds, nabla, dirs, dir_div, P, rgb);
         NM_LAUNCH_CHECK();
         return 0;
     }

@@ -91,182 +91,189 @@ __global__ void nm_pack_weight_h_kernel(const float* __restrict__ src, int in_di
     dst[base + 64 * 8 + (size_t)lane * 8 + el] = h2;
 }
 
-// B operand (weights) of one k-step for the two column tiles of a wave: 4 x 16 bytes per lane.
+// Work split inside a workgroup (64 activation rows x 256 output columns per layer): a wave owns all
+// 64 rows of CT 32-column tiles, so there are 8/CT waves.  CT = 2: 256 threads, two workgroups per CU
+// = 2 waves per SIMD.  CT = 1 (512 threads, 4 waves per SIMD, half the accumulators per wave) was
+// measured and is slower -- geometry MLP 1.81 vs 1.43 ms per 2^20 points: every wave re-reads the
+// whole A tile from LDS, the 128-register budget spills, and four waves sharing one matrix pipe
+// stretch each K phase more than the extra epilogue overlap returns -- so only CT = 2 is built.
+#define NM_H_CT 2
+#define NM_H_THREADS (64 * 8 / NM_H_CT)
+#define NM_H_WAVES_PER_SIMD (4 / NM_H_CT)  // two workgroups per CU (LDS: 2 x 68 KiB)
+
+// B operand (weights) of one k-step for the CT column tiles of a wave: 2*CT x 16 bytes per lane.
+template <int CT>
 struct NmBFrag {
-    nm_h8 b0a, b0b, b1a, b1b;
+    nm_h8 a[CT], b[CT];  // plane h1, plane h2
 };
 __device__ __forceinline__ const nm_h8* nm_b_base(const _Float16* W, int Kpad, int ctile) {
     return reinterpret_cast<const nm_h8*>(W) + (size_t)ctile * (Kpad >> 4) * 2 * 64 + (threadIdx.x & 63);
 }
-__device__ __forceinline__ NmBFrag nm_ld_b(const nm_h8* b0p, const nm_h8* b1p, int ks) {
-    NmBFrag f;
+template <int CT>
+__device__ __forceinline__ NmBFrag<CT> nm_ld_b(const nm_h8* const (&bp)[CT], int ks) {
+    NmBFrag<CT> f;
     const int o = ks * 128;
-    f.b0a = b0p[o];
-    f.b0b = b0p[o + 64];
-    f.b1a = b1p[o];
-    f.b1b = b1p[o + 64];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        f.a[c] = bp[c][o];
+        f.b[c] = bp[c][o + 64];
+    }
     return f;
 }
 // the first two k-steps of a layer (issued early: before the input phase / the previous epilogue)
-__device__ __forceinline__ void nm_prefetch_b(const NmLayerH L, NmBFrag& p0, NmBFrag& p1) {
+template <int CT>
+__device__ __forceinline__ void nm_prefetch_b(const NmLayerH L, NmBFrag<CT>& p0, NmBFrag<CT>& p1) {
     const int wave = threadIdx.x >> 6;
-    const nm_h8* b0p = nm_b_base(L.W, L.Kpad, wave * 2);
-    const nm_h8* b1p = nm_b_base(L.W, L.Kpad, wave * 2 + 1);
-    p0 = nm_ld_b(b0p, b1p, 0);
-    p1 = nm_ld_b(b0p, b1p, 1);  // Kpad >= 32 always (in_dim >= 17)
+    const nm_h8* bp[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bp[c] = nm_b_base(L.W, L.Kpad, wave * CT + c);
+    p0 = nm_ld_b<CT>(bp, 0);
+    p1 = nm_ld_b<CT>(bp, 1);  // Kpad >= 32 always (in_dim >= 17)
 }
 
-struct NmAccH {  // 2x2 output tiles of a wave, main and 2^11-scaled accumulators
-    nm_f32x16 hi00, hi01, hi10, hi11, lo00, lo01, lo10, lo11;
+template <int CT>
+struct NmAccH {  // 2 row tiles x CT column tiles of a wave, main and 2^11-scaled accumulators
+    nm_f32x16 hi[2][CT], lo[2][CT];
 };
 
+// the 6*CT MFMAs of one k-step: a[rt][plane], F = weights
+#define NM_H_MFMAS(A, F)                                                                              \
+    _Pragma("unroll") for (int rt_ = 0; rt_ < 2; ++rt_) _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_)   \
+        c.hi[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[rt_][0], F.a[c_], c.hi[rt_][c_], 0, 0, 0);  \
+    _Pragma("unroll") for (int rt_ = 0; rt_ < 2; ++rt_) _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_)   \
+        c.lo[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[rt_][0], F.b[c_], c.lo[rt_][c_], 0, 0, 0);  \
+    _Pragma("unroll") for (int rt_ = 0; rt_ < 2; ++rt_) _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_)   \
+        c.lo[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[rt_][1], F.a[c_], c.lo[rt_][c_], 0, 0, 0);
+
 // K loop of one layer, fully unrolled for a compile-time number of k-steps.
-// The weights come straight from L2 (each wave owns 64 of the 256 output columns, nothing is shared
-// inside the workgroup), ~700 cycles away, while one k-step is 12 MFMAs = 384 matrix-pipe cycles:
+// The weights come straight from L2 (each wave owns its own output columns, nothing is shared
+// inside the workgroup), ~700 cycles away, while one k-step is 6*CT MFMAs of 32 matrix-pipe cycles:
 // the B fragments are fetched TWO steps ahead (three rotating register sets; the first two steps
 // arrive in pre0/pre1, requested before the previous epilogue), the A fragments (LDS) one step.
 // Straight-line code on purpose: in a rolled loop the compiler drains ALL outstanding loads once
 // per iteration (s_waitcnt vmcnt(0) for the loop-carried ones) and, left alone, its scheduler sinks
-// the prefetches down to their first use; unrolled, each step waits for exactly its own fragment
-// (vmcnt(8)), and the sched_barriers pin the issue points.
-template <int KS>
-__device__ __forceinline__ void nm_kloop_h(const _Float16* a0p, const _Float16* a1p, const nm_h8* b0p, const nm_h8* b1p,
-                                           const NmBFrag& pre0, const NmBFrag& pre1, NmAccH& c) {
-    NmBFrag f[3];
+// the prefetches down to their first use; unrolled, each step waits for exactly its own fragment,
+// and the sched_barriers pin the issue points.
+template <int KS, int CT>
+__device__ __forceinline__ void nm_kloop_h(const _Float16* a0p, const _Float16* a1p, const nm_h8* const (&bp)[CT],
+                                           const NmBFrag<CT>& pre0, const NmBFrag<CT>& pre1, NmAccH<CT>& c) {
+    NmBFrag<CT> f[3];
     f[0] = pre0;
     f[1] = pre1;
-    nm_h8 a[2][4];
-    a[0][0] = *reinterpret_cast<const nm_h8*>(a0p);
-    a[0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
-    a[0][2] = *reinterpret_cast<const nm_h8*>(a1p);
-    a[0][3] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE);
+    nm_h8 a[2][2][2];  // [buffer][row tile][plane]
+    a[0][0][0] = *reinterpret_cast<const nm_h8*>(a0p);
+    a[0][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
+    a[0][1][0] = *reinterpret_cast<const nm_h8*>(a1p);
+    a[0][1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         __builtin_amdgcn_sched_barrier(0);
-        if (ks + 2 < KS) f[(ks + 2) % 3] = nm_ld_b(b0p, b1p, ks + 2);
+        if (ks + 2 < KS) f[(ks + 2) % 3] = nm_ld_b<CT>(bp, ks + 2);
         if (ks + 1 < KS) {
             const int oa = (ks + 1) * 16;
-            a[(ks + 1) & 1][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
-            a[(ks + 1) & 1][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
-            a[(ks + 1) & 1][2] = *reinterpret_cast<const nm_h8*>(a1p + oa);
-            a[(ks + 1) & 1][3] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE + oa);
+            a[(ks + 1) & 1][0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
+            a[(ks + 1) & 1][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
+            a[(ks + 1) & 1][1][0] = *reinterpret_cast<const nm_h8*>(a1p + oa);
+            a[(ks + 1) & 1][1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE + oa);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const NmBFrag& F = f[ks % 3];
-        const nm_h8 a0a = a[ks & 1][0], a0b = a[ks & 1][1], a1a = a[ks & 1][2], a1b = a[ks & 1][3];
-        c.hi00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b0a, c.hi00, 0, 0, 0);
-        c.hi01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b1a, c.hi01, 0, 0, 0);
-        c.hi10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b0a, c.hi10, 0, 0, 0);
-        c.hi11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b1a, c.hi11, 0, 0, 0);
-        c.lo00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b0b, c.lo00, 0, 0, 0);
-        c.lo01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b1b, c.lo01, 0, 0, 0);
-        c.lo10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b0b, c.lo10, 0, 0, 0);
-        c.lo11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b1b, c.lo11, 0, 0, 0);
-        c.lo00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0b, F.b0a, c.lo00, 0, 0, 0);
-        c.lo01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0b, F.b1a, c.lo01, 0, 0, 0);
-        c.lo10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1b, F.b0a, c.lo10, 0, 0, 0);
-        c.lo11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1b, F.b1a, c.lo11, 0, 0, 0);
+        NM_H_MFMAS(a[ks & 1], f[ks % 3])
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
 // any other layer width: rolled loop, fragments one step ahead
-__device__ __forceinline__ void nm_kloop_h_generic(int KS, const _Float16* a0p, const _Float16* a1p, const nm_h8* b0p,
-                                                   const nm_h8* b1p, const NmBFrag& pre0, NmAccH& c) {
-    NmBFrag nf = pre0;
-    nm_h8 na0a = *reinterpret_cast<const nm_h8*>(a0p), na0b = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
-    nm_h8 na1a = *reinterpret_cast<const nm_h8*>(a1p), na1b = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE);
+template <int CT>
+__device__ __forceinline__ void nm_kloop_h_generic(int KS, const _Float16* a0p, const _Float16* a1p,
+                                                   const nm_h8* const (&bp)[CT], const NmBFrag<CT>& pre0, NmAccH<CT>& c) {
+    NmBFrag<CT> nf = pre0;
+    nm_h8 na[2][2];
+    na[0][0] = *reinterpret_cast<const nm_h8*>(a0p);
+    na[0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
+    na[1][0] = *reinterpret_cast<const nm_h8*>(a1p);
+    na[1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE);
     for (int ks = 0; ks < KS; ++ks) {
-        const NmBFrag F = nf;
-        const nm_h8 a0a = na0a, a0b = na0b, a1a = na1a, a1b = na1b;
+        const NmBFrag<CT> F = nf;
+        nm_h8 A[2][2];
+        A[0][0] = na[0][0]; A[0][1] = na[0][1]; A[1][0] = na[1][0]; A[1][1] = na[1][1];
         if (ks + 1 < KS) {
-            nf = nm_ld_b(b0p, b1p, ks + 1);
+            nf = nm_ld_b<CT>(bp, ks + 1);
             const int oa = (ks + 1) * 16;
-            na0a = *reinterpret_cast<const nm_h8*>(a0p + oa);
-            na0b = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
-            na1a = *reinterpret_cast<const nm_h8*>(a1p + oa);
-            na1b = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE + oa);
+            na[0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
+            na[0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
+            na[1][0] = *reinterpret_cast<const nm_h8*>(a1p + oa);
+            na[1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE + oa);
         }
-        c.hi00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b0a, c.hi00, 0, 0, 0);
-        c.hi01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b1a, c.hi01, 0, 0, 0);
-        c.hi10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b0a, c.hi10, 0, 0, 0);
-        c.hi11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b1a, c.hi11, 0, 0, 0);
-        c.lo00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b0b, c.lo00, 0, 0, 0);
-        c.lo01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0a, F.b1b, c.lo01, 0, 0, 0);
-        c.lo10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b0b, c.lo10, 0, 0, 0);
-        c.lo11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1a, F.b1b, c.lo11, 0, 0, 0);
-        c.lo00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0b, F.b0a, c.lo00, 0, 0, 0);
-        c.lo01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0b, F.b1a, c.lo01, 0, 0, 0);
-        c.lo10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1b, F.b0a, c.lo10, 0, 0, 0);
-        c.lo11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1b, F.b1a, c.lo11, 0, 0, 0);
+        NM_H_MFMAS(A, F)
     }
 }
 
 // One dense layer on the split-half LDS tile (in place), see the header comment.
 // pre0/pre1: B fragments of this layer's first two k-steps on entry, of the next layer's on exit
 // (requested before the epilogue so that they arrive while it runs).
-template <int ACT, bool TANGENT>
+template <int ACT, bool TANGENT, int CT>
 __device__ __forceinline__ void nm_mlp_layer_h(_Float16* tile, const NmLayerH L, const bool has_next, const NmLayerH next,
-                                               NmBFrag& pre0, NmBFrag& pre1, int stamp_slot) {
+                                               NmBFrag<CT>& pre0, NmBFrag<CT>& pre1, int stamp_slot) {
     const float* __restrict__ bias = L.b;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, h = lane >> 5;
-    const int n0 = wave * 64;
+    const int n0 = wave * 32 * CT;
     const int KS = L.Kpad >> 4;
     const _Float16* a0p = tile + li * NM_H_STRIDE + 8 * h;
     const _Float16* a1p = tile + (32 + li) * NM_H_STRIDE + 8 * h;
-    const nm_h8* b0p = nm_b_base(L.W, L.Kpad, wave * 2);
-    const nm_h8* b1p = nm_b_base(L.W, L.Kpad, wave * 2 + 1);
-    NmAccH c;
-    c.hi00 = c.hi01 = c.hi10 = c.hi11 = c.lo00 = c.lo01 = c.lo10 = c.lo11 = nm_f32x16{0};
+    const nm_h8* bp[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bp[c] = nm_b_base(L.W, L.Kpad, wave * CT + c);
+    NmAccH<CT> c;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) c.hi[rt][ct] = c.lo[rt][ct] = nm_f32x16{0};
     switch (KS) {  // the widths of the reference configuration get the unrolled form
-        case 16: nm_kloop_h<16>(a0p, a1p, b0p, b1p, pre0, pre1, c); break;  // hidden layers (W = 256)
-        case 12: nm_kloop_h<12>(a0p, a1p, b0p, b1p, pre0, pre1, c); break;  // geometry input 177 -> 192
-        case 13: nm_kloop_h<13>(a0p, a1p, b0p, b1p, pre0, pre1, c); break;  // colour input 207 -> 208
-        default: nm_kloop_h_generic(KS, a0p, a1p, b0p, b1p, pre0, c); break;
+        case 16: nm_kloop_h<16, CT>(a0p, a1p, bp, pre0, pre1, c); break;  // hidden layers (W = 256)
+        case 12: nm_kloop_h<12, CT>(a0p, a1p, bp, pre0, pre1, c); break;  // geometry input 177 -> 192
+        case 13: nm_kloop_h<13, CT>(a0p, a1p, bp, pre0, pre1, c); break;  // colour input 207 -> 208
+        default: nm_kloop_h_generic<CT>(KS, a0p, a1p, bp, pre0, c); break;
     }
-    const nm_f32x16 &hi00 = c.hi00, &hi01 = c.hi01, &hi10 = c.hi10, &hi11 = c.hi11;
-    const nm_f32x16 &lo00 = c.lo00, &lo01 = c.lo01, &lo10 = c.lo10, &lo11 = c.lo11;
-    if (has_next) nm_prefetch_b(next, pre0, pre1);
+    if (has_next) nm_prefetch_b<CT>(next, pre0, pre1);
     __syncthreads();  // every wave has finished reading the input tile
     nm_phase_stamp(stamp_slot);
-    const float bias0 = bias[n0 + li], bias1 = bias[n0 + 32 + li];
     const float sc = 1.0f / 2048.0f;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;  // MFMA 32x32 C/D layout
-        const float z00 = fmaf(lo00[reg], sc, hi00[reg]) + bias0, z01 = fmaf(lo01[reg], sc, hi01[reg]) + bias1;
-        if (TANGENT) {
-            float g0, g1, y0, y1;
-            if (ACT == 0) {
-                y0 = nm_softplus100(z00, &g0);
-                y1 = nm_softplus100(z01, &g1);
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = n0 + 32 * ct + li;
+        const float bv = bias[col];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;  // MFMA 32x32 C/D layout
+            const float z0 = fmaf(c.lo[0][ct][reg], sc, c.hi[0][ct][reg]) + bv;
+            const float t1 = fmaf(c.lo[1][ct][reg], sc, c.hi[1][ct][reg]);
+            if (TANGENT) {
+                float g0, y0;
+                if (ACT == 0) {
+                    y0 = nm_softplus100(z0, &g0);
+                } else {
+                    y0 = fmaxf(z0, 0.f);
+                    g0 = z0 > 0.f ? 1.f : 0.f;
+                }
+                nm_store_split(tile, row, col, y0);
+                nm_store_split(tile, 32 + row, col, t1 * g0);
             } else {
-                y0 = fmaxf(z00, 0.f); g0 = z00 > 0.f ? 1.f : 0.f;
-                y1 = fmaxf(z01, 0.f); g1 = z01 > 0.f ? 1.f : 0.f;
-            }
-            nm_store_split(tile, row, n0 + li, y0);
-            nm_store_split(tile, row, n0 + 32 + li, y1);
-            nm_store_split(tile, 32 + row, n0 + li, fmaf(lo10[reg], sc, hi10[reg]) * g0);
-            nm_store_split(tile, 32 + row, n0 + 32 + li, fmaf(lo11[reg], sc, hi11[reg]) * g1);
-        } else {
-            const float z10 = fmaf(lo10[reg], sc, hi10[reg]) + bias0, z11 = fmaf(lo11[reg], sc, hi11[reg]) + bias1;
-            if (ACT == 0) {
-                nm_store_split(tile, row, n0 + li, nm_softplus100(z00, nullptr));
-                nm_store_split(tile, row, n0 + 32 + li, nm_softplus100(z01, nullptr));
-                nm_store_split(tile, 32 + row, n0 + li, nm_softplus100(z10, nullptr));
-                nm_store_split(tile, 32 + row, n0 + 32 + li, nm_softplus100(z11, nullptr));
-            } else {
-                nm_store_split(tile, row, n0 + li, fmaxf(z00, 0.f));
-                nm_store_split(tile, row, n0 + 32 + li, fmaxf(z01, 0.f));
-                nm_store_split(tile, 32 + row, n0 + li, fmaxf(z10, 0.f));
-                nm_store_split(tile, 32 + row, n0 + 32 + li, fmaxf(z11, 0.f));
+                const float z1 = t1 + bv;
+                if (ACT == 0) {
+                    nm_store_split(tile, row, col, nm_softplus100(z0, nullptr));
+                    nm_store_split(tile, 32 + row, col, nm_softplus100(z1, nullptr));
+                } else {
+                    nm_store_split(tile, row, col, fmaxf(z0, 0.f));
+                    nm_store_split(tile, 32 + row, col, fmaxf(z1, 0.f));
+                }
             }
         }
     }
     __syncthreads();
     nm_phase_stamp(stamp_slot + 1);
 }
+#undef NM_H_MFMAS
 
 // x and its sin/cos bands for 4 consecutive feature dims, written split into the tile row.
 // Odd bands come from the even band below them by the double-angle identities (3 operations
@@ -295,7 +302,7 @@ __device__ __forceinline__ void nm_embed4_h(_Float16* tile, int row, int col0, i
 
 // ------------------------------------------------------------------ geometry MLP (split-half)
 template <bool NABLA>
-__global__ __launch_bounds__(256, 2) void nm_geo_mlp_h_kernel(NmGeoParamsH prm, const float* __restrict__ fg_rec,
+__global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_h_kernel(NmGeoParamsH prm, const float* __restrict__ fg_rec,
                                                               const float* __restrict__ ds, const float* __restrict__ grad,
                                                               NmRecMap rmap, long long npts, float* __restrict__ sdf_out, int P,
                                                               int stride, int off, float* __restrict__ nabla_out) {
@@ -305,10 +312,10 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_h_kernel(NmGeoParamsH prm, 
     const long long base = (long long)blockIdx.x * PTS;
     const NmDivBase rdiv = nm_div_base(base, rmap.stride ? rmap.P : 1), odiv = nm_div_base(base, P);
     nm_phase_stamp(0);
-    NmBFrag pre0, pre1;
-    nm_prefetch_b(prm.layer[0], pre0, pre1);  // in flight during the input phase
+    NmBFrag<NM_H_CT> pre0, pre1;
+    nm_prefetch_b<NM_H_CT>(prm.layer[0], pre0, pre1);  // in flight during the input phase
     const int Kpad0 = prm.layer[0].Kpad;
-    for (int task = threadIdx.x; task < PTS * 8; task += 256) {
+    for (int task = threadIdx.x; task < PTS * 8; task += NM_H_THREADS) {
         const int p = task >> 3, j = task & 7;
         const long long q = base + p;
         if (q >= npts) {
@@ -356,8 +363,8 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_h_kernel(NmGeoParamsH prm, 
     __syncthreads();
     nm_phase_stamp(1);
     for (int l = 0; l < prm.D; ++l)  // (kernel-argument loads with a uniform index: scalar)
-        nm_mlp_layer_h<0, NABLA>(tile, prm.layer[l], l + 1 < prm.D, prm.layer[l + 1 < prm.D ? l + 1 : l], pre0, pre1, 2 + 2 * l);
-    {
+        nm_mlp_layer_h<0, NABLA, NM_H_CT>(tile, prm.layer[l], l + 1 < prm.D, prm.layer[l + 1 < prm.D ? l + 1 : l], pre0, pre1, 2 + 2 * l);
+    if (threadIdx.x < 256) {  // output projection: 4 lanes per row
         const int row = threadIdx.x >> 2, q4 = threadIdx.x & 3;
         float s = 0.f;
         for (int m = 0; m < 8; ++m) {  // columns 8*(q4 + 4*m) .. +8: 16-byte LDS reads, 4 lanes cover 64 B
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_h_kernel(NmGeoParamsH prm, 
 }
 
 // ------------------------------------------------------------------ colour MLP (split-half)
-__global__ __launch_bounds__(256, 2) void nm_col_mlp_h_kernel(NmColParamsH prm, const float* __restrict__ ft_rec,
+__global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_h_kernel(NmColParamsH prm, const float* __restrict__ ft_rec,
                                                               const float* __restrict__ ds, const float* __restrict__ nabla,
                                                               const float* __restrict__ dirs, int dir_div, long long npts,
                                                               float* __restrict__ rgb_out) {
@@ -404,13 +411,13 @@ __global__ __launch_bounds__(256, 2) void nm_col_mlp_h_kernel(NmColParamsH prm, 
     const long long base = (long long)blockIdx.x * NM_ROWS;
     const NmDivBase ddiv = nm_div_base(base, dir_div);
     nm_phase_stamp(0);
-    NmBFrag pre0, pre1;
-    nm_prefetch_b(prm.layer[0], pre0, pre1);  // in flight during the input phase
+    NmBFrag<NM_H_CT> pre0, pre1;
+    nm_prefetch_b<NM_H_CT>(prm.layer[0], pre0, pre1);  // in flight during the input phase
     const int Kpad0 = prm.layer[0].Kpad;
     const int o_d = prm.use_nabla ? 3 : 0;
     const int o_v = o_d + prm.d_emb;
     const int o_f = o_v + 3 * (1 + 2 * prm.multires_view);
-    for (int task = threadIdx.x; task < NM_ROWS * 8; task += 256) {
+    for (int task = threadIdx.x; task < NM_ROWS * 8; task += NM_H_THREADS) {
         const int p = task >> 3, j = task & 7;
         const long long q = base + p;
         if (q >= npts) {
@@ -465,8 +472,8 @@ __global__ __launch_bounds__(256, 2) void nm_col_mlp_h_kernel(NmColParamsH prm, 
     __syncthreads();
     nm_phase_stamp(1);
     for (int l = 0; l < prm.D; ++l)
-        nm_mlp_layer_h<1, false>(tile, prm.layer[l], l + 1 < prm.D, prm.layer[l + 1 < prm.D ? l + 1 : l], pre0, pre1, 2 + 2 * l);
-    {
+        nm_mlp_layer_h<1, false, NM_H_CT>(tile, prm.layer[l], l + 1 < prm.D, prm.layer[l + 1 < prm.D ? l + 1 : l], pre0, pre1, 2 + 2 * l);
+    if (threadIdx.x < 256) {  // output projection: 4 lanes per row
         const int row = threadIdx.x >> 2, q4 = threadIdx.x & 3;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
         for (int m = 0; m < 8; ++m) {
