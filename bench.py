@@ -216,7 +216,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x2-split (22-bit operands, fp32 accumulate; K-NN and per-ray stages fp32)" if split else "f32", "data": "synthetic",
             "config": {"workload": f"S-DTU V={args.V} {args.H}x{args.W} rays/frame/GPU, 64+64 samples, bounded_near_far (256 probes), "
-                                   f"calc_normal, 639 K-NN queries + 383 geometry-MLP + 127 colour-MLP evals per ray",
+                                   f"calc_normal, per ray 639 K-NN points (511 searched, 128 reused), 255 geometry-MLP evaluations with nablas (the reference's 128 forward-only ones at the same points are the value rows of these) + 127 colour-MLP",
                        "rayschunk": args.rayschunk, "parallelism": f"rays sharded: {world} GPU(s) x 1 frame per step, 1 all-gather of pixels"},
             "roofline": {"bound": "mfma", "kernel": ({"geo_mlp": "nm_geo_mlp_h_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_h_kernel<true>",
                                                       "color_mlp": "nm_col_mlp_h_kernel"} if split else

@@ -395,21 +395,21 @@ static int nm_check_field_args(nm_field_t f, nm_grid_t g, const nm_field_tables*
 
 static int nm_launch_geo(nm_field_t f, const float* fg, const float* ds, const float* grad, long long P, bool nabla,
                          float* sdf, int Pper, int stride, int off, float* nabla_out, hipStream_t stream,
-                         NmRecMap rmap = NM_COMPACT) {
+                         NmRecMap rmap = NM_COMPACT, int nabla_slotted = 0) {
     if (P <= 0) return 0;
     NmProfScope prof(nabla ? NM_K_GEO_NABLA : NM_K_GEO, P, stream);
     if (f->precision == 1) {
-        if (nabla) hipLaunchKernelGGL((nm_geo_mlp_h_kernel<true>), dim3(nm_blocks(P, 32)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out);
-        else hipLaunchKernelGGL((nm_geo_mlp_h_kernel<false>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out);
+        if (nabla) hipLaunchKernelGGL((nm_geo_mlp_h_kernel<true>), dim3(nm_blocks(P, 32)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted);
+        else hipLaunchKernelGGL((nm_geo_mlp_h_kernel<false>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted);
         NM_LAUNCH_CHECK();
         return 0;
     }
     if (nabla) {
         hipLaunchKernelGGL((nm_geo_mlp_kernel<true, false>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo, fg, ds,
-                           grad, rmap, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr);
+                           grad, rmap, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr, nabla_slotted);
     } else {
         hipLaunchKernelGGL((nm_geo_mlp_kernel<false, false>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->geo, fg, ds,
-                           grad, rmap, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr);
+                           grad, rmap, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr, nabla_slotted);
     }
     NM_LAUNCH_CHECK();
     return 0;
@@ -601,9 +601,15 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     src.out_stride = cap;
     src.out_off = 0;
     if (nm_launch_distance(g, src, (long long)R * c->N_samples, t->indicator_vector, t->indicator_weight, ws.slots.ds, nullptr, nullptr, nullptr, want_grad ? ws.slots.grad : nullptr, stream, ws.radius, ga_slots)) return 1;
+    // With normals requested the sampling passes already run the tangent form of the geometry MLP:
+    // forward_with_nablas(pts) (renderer.py:271-276) is evaluated at exactly these points, and the
+    // value rows of the tangent kernel are bit-identical to the forward-only kernel, so the nablas
+    // are written per slot now (into the buffer the mid-point pass overwrites later) and merely
+    // permuted at the end -- instead of a second pass of N evaluations per ray.
+    float* nab_slot = want_grad ? ws.nab_mid : nullptr;
     {
         const NmRecMap rm = {c->N_samples, cap, 0, nullptr};
-        if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, nullptr, (long long)R * c->N_samples, false, ws.sdf, c->N_samples, cap, 0, nullptr, stream, rm)) return 1;
+        if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, want_grad ? ws.slots.grad : nullptr, (long long)R * c->N_samples, want_grad, ws.sdf, c->N_samples, cap, 0, nab_slot, stream, rm, 1)) return 1;
     }
     if (dbg && dbg->sdf_coarse) {
         hipLaunchKernelGGL(nm_copy_strided_kernel, dim3(nm_blocks(R * c->N_samples, 256)), dim3(256), 0, stream, ws.sdf, (long long)R, c->N_samples, cap, dbg->sdf_coarse);
@@ -636,18 +642,19 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
             }
             if (nm_launch_distance(g, src, (long long)R * n_new, t->indicator_vector, t->indicator_weight, ws.slots.ds, nullptr, nullptr, nullptr, want_grad ? ws.slots.grad : nullptr, stream, ws.radius, ga_slots)) return 1;
             const NmRecMap rm = {n_new, cap, n, nullptr};
-            if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, nullptr, (long long)R * n_new, false, ws.sdf, n_new, cap, n, nullptr, stream, rm)) return 1;
+            if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, want_grad ? ws.slots.grad : nullptr, (long long)R * n_new, want_grad, ws.sdf, n_new, cap, n, nab_slot, stream, rm, 1)) return 1;
             n += n_new;
             pending = n_new;
         }
     }
     hipLaunchKernelGGL(nm_rays_finalize_kernel, rgrid, rblock, ray_lds, stream, ws.d, ws.sdf, ws.slot, ws.radius, (long long)R, cap, n, pending, ws.dmid, ws.bound_mid);
     NM_LAUNCH_CHECK();
-    // SDF (+ nablas) at all N sample points (renderer.py:264, 271-276): no new search.  Without
-    // normals the SDF values merged above ARE forward_density_only(pts) (same points, same kernel).
+    // SDF (+ nablas) at all N sample points (renderer.py:264, 271-276): no new search and no new
+    // MLP pass -- the SDF values merged above ARE forward_with_nablas(pts)[0] (same points, same
+    // arithmetic), the nablas are brought into sorted order through the slot permutation.
     if (c->calc_normal) {
-        const NmRecMap rm = {N, cap, 0, ws.slot};
-        if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, ws.slots.grad, (long long)R * N, true, ws.sdf, N, cap, 0, ws.nab_pts, stream, rm)) return 1;
+        hipLaunchKernelGGL(nm_permute_rows3_kernel, dim3(nm_blocks(R * N, 256)), dim3(256), 0, stream, nab_slot, ws.slot, (long long)R, cap, N, ws.nab_pts);
+        NM_LAUNCH_CHECK();
     }
     // SDF + nabla + radiance at the N-1 mid-points (renderer.py:266-267, 279-282)
     src.order = nullptr;
@@ -848,7 +855,7 @@ int nm_selfcheck_field(nm_field_t f, nm_grid_t g, const nm_field_tables* t, cons
     const NmGather ga = {t->geometry_features, f->geo.gdim, s.fg, t->color_features, f->col.cdim, s.ft};
     if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr, s.grad, stream, nullptr, ga)) return 1;
     hipLaunchKernelGGL((nm_geo_mlp_kernel<true, true>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo, s.fg, s.ds, s.grad,
-                       NM_COMPACT, (long long)P, sdf, 1, 1, 0, nabla, valu_tmp);
+                       NM_COMPACT, (long long)P, sdf, 1, 1, 0, nabla, valu_tmp, 0);
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL((nm_col_mlp_kernel<true>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->col, s.ft, s.ds, nabla,
                        view_dirs, 1, (long long)P, rgb, valu_tmp);

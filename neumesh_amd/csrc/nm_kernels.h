@@ -606,6 +606,19 @@ __global__ void nm_idx64_to_32_kernel(const long long* __restrict__ src, long lo
     if (e < n) dst[e] = (int)src[e];
 }
 
+// dst[r][j][0..3) = src[r][slot[r][j]][0..3)  (per-slot rows -> sorted sample order)
+__global__ void nm_permute_rows3_kernel(const float* __restrict__ src, const int* __restrict__ slot, long long R, int cap,
+                                        int n, float* __restrict__ dst) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= R * n) return;
+    const long long r = e / n;
+    const int j = (int)(e - r * n);
+    const long long s = r * cap + slot[r * cap + j];
+    dst[e * 3] = src[s * 3];
+    dst[e * 3 + 1] = src[s * 3 + 1];
+    dst[e * 3 + 2] = src[s * 3 + 2];
+}
+
 __global__ void nm_copy_strided_kernel(const float* __restrict__ src, long long R, int n, int src_stride,
                                        float* __restrict__ dst) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;

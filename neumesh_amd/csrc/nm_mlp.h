@@ -312,13 +312,13 @@ __device__ __forceinline__ void nm_embed4(float* row, int dim, int bands, int ch
 // Points q in [0, npts): inputs ds[rec], fg_rec[rec][gdim] (interpolated geometry code, from the
 // K-NN/distance kernel) and, with NABLA, grad[rec][3] = d ds/d xyz; rec = nm_rec_index(rmap, q).  Output sdf to sdf_out[(q / P) * stride + off + q % P]
 // (P = samples per ray of this call; P = 1, stride = 1 for flat outputs) and
-// nabla_out[q][3] = (d sdf/d ds) * grad[q].
+// nabla_out[q][3] = (d sdf/d ds) * grad[q]  (nabla_slotted: written at the sdf_out position instead of q).
 template <bool NABLA, bool VALU_CHECK>
 __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, const float* __restrict__ fg_rec,
                                                             const float* __restrict__ ds, const float* __restrict__ grad,
                                                             NmRecMap rmap, long long npts, float* __restrict__ sdf_out, int P,
                                                             int stride, int off, float* __restrict__ nabla_out,
-                                                            float* __restrict__ valu_tmp) {
+                                                            float* __restrict__ valu_tmp, int nabla_slotted) {
     __shared__ __attribute__((aligned(16))) float act[NM_ROWS * NM_LDS_STRIDE + NM_ROWS];
     float* red = act + NM_ROWS * NM_LDS_STRIDE;
     constexpr int PTS = NABLA ? 32 : 64;
@@ -393,18 +393,18 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, con
         const long long q = base + threadIdx.x;
         if (q < npts) {
             const float sdf = red[threadIdx.x] + prm.bd;
-            if (sdf_out) {
-                long long orow;
-                int op;
-                nm_div_local(odiv, (int)threadIdx.x, orow, op);
-                sdf_out[orow * stride + off + op] = sdf;
-            }
+            long long orow;
+            int op;
+            nm_div_local(odiv, (int)threadIdx.x, orow, op);
+            const long long oidx = orow * stride + off + op;  // (ray, sample) addressed output position
+            if (sdf_out) sdf_out[oidx] = sdf;
             if (NABLA && nabla_out) {
                 const float dsdf = red[32 + threadIdx.x];
                 const long long rq = nm_rec_index_local(rmap, rdiv, base, (int)threadIdx.x);
-                nabla_out[q * 3 + 0] = dsdf * grad[rq * 3 + 0];
-                nabla_out[q * 3 + 1] = dsdf * grad[rq * 3 + 1];
-                nabla_out[q * 3 + 2] = dsdf * grad[rq * 3 + 2];
+                const long long no = nabla_slotted ? oidx : q;
+                nabla_out[no * 3 + 0] = dsdf * grad[rq * 3 + 0];
+                nabla_out[no * 3 + 1] = dsdf * grad[rq * 3 + 1];
+                nabla_out[no * 3 + 2] = dsdf * grad[rq * 3 + 2];
             }
         }
     }

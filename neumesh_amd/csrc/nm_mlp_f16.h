@@ -305,7 +305,8 @@ template <bool NABLA>
 __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_h_kernel(NmGeoParamsH prm, const float* __restrict__ fg_rec,
                                                               const float* __restrict__ ds, const float* __restrict__ grad,
                                                               NmRecMap rmap, long long npts, float* __restrict__ sdf_out, int P,
-                                                              int stride, int off, float* __restrict__ nabla_out) {
+                                                              int stride, int off, float* __restrict__ nabla_out,
+                                                              int nabla_slotted) {
     __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE + 2 * NM_ROWS + NM_EXP_LDS_PAD];
     float* red = reinterpret_cast<float*>(tile + 2 * NM_H_PLANE);
     constexpr int PTS = NABLA ? 32 : 64;
@@ -383,18 +384,18 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
         const long long q = base + threadIdx.x;
         if (q < npts) {
             const float sdf = red[threadIdx.x] + prm.bd;
-            if (sdf_out) {
-                long long orow;
-                int op;
-                nm_div_local(odiv, (int)threadIdx.x, orow, op);
-                sdf_out[orow * stride + off + op] = sdf;
-            }
+            long long orow;
+            int op;
+            nm_div_local(odiv, (int)threadIdx.x, orow, op);
+            const long long oidx = orow * stride + off + op;  // (ray, sample) addressed output position
+            if (sdf_out) sdf_out[oidx] = sdf;
             if (NABLA && nabla_out) {
                 const float dsdf = red[32 + threadIdx.x] * (1.0f / NM_TANGENT_SCALE);
                 const long long rq = nm_rec_index_local(rmap, rdiv, base, (int)threadIdx.x);
-                nabla_out[q * 3 + 0] = dsdf * grad[rq * 3 + 0];
-                nabla_out[q * 3 + 1] = dsdf * grad[rq * 3 + 1];
-                nabla_out[q * 3 + 2] = dsdf * grad[rq * 3 + 2];
+                const long long no = nabla_slotted ? oidx : q;
+                nabla_out[no * 3 + 0] = dsdf * grad[rq * 3 + 0];
+                nabla_out[no * 3 + 1] = dsdf * grad[rq * 3 + 1];
+                nabla_out[no * 3 + 2] = dsdf * grad[rq * 3 + 2];
             }
         }
     }
