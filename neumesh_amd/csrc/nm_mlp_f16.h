@@ -316,9 +316,33 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
     NmBFrag<NM_H_CT> pre0, pre1;
     nm_prefetch_b<NM_H_CT>(prm.layer[0], pre0, pre1);  // in flight during the input phase
     const int Kpad0 = prm.layer[0].Kpad;
-    for (int task = threadIdx.x; task < PTS * 8; task += NM_H_THREADS) {
+    // All global loads of the input phase are issued first (both task rounds), the embedding work
+    // follows: written in program order each round exposed two dependent memory latencies.
+    constexpr int ROUNDS = PTS * 8 / NM_H_THREADS;
+    float in_ds[ROUNDS];
+    float4 in_fg[ROUNDS][2];
+    const int nchunk = prm.gdim >> 2;  // <= 16: at most two 16-byte chunks per lane
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int task = threadIdx.x + rd * NM_H_THREADS;
+        const int p = task >> 3, j = task & 7;
+        in_ds[rd] = 0.f;
+        in_fg[rd][0] = in_fg[rd][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (base + p < npts) {
+            const long long rq = nm_rec_index_local(rmap, rdiv, base, p);
+            in_ds[rd] = ds[rq];
+            if (j < nchunk) in_fg[rd][0] = *reinterpret_cast<const float4*>(fg_rec + rq * prm.gdim + 4 * j);
+            if (j + 8 < nchunk) in_fg[rd][1] = *reinterpret_cast<const float4*>(fg_rec + rq * prm.gdim + 4 * (j + 8));
+        }
+    }
+#pragma unroll 1  // (one copy of the embedding code: the round's inputs are selected, not re-inlined)
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int task = threadIdx.x + rd * NM_H_THREADS;
         const int p = task >> 3, j = task & 7;
         const long long q = base + p;
+        const int sel = ROUNDS > 1 ? rd : 0;
+        const float dsv = sel ? in_ds[ROUNDS - 1] : in_ds[0];
+        const float4 fg0 = sel ? in_fg[ROUNDS - 1][0] : in_fg[0][0], fg1 = sel ? in_fg[ROUNDS - 1][1] : in_fg[0][1];
         if (q >= npts) {
             for (int c = j; c < Kpad0; c += 8) {
                 tile[p * NM_H_STRIDE + c] = (_Float16)0.0f;
@@ -334,8 +358,6 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
             tile[p * NM_H_STRIDE + c] = (_Float16)0.0f;
             tile[NM_H_PLANE + p * NM_H_STRIDE + c] = (_Float16)0.0f;
         }
-        const long long rq = nm_rec_index_local(rmap, rdiv, base, p);
-        const float dsv = ds[rq];
         if (j == 0) {
             nm_store_split(tile, p, 0, dsv);
             if (NABLA) nm_store_split(tile, 32 + p, 0, NM_TANGENT_SCALE);
@@ -356,10 +378,8 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
                 nm_store_split(tile, 32 + p, 2 + 2 * b, -(NM_TANGENT_SCALE * f) * s);
             }
         }
-        for (int chunk = j; chunk < (prm.gdim >> 2); chunk += 8) {
-            const float4 fg = *reinterpret_cast<const float4*>(fg_rec + rq * prm.gdim + 4 * chunk);
-            nm_embed4_h(tile, p, prm.d_emb, prm.gdim, prm.multires_fg, chunk, fg);
-        }
+        if (j < nchunk) nm_embed4_h(tile, p, prm.d_emb, prm.gdim, prm.multires_fg, j, fg0);
+        if (j + 8 < nchunk) nm_embed4_h(tile, p, prm.d_emb, prm.gdim, prm.multires_fg, j + 8, fg1);
     }
     __syncthreads();
     nm_phase_stamp(1);
@@ -418,9 +438,46 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
     const int o_d = prm.use_nabla ? 3 : 0;
     const int o_v = o_d + prm.d_emb;
     const int o_f = o_v + 3 * (1 + 2 * prm.multires_view);
-    for (int task = threadIdx.x; task < NM_ROWS * 8; task += NM_H_THREADS) {
+    constexpr int ROUNDS = NM_ROWS * 8 / NM_H_THREADS;  // global loads of both task rounds first (see the geometry kernel)
+    float in_ds[ROUNDS], in_nb[ROUNDS][3], in_dv[ROUNDS][3];
+    float4 in_ft[ROUNDS][2];
+    const int nchunk = prm.cdim >> 2;
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int task = threadIdx.x + rd * NM_H_THREADS;
         const int p = task >> 3, j = task & 7;
         const long long q = base + p;
+        in_ds[rd] = 0.f;
+        in_nb[rd][0] = in_nb[rd][1] = in_nb[rd][2] = 0.f;
+        in_dv[rd][0] = in_dv[rd][1] = in_dv[rd][2] = 0.f;
+        in_ft[rd][0] = in_ft[rd][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < npts) {
+            in_ds[rd] = ds[q];
+            if (j == 0 && prm.use_nabla) {
+                in_nb[rd][0] = nabla[q * 3 + 0];
+                in_nb[rd][1] = nabla[q * 3 + 1];
+                in_nb[rd][2] = nabla[q * 3 + 2];
+            }
+            long long ray;
+            int unused_p;
+            nm_div_local(ddiv, p, ray, unused_p);
+            in_dv[rd][0] = dirs[ray * 3 + 0];
+            in_dv[rd][1] = dirs[ray * 3 + 1];
+            in_dv[rd][2] = dirs[ray * 3 + 2];
+            if (j < nchunk) in_ft[rd][0] = *reinterpret_cast<const float4*>(ft_rec + q * prm.cdim + 4 * j);
+            if (j + 8 < nchunk) in_ft[rd][1] = *reinterpret_cast<const float4*>(ft_rec + q * prm.cdim + 4 * (j + 8));
+        }
+    }
+#pragma unroll 1
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int task = threadIdx.x + rd * NM_H_THREADS;
+        const int p = task >> 3, j = task & 7;
+        const long long q = base + p;
+        const int sel = ROUNDS > 1 ? rd : 0;
+        const float dsv = sel ? in_ds[ROUNDS - 1] : in_ds[0];
+        const float nb[3] = {sel ? in_nb[ROUNDS - 1][0] : in_nb[0][0], sel ? in_nb[ROUNDS - 1][1] : in_nb[0][1], sel ? in_nb[ROUNDS - 1][2] : in_nb[0][2]};
+        const float dv[3] = {sel ? in_dv[ROUNDS - 1][0] : in_dv[0][0], sel ? in_dv[ROUNDS - 1][1] : in_dv[0][1], sel ? in_dv[ROUNDS - 1][2] : in_dv[0][2]};
+        const float4 ft0 = sel ? in_ft[ROUNDS - 1][0] : in_ft[0][0], ft1 = sel ? in_ft[ROUNDS - 1][1] : in_ft[0][1];
         if (q >= npts) {
             for (int c = j; c < Kpad0; c += 8) {
                 tile[p * NM_H_STRIDE + c] = (_Float16)0.0f;
@@ -432,13 +489,12 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
             tile[p * NM_H_STRIDE + c] = (_Float16)0.0f;
             tile[NM_H_PLANE + p * NM_H_STRIDE + c] = (_Float16)0.0f;
         }
-        const float dsv = ds[q];
         if (j == 0) {
             nm_store_split(tile, p, o_d, dsv);
             if (prm.use_nabla) {
-                nm_store_split(tile, p, 0, nabla[q * 3 + 0]);
-                nm_store_split(tile, p, 1, nabla[q * 3 + 1]);
-                nm_store_split(tile, p, 2, nabla[q * 3 + 2]);
+                nm_store_split(tile, p, 0, nb[0]);
+                nm_store_split(tile, p, 1, nb[1]);
+                nm_store_split(tile, p, 2, nb[2]);
             }
         }
         for (int b = j; b < prm.multires_d; b += 8) {
@@ -448,27 +504,21 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
             nm_store_split(tile, p, o_d + 2 + 2 * b, co);
         }
         {
-            long long ray;
-            int unused_p;
-            nm_div_local(ddiv, p, ray, unused_p);
-            const float* dv = dirs + ray * 3;
             if (j == 1) {
                 nm_store_split(tile, p, o_v, dv[0]);
                 nm_store_split(tile, p, o_v + 1, dv[1]);
                 nm_store_split(tile, p, o_v + 2, dv[2]);
             }
             for (int e = j; e < 3 * prm.multires_view; e += 8) {
-                const int dim = e % 3, b = e / 3;
+                const int b = e / 3, dim = e - 3 * b;
                 float s, co;
-                nm_sincos(dv[dim] * (float)(1 << b), &s, &co);
+                nm_sincos((dim == 0 ? dv[0] : dim == 1 ? dv[1] : dv[2]) * (float)(1 << b), &s, &co);
                 nm_store_split(tile, p, o_v + 3 + 6 * b + dim, s);
                 nm_store_split(tile, p, o_v + 6 + 6 * b + dim, co);
             }
         }
-        for (int chunk = j; chunk < (prm.cdim >> 2); chunk += 8) {
-            const float4 ft = *reinterpret_cast<const float4*>(ft_rec + q * prm.cdim + 4 * chunk);
-            nm_embed4_h(tile, p, o_f, prm.cdim, prm.multires_ft, chunk, ft);
-        }
+        if (j < nchunk) nm_embed4_h(tile, p, o_f, prm.cdim, prm.multires_ft, j, ft0);
+        if (j + 8 < nchunk) nm_embed4_h(tile, p, o_f, prm.cdim, prm.multires_ft, j + 8, ft1);
     }
     __syncthreads();
     nm_phase_stamp(1);
