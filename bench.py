@@ -113,7 +113,8 @@ def main():
     ap.add_argument("--H", type=int, default=800)
     ap.add_argument("--W", type=int, default=800)
     ap.add_argument("--V", type=int, default=140_000)
-    ap.add_argument("--rayschunk", type=int, default=65536)
+    ap.add_argument("--rayschunk", type=int, default=0,
+                    help="rays per nm_render_rays call; 0 = the whole frame in one call (56 KB of workspace per ray: 36 GB for 800x800)")
     ap.add_argument("--mlp-precision", choices=["f16x2", "fp32"], default="f16x2",
                     help="MLP arithmetic: split-half f16 MFMA (default; 22-bit operands, fp32 accumulation) or fp32 MFMA")
     ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU-baseline sample (0 disables)")
@@ -152,7 +153,7 @@ def main():
     gathered = torch.empty((world * n_rays, 8), dtype=torch.float32, device=dev) if world > 1 else None
 
     def step(i):
-        ret = render_rays_fused(model, rays[i][0], rays[i][1], cfg, args.rayschunk, tables=tables)
+        ret = render_rays_fused(model, rays[i][0], rays[i][1], cfg, args.rayschunk or n_rays, tables=tables)
         if world > 1:
             packed, _ = pack_outputs(ret)
             dist.all_gather_into_tensor(gathered, packed)   # the path's only collective: final pixels
@@ -217,7 +218,7 @@ def main():
             "dtype": "f16x2-split (22-bit operands, fp32 accumulate; K-NN and per-ray stages fp32)" if split else "f32", "data": "synthetic",
             "config": {"workload": f"S-DTU V={args.V} {args.H}x{args.W} rays/frame/GPU, 64+64 samples, bounded_near_far (256 probes), "
                                    f"calc_normal, per ray 639 K-NN points (511 searched, 128 reused), 255 geometry-MLP evaluations with nablas (the reference's 128 forward-only ones at the same points are the value rows of these) + 127 colour-MLP",
-                       "rayschunk": args.rayschunk, "parallelism": f"rays sharded: {world} GPU(s) x 1 frame per step, 1 all-gather of pixels"},
+                       "rayschunk": args.rayschunk or n_rays, "parallelism": f"rays sharded: {world} GPU(s) x 1 frame per step, 1 all-gather of pixels"},
             "roofline": {"bound": "mfma", "kernel": ({"geo_mlp": "nm_geo_mlp_h_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_h_kernel<true>",
                                                       "color_mlp": "nm_col_mlp_h_kernel"} if split else
                                                      {"geo_mlp": "nm_geo_mlp_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_kernel<true>",

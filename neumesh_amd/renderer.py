@@ -11,6 +11,7 @@ kernels on the current stream, with no per-stage tensors materialised in Python.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 from typing import Optional
 
@@ -51,10 +52,11 @@ def make_render_cfg(obj_bounding_radius=1.0, N_samples=64, N_importance=64, N_up
 
 
 class _Workspace:
-    """Caller-owned scratch for nm_render_rays, reused across chunks / frames."""
+    """Caller-owned scratch for nm_render_rays, reused across chunks / frames (one per chunk lane)."""
 
     def __init__(self):
         self.buf = None
+        self.stream = None
 
     def get(self, nbytes: int, device):
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
@@ -62,8 +64,27 @@ class _Workspace:
             self.buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         return self.buf
 
+    def side_stream(self, device):
+        if self.stream is None or self.stream.device != device:
+            self.stream = torch.cuda.Stream(device=device)
+        return self.stream
 
-_WS = _Workspace()
+
+# Ray chunks are independent, and a chunk's launch sequence has under-filled stretches (the per-ray
+# kernels occupy 2 waves per CU, every launch ends in a tail): when a call needs several chunks,
+# consecutive chunks go to alternating HIP streams, each with its own workspace, so that one chunk's
+# tails are filled by the other's kernels (800x800 frame on one MI355X: 65536-ray chunks 1029 ->
+# 909 ms, 327680-ray chunks 951 -> 895 ms; the whole frame as ONE chunk, 925 ms, is single-stream).
+# NEUMESH_RENDER_STREAMS=1 restores the single-stream order.
+_LANES = [_Workspace(), _Workspace()]
+_WS = _LANES[0]
+
+
+def _n_lanes() -> int:
+    try:
+        return max(1, min(len(_LANES), int(os.environ.get("NEUMESH_RENDER_STREAMS", "2"))))
+    except ValueError:
+        return 2
 
 
 def render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int, detailed: bool = False,
@@ -91,13 +112,23 @@ def render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg: _lib.RenderCfg, raysc
     ws_bytes = int(lib.nm_render_workspace_bytes(C.byref(cfg), chunk))
     if ws_bytes < 0:
         _lib.check(1, "nm_render_workspace_bytes")
-    ws = _WS.get(ws_bytes, dev)
+    starts = list(range(0, R, chunk))
+    lanes = _LANES[:min(_n_lanes(), len(starts))]
+    wss = [lane.get(ws_bytes, dev) for lane in lanes]
     field, grid = model.field_handle(), model.mesh_grid.grid.handle
     t, keep = tables if tables is not None else model.field_tables()
     with torch.cuda.device(dev):
-        stream = _lib.current_stream(dev)
-        for i in (range(0, R, chunk) if progress is None else progress(range(0, R, chunk))):
+        main = torch.cuda.current_stream(dev)
+        if len(lanes) > 1:  # fork: the side streams start after everything already queued on the caller's stream
+            side = [lane.side_stream(dev) for lane in lanes]
+            for st in side:
+                st.wait_stream(main)
+            streams = [C.c_void_p(st.cuda_stream) for st in side]
+        else:
+            side, streams = [], [_lib.current_stream(dev)]
+        for ci, i in enumerate(starts if progress is None else progress(starts)):
             n = min(chunk, R - i)
+            ws, stream = wss[ci % len(lanes)], streams[ci % len(lanes)]
             dbg = None
             if detailed:
                 dbg = _lib.RenderDebug()
@@ -112,6 +143,8 @@ def render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg: _lib.RenderCfg, raysc
                 _lib.ptr(out["rgb"][i:]), _lib.ptr(out["depth_volume"][i:]), _lib.ptr(out["mask_volume"][i:]),
                 _lib.ptr(out["normals_volume"][i:]) if cfg.calc_normal else None,
                 C.byref(dbg) if dbg is not None else None, _lib.ptr(ws), stream), "nm_render_rays")
+        for st in side:  # join
+            main.wait_stream(st)
     del keep
     if detailed:
         s = model.forward_s().detach()
