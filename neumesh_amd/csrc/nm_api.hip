@@ -476,6 +476,21 @@ int nm_field_color(nm_field_t f, const float* color_features, const float* ds, c
 }
 
 // ============================================================================== renderer
+// 4-sample tiles a wave chains along its rays in the regular-grid passes (probes, coarse samples):
+// as long as possible (measured on the 800x800 frame: 1 -> 414 ms of K-NN, 8 -> 374, 32 -> 361), but
+// never so long that the launch has fewer than ~4 waves per SIMD of the whole chip.
+static int nm_chain_tiles(long long R, int P) {
+    const char* e = getenv("NEUMESH_CHAIN_TILES");  // upper limit (tests compare 1 against the default)
+    int vmax = e ? atoi(e) : 32;
+    if (vmax < 1) vmax = 1;
+    if (vmax > 64) vmax = 64;
+    const long long tiles_p = (P + 3) / 4, total = ((R + 15) / 16) * tiles_p;
+    long long c = total / 16384;
+    if (c > vmax) c = vmax;
+    if (c > tiles_p) c = tiles_p;
+    return c < 1 ? 1 : (int)c;
+}
+
 // the per-ray kernels keep 64 rays' rows in dynamic LDS (nm_ray_lds_bytes(cap) > 64 KiB for cap >= 110)
 static int nm_ray_lds_prepare(int cap, size_t* bytes) {
     *bytes = nm_ray_lds_bytes(cap);
@@ -565,6 +580,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     const float* nf = ws.nf0;
     if (c->bounded_near_far) {  // renderer.py:66-102
         src.mode = 2;
+        src.chain = nm_chain_tiles(R, c->probe_grid);
         src.P = c->probe_grid;
         src.nearfar = ws.nf0;
         src.depth_out = nullptr;
@@ -593,6 +609,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     const bool want_grad = c->calc_normal != 0;
     const NmGather ga_slots = {t->geometry_features, f->geo.gdim, ws.slots.fg, nullptr, 0, nullptr};
     src.mode = 2;
+    src.chain = nm_chain_tiles(R, c->N_samples);
     src.P = c->N_samples;
     src.nearfar = nf;
     src.depth_out = ws.d;

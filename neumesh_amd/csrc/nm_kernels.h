@@ -31,6 +31,9 @@ struct NmPointSrc {
     // lane -> (ray, sample) assignment by depth buckets (optional, see nm_rays_order_kernel):
     // order[group*64*P + j] = (ray - group*64)*P + p of the j-th sample of the 64-ray group
     const unsigned short* order;
+    // mode 2 only: a wave walks `chain` consecutive 4-sample tiles of its 16 rays (0/1 = one tile) and
+    // warm-starts every tile after the first from the tile before it (see nm_distance_kernel)
+    int chain;
 };
 
 // (r, p) = (ray, sample) of query q = r*P + p, as produced by nm_lane_query (mode 0: r = q, p = 0)
@@ -47,14 +50,14 @@ __device__ __forceinline__ float nm_init_bound(const NmPointSrc& s, long long r,
     return b * b;
 }
 
-__device__ __forceinline__ void nm_fetch_point(const NmPointSrc& s, long long r, int p, float& x, float& y, float& z) {
+__device__ __forceinline__ void nm_fetch_point(const NmPointSrc& s, long long r, int p, float& x, float& y, float& z, float& d) {
     if (s.mode == 0) {
         x = s.xyz[r * 3];
         y = s.xyz[r * 3 + 1];
         z = s.xyz[r * 3 + 2];
+        d = 0.f;
         return;
     }
-    float d;
     if (s.mode == 1) {
         d = s.depth[r * s.dstride + s.doff + p];
     } else {
@@ -190,7 +193,8 @@ __device__ __forceinline__ void nm_knn_wave(const NmGridView& g, float qx, float
 // 16 adjacent rays x 4 consecutive samples (the most compact 64-query footprint, see above);
 // importance samples, which are not regular in depth, go by depth buckets over 64 adjacent rays
 // (s.order); point-wise launches (mode 0) take 64 consecutive points.
-__device__ __forceinline__ bool nm_lane_query(const NmPointSrc& s, long long Q, long long& q, long long& r, int& p) {
+__device__ __forceinline__ int nm_chain_len(const NmPointSrc& s) { return (s.mode == 2 && !s.order && s.chain > 1) ? s.chain : 1; }
+__device__ __forceinline__ bool nm_lane_query(const NmPointSrc& s, long long Q, long long& q, long long& r, int& p, int it = 0) {
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (s.mode == 0) {
@@ -209,8 +213,9 @@ __device__ __forceinline__ bool nm_lane_query(const NmPointSrc& s, long long Q, 
         q = r * s.P + p;
         return rl < 64u && r < R;
     }
-    const long long tiles_p = (s.P + 3) >> 2;
-    const long long rb = wave / tiles_p, sb = wave - rb * tiles_p;
+    const int chain = nm_chain_len(s);
+    const long long tiles_p = ((s.P + 3) >> 2), groups_p = (tiles_p + chain - 1) / chain;
+    const long long rb = wave / groups_p, sb = (wave - rb * groups_p) * chain + it;
     r = rb * 16 + (lane >> 2);
     p = (int)(sb * 4) + (lane & 3);
     q = r * s.P + p;
@@ -220,7 +225,10 @@ static inline unsigned nm_query_blocks(const NmPointSrc& s, long long Q) {
     long long waves;
     if (s.mode == 0) waves = (Q + 63) / 64;
     else if (s.order) waves = ((Q / s.P + 63) / 64) * s.P;
-    else waves = ((Q / s.P + 15) / 16) * ((s.P + 3) / 4);
+    else {
+        const int chain = (s.mode == 2 && s.chain > 1) ? s.chain : 1;
+        waves = ((Q / s.P + 15) / 16) * (((s.P + 3) / 4 + chain - 1) / chain);
+    }
     return (unsigned)((waves + 3) / 4);  // 4 waves per 256-thread block
 }
 
@@ -286,8 +294,8 @@ __global__ __launch_bounds__(256) void nm_knn_kernel(NmGridView g, NmPointSrc sr
     long long q, r;
     int p;
     const bool active = nm_lane_query(src, Q, q, r, p);
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (active) nm_fetch_point(src, r, p, x, y, z);
+    float x = 0.f, y = 0.f, z = 0.f, dep = 0.f;
+    if (active) nm_fetch_point(src, r, p, x, y, z, dep);
     unsigned long long kk[K];
     nm_knn_wave<K>(g, x, y, z, active, kk);
     if (!active) return;
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(256) void nm_knn_kernel(NmGridView g, NmPointSrc sr
 // ------------------------------------------------- K-NN + weights + projected signed distance
 // (models/mesh_grid.py:88-144 fused; nothing of shape [Q,8,3] is ever materialised)
 // Any output pointer may be null.  ds_out is indexed by q (compact).
-__global__ __launch_bounds__(256) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
+__global__ __launch_bounds__(256, 4) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
                                                           const float* __restrict__ verts,
                                                           const float* __restrict__ indicator, float w1,
                                                           float* __restrict__ ds_out, int* __restrict__ idx32_out,
@@ -314,58 +322,76 @@ __global__ __launch_bounds__(256) void nm_distance_kernel(NmGridView g, NmPointS
                                                           float* __restrict__ radius_out,
                                                           const float* __restrict__ geo_table, int gdim, float* __restrict__ fg_out,
                                                           const float* __restrict__ col_table, int cdim, float* __restrict__ ft_out) {
-    long long q, r;
-    int p;
-    const bool active = nm_lane_query(src, Q, q, r, p);
-    float x = 0.f, y = 0.f, z = 0.f, init = NM_INF_F;
-    if (active) {
-        nm_fetch_point(src, r, p, x, y, z);
-        init = nm_init_bound(src, r, p);
-    }
-    float bd[8], wk[8], gr[3];
-    int bi[8];
-    {
-        unsigned long long kk[8];
-        nm_knn_wave<8>(g, x, y, z, active, kk, init);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            bd[k] = nm_key_d2(kk[k]);
-            bi[k] = nm_key_idx(kk[k]);
+    // Chained tiles (regular depth grids: probes, coarse samples): the wave walks `chain` consecutive
+    // 4-sample tiles of its 16 rays; from the second tile on every lane starts its search from a
+    // proven bound -- the K-th-neighbour radius of the LAST sample of the previous tile on the same
+    // ray plus the depth gap to it (triangle inequality along a unit direction) -- instead of +INF.
+    const int chain = nm_chain_len(src);
+    const int lane = threadIdx.x & 63;
+    float prev_rad = NM_INF_F, prev_dep = 0.f;
+    for (int it = 0; it < chain; ++it) {
+        long long q, r;
+        int p;
+        const bool active = nm_lane_query(src, Q, q, r, p, it);
+        float x = 0.f, y = 0.f, z = 0.f, dep = 0.f, init = NM_INF_F;
+        if (active) {
+            nm_fetch_point(src, r, p, x, y, z, dep);
+            init = nm_init_bound(src, r, p);
         }
-    }
-    float ds = 0.f;
-    long long o = 0;
-    if (active) {
-        ds = nm_projected_distance8(x, y, z, bd, bi, verts, indicator, w1, wk, grad_out ? gr : nullptr);
-        o = nm_out_index(src, q, r, p);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            bi[k] = 0;
-            wk[k] = 0.f;
+        if (chain > 1) {
+            const float pr = __shfl(prev_rad, lane | 3), pd = __shfl(prev_dep, lane | 3);
+            if (it > 0 && pr < NM_INF_F) {
+                const float b = (pr + fabsf(dep - pd)) * 1.0001f + 1e-5f;
+                init = fminf(init, b * b);
+            }
         }
-    }
-    if (fg_out) nm_gather_interp(geo_table, gdim, bi, wk, active, o, fg_out);
-    if (ft_out) nm_gather_interp(col_table, cdim, bi, wk, active, o, ft_out);
-    if (!active) return;
-    if (ds_out) ds_out[o] = ds;
-    if (radius_out) radius_out[o] = nm_sqrt(bd[7]);
-    if (idx32_out) {
-        *reinterpret_cast<int4*>(idx32_out + o * 8) = make_int4(bi[0], bi[1], bi[2], bi[3]);
-        *reinterpret_cast<int4*>(idx32_out + o * 8 + 4) = make_int4(bi[4], bi[5], bi[6], bi[7]);
-    }
-    if (idx64_out) {
+        float bd[8], wk[8], gr[3];
+        int bi[8];
+        {
+            unsigned long long kk[8];
+            nm_knn_wave<8>(g, x, y, z, active, kk, init);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) idx64_out[o * 8 + k] = (long long)bi[k];
-    }
-    if (w_out) {
-        *reinterpret_cast<float4*>(w_out + o * 8) = make_float4(wk[0], wk[1], wk[2], wk[3]);
-        *reinterpret_cast<float4*>(w_out + o * 8 + 4) = make_float4(wk[4], wk[5], wk[6], wk[7]);
-    }
-    if (grad_out) {
-        grad_out[o * 3] = gr[0];
-        grad_out[o * 3 + 1] = gr[1];
-        grad_out[o * 3 + 2] = gr[2];
+            for (int k = 0; k < 8; ++k) {
+                bd[k] = nm_key_d2(kk[k]);
+                bi[k] = nm_key_idx(kk[k]);
+            }
+        }
+        prev_rad = (active && bi[7] != 0x7fffffff) ? nm_sqrt(bd[7]) : NM_INF_F;
+        prev_dep = dep;
+        float ds = 0.f;
+        long long o = 0;
+        if (active) {
+            ds = nm_projected_distance8(x, y, z, bd, bi, verts, indicator, w1, wk, grad_out ? gr : nullptr);
+            o = nm_out_index(src, q, r, p);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                bi[k] = 0;
+                wk[k] = 0.f;
+            }
+        }
+        if (fg_out) nm_gather_interp(geo_table, gdim, bi, wk, active, o, fg_out);
+        if (ft_out) nm_gather_interp(col_table, cdim, bi, wk, active, o, ft_out);
+        if (!active) continue;
+        if (ds_out) ds_out[o] = ds;
+        if (radius_out) radius_out[o] = nm_sqrt(bd[7]);
+        if (idx32_out) {
+            *reinterpret_cast<int4*>(idx32_out + o * 8) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+            *reinterpret_cast<int4*>(idx32_out + o * 8 + 4) = make_int4(bi[4], bi[5], bi[6], bi[7]);
+        }
+        if (idx64_out) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) idx64_out[o * 8 + k] = (long long)bi[k];
+        }
+        if (w_out) {
+            *reinterpret_cast<float4*>(w_out + o * 8) = make_float4(wk[0], wk[1], wk[2], wk[3]);
+            *reinterpret_cast<float4*>(w_out + o * 8 + 4) = make_float4(wk[4], wk[5], wk[6], wk[7]);
+        }
+        if (grad_out) {
+            grad_out[o * 3] = gr[0];
+            grad_out[o * 3 + 1] = gr[1];
+            grad_out[o * 3 + 2] = gr[2];
+        }
     }
 }
 
@@ -549,7 +575,8 @@ __global__ void nm_rays_points_kernel(NmPointSrc src, long long Q, float* __rest
     if (q >= Q) return;
     float x, y, z;
     const long long r = q / src.P;
-    nm_fetch_point(src, r, (int)(q - r * src.P), x, y, z);
+    float dep;
+    nm_fetch_point(src, r, (int)(q - r * src.P), x, y, z, dep);
     xyz[3 * q] = x;
     xyz[3 * q + 1] = y;
     xyz[3 * q + 2] = z;

@@ -370,3 +370,23 @@ def test_render_frame_properties_dtu_scale(dtu_scale, cuda_device, torch_mod):
     np.testing.assert_allclose(acc.cpu().numpy()[sub], out["mask_volume"], atol=1e-4)
     np.testing.assert_allclose(depth.cpu().numpy()[sub], out["depth_volume"], atol=2e-4)
     assert compare.psnr(rgb.cpu().numpy()[sub], out["rgb"]) > 90.0
+    # chained, warm-started tiles of the regular-grid passes (active from 8192 rays per call) must not
+    # change a bit relative to independent tiles
+    rows = np.arange(336, 464)
+    pix = (rows[:, None] * W + np.arange(336, 464)[None, :]).reshape(-1)
+    o, d = synthetic.camera_rays(c2w, K, H, W)
+    o, d = o[pix], d[pix]
+    import os
+    old = os.environ.get("NEUMESH_CHAIN_TILES")
+    try:
+        with torch.no_grad():
+            os.environ["NEUMESH_CHAIN_TILES"] = "1"
+            a_rgb, a_depth, a_ex = volume_render(_t(o, cuda_device), _t(d, cuda_device), model, rayschunk=16384, **kw)
+            os.environ["NEUMESH_CHAIN_TILES"] = "32"
+            b_rgb, b_depth, b_ex = volume_render(_t(o, cuda_device), _t(d, cuda_device), model, rayschunk=16384, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("NEUMESH_CHAIN_TILES", None)
+        else:
+            os.environ["NEUMESH_CHAIN_TILES"] = old
+    assert torch.equal(a_rgb, b_rgb) and torch.equal(a_depth, b_depth) and torch.equal(a_ex["normals_volume"], b_ex["normals_volume"])
