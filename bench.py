@@ -105,8 +105,107 @@ def cpu_baseline(mesh, model, H, W, n_rays, gpu_rgb_frame0, rays0=None):
     return res, parity
 
 
+def stress5(args):
+    """BASELINE config 5, the HBM-bound case of the path: V = 1 000 000 vertices, one 256-d
+    vertex feature table, kernels = K-NN + gather-interpolate only (nm_distance_interpolate), queries =
+    the 4096x4096 rays of a frame, one point per ray where it meets the surface shell.  One step = one
+    such frame, in slabs of 256 image rows (the 1 KiB/query output of a slab is 1 GiB)."""
+    import torch
+    import torch.distributed as dist
+    from neumesh_amd import _lib, synthetic
+    from neumesh_amd.mesh_grid import MeshGrid
+    from neumesh_amd.rays import make_rays
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    lib = _lib.load()
+    V, dim, H, W, slab = 1_000_000, 256, 4096, 4096, 256
+    mesh = synthetic.fibonacci_blob(V)
+    grid = MeshGrid(_Mesh(mesh), dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    table = torch.randn((V, dim), generator=gen, device=dev)
+    ind = grid.vertex_normals.contiguous()
+    K = synthetic.pinhole_intrinsics(H, W)
+    total = args.warmup + args.steps
+    feat = torch.empty((slab * W, dim), device=dev)
+    ds = torch.empty((slab * W,), device=dev)
+
+    def frame_points(f):  # resident before timing: [H*W,3] points on the r = 0.75 shell along the rays of frame f
+        o, d = make_rays(synthetic.orbit_pose(f * world + rank), K, H, W, dev)
+        d = torch.nn.functional.normalize(d, dim=-1)
+        b = (o * d).sum(-1)
+        t = -b - torch.sqrt(torch.clamp(b * b - ((o * o).sum(-1) - 0.75 ** 2), min=0.0))
+        return (o + t[:, None] * d).contiguous()
+
+    pts = [frame_points(f) for f in range(total)]
+    stream = _lib.current_stream(dev)
+
+    def step(i):
+        for r0 in range(0, H, slab):
+            q = pts[i][r0 * W:(r0 + slab) * W]
+            _lib.check(lib.nm_distance_interpolate(grid.grid.handle, _lib.ptr(q), q.shape[0], _lib.ptr(ind), 0.1, _lib.ptr(table), dim,
+                                                   _lib.ptr(ds), None, None, _lib.ptr(feat), stream), "nm_distance_interpolate")
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    lib.nm_profile_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms, n, u = C.c_double(), C.c_int64(), C.c_int64()
+    _lib.check(lib.nm_profile_read(0, C.byref(ms), C.byref(n), C.byref(u)), "nm_profile_read")
+    lib.nm_profile_enable(0)
+    if rank == 0:
+        bytes_q = 12 + 8 * dim * 4          # SURVEY 8d: query + 8 gathered rows (the 4*dim-byte output row is extra)
+        per_launch_q = u.value / max(n.value, 1)
+        avg_ms = ms.value / max(n.value, 1)
+        achieved = per_launch_q * bytes_q / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_stress5.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("knn_distance", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        print(json.dumps({
+            "metric": "K-NN + gather-interpolate queries/sec, 1M-vertex mesh x 256-d features, 4096x4096 rays (BASELINE config 5)",
+            "value": world * H * W * args.steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"stress5: V={V}, {dim}-d table ({V * dim * 4 / 2**30:.2f} GiB), {H}x{W} queries per step per GPU in slabs of {slab} rows",
+                       "parallelism": f"queries sharded: {world} GPU(s) x 1 frame per step, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "nm_distance_kernel<false> (K-NN + weights + 8-row gather-interpolate)",
+                         "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                         "bytes_per_query": bytes_q, "written_bytes_per_query_not_counted": dim * 4 + 4,
+                         "avg_launch_ms": avg_ms, "launches": n.value, "traffic": traffic}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=["frame", "stress5"], default="frame",
+                    help="frame = BASELINE configs[1], the headline 800x800x128 render (default); stress5 = BASELINE configs[4], "
+                         "the HBM-bound K-NN + 256-d gather stress (a second roofline, not the headline metric)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -119,6 +218,8 @@ def main():
                     help="MLP arithmetic: split-half f16 MFMA (default; 22-bit operands, fp32 accumulation) or fp32 MFMA")
     ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU-baseline sample (0 disables)")
     args = ap.parse_args()
+    if args.workload == "stress5":
+        return stress5(args)
 
     import torch
     import torch.distributed as dist

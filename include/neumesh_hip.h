@@ -18,6 +18,8 @@
  *   nm_grid_create        frnn.frnn_grid_points(..., grid=None)  models/mesh_grid.py:64-74
  *   nm_knn                frnn.frnn_grid_points(..., grid=g)     models/mesh_grid.py:109-119
  *   nm_compute_distance   MeshGrid.compute_distance_frnn         models/mesh_grid.py:88-144
+ *   nm_distance_interpolate  compute_distance_frnn + interpolation(features, indices, weights)
+ *                                                 mesh_grid.py:88-144 + neumesh.py:11-13
  *   nm_field_density      NeuMesh.forward_density_only / forward_with_nablas
  *                                                 models/frameworks/neumesh/neumesh.py:140-154
  *   nm_field_forward      NeuMesh.forward                        neumesh.py:113-138
@@ -80,6 +82,15 @@ int nm_compute_distance(nm_grid_t g, const float* q_device, int64_t Q,
                         const float* indicator_device, float w1, int K, float* ds_device,
                         int64_t* idx_device, float* w_device, float* dds_dx_device,
                         nm_stream_t stream);
+
+/* nm_compute_distance followed by interpolation(table, idx, w) = sum_k table[idx_k] * w_k
+ * (models/frameworks/neumesh/neumesh.py:11-13) in the same kernel: the wave that found the
+ * neighbours gathers their rows.  table: device [V,dim] fp32, dim a multiple of 4 (any width: the
+ * 256-d stress table of BASELINE config 5 included); feat: device [Q,dim].  ds / idx / w may be NULL. */
+int nm_distance_interpolate(nm_grid_t g, const float* q_device, int64_t Q,
+                            const float* indicator_device, float w1, const float* table_device,
+                            int dim, float* ds_device, int64_t* idx_device, float* w_device,
+                            float* feat_device, nm_stream_t stream);
 
 /* ----------------------------------------------------------------------------------- field
  * Dense layers are given as PyTorch stores nn.Linear: weight [out,in] row-major, bias [out]

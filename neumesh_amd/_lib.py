@@ -65,6 +65,7 @@ SIGNATURES = {
     "nm_grid_get_info": (C.c_int, [_P, C.POINTER(GridInfo)]),
     "nm_knn": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P, _P]),
     "nm_compute_distance": (C.c_int, [_P, _P, C.c_int64, _P, C.c_float, C.c_int, _P, _P, _P, _P, _P]),
+    "nm_distance_interpolate": (C.c_int, [_P, _P, C.c_int64, _P, C.c_float, _P, C.c_int, _P, _P, _P, _P, _P]),
     "nm_field_create": (C.c_int, [C.POINTER(FieldDesc), _P, C.POINTER(_P)]),
     "nm_field_update": (C.c_int, [_P, C.POINTER(FieldDesc), _P]),
     "nm_field_destroy": (C.c_int, [_P]),

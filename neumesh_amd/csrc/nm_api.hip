@@ -198,8 +198,12 @@ static int nm_launch_distance(nm_grid_t g, const NmPointSrc& src, long long Q, c
                               float* radius = nullptr, NmGather ga = NM_NO_GATHER) {
     if (Q <= 0) return 0;
     NmProfScope prof(NM_K_DISTANCE, Q, stream);
-    hipLaunchKernelGGL(nm_distance_kernel, dim3(nm_query_blocks(src, Q)), dim3(256), 0, stream, g->view, src, Q, g->verts,
-                       indicator, w1, ds, idx32, idx64, w, grad, radius, ga.geo_table, ga.gdim, ga.fg, ga.col_table, ga.cdim, ga.ft);
+    if (nm_chain_len(src) > 1)
+        hipLaunchKernelGGL(nm_distance_kernel<true>, dim3(nm_query_blocks(src, Q)), dim3(256), 0, stream, g->view, src, Q, g->verts,
+                           indicator, w1, ds, idx32, idx64, w, grad, radius, ga.geo_table, ga.gdim, ga.fg, ga.col_table, ga.cdim, ga.ft);
+    else
+        hipLaunchKernelGGL(nm_distance_kernel<false>, dim3(nm_query_blocks(src, Q)), dim3(256), 0, stream, g->view, src, Q, g->verts,
+                           indicator, w1, ds, idx32, idx64, w, grad, radius, ga.geo_table, ga.gdim, ga.fg, ga.col_table, ga.cdim, ga.ft);
     NM_LAUNCH_CHECK();
     return 0;
 }
@@ -214,6 +218,18 @@ int nm_compute_distance(nm_grid_t g, const float* q, int64_t Q, const float* ind
     if (g->view.V < 8) return nm_fail("nm_compute_distance: mesh has %d < 8 vertices", g->view.V);
     if (Q < 0) return nm_fail("nm_compute_distance: Q<0");
     return nm_launch_distance(g, nm_src_xyz(q), Q, indicator, w1, ds, nullptr, reinterpret_cast<long long*>(idx), w, dds_dx, stream);
+}
+
+int nm_distance_interpolate(nm_grid_t g, const float* q, int64_t Q, const float* indicator, float w1, const float* table,
+                            int dim, float* ds, int64_t* idx, float* w, float* feat, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Q == 0) return 0;
+    if (!g || !q || !indicator || !table || !feat) return nm_fail("nm_distance_interpolate: NULL argument");
+    if (Q < 0) return nm_fail("nm_distance_interpolate: Q<0");
+    if (dim < 4 || dim % 4) return nm_fail("nm_distance_interpolate: dim=%d must be a positive multiple of 4", dim);
+    if (g->view.V < 8) return nm_fail("nm_distance_interpolate: mesh has %d < 8 vertices", g->view.V);
+    const NmGather ga = {table, dim, feat, nullptr, 0, nullptr};
+    return nm_launch_distance(g, nm_src_xyz(q), Q, indicator, w1, ds, nullptr, reinterpret_cast<long long*>(idx), w, nullptr, stream, nullptr, ga);
 }
 
 // =============================================================================== field

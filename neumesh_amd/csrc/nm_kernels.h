@@ -193,7 +193,7 @@ __device__ __forceinline__ void nm_knn_wave(const NmGridView& g, float qx, float
 // 16 adjacent rays x 4 consecutive samples (the most compact 64-query footprint, see above);
 // importance samples, which are not regular in depth, go by depth buckets over 64 adjacent rays
 // (s.order); point-wise launches (mode 0) take 64 consecutive points.
-__device__ __forceinline__ int nm_chain_len(const NmPointSrc& s) { return (s.mode == 2 && !s.order && s.chain > 1) ? s.chain : 1; }
+__host__ __device__ __forceinline__ int nm_chain_len(const NmPointSrc& s) { return (s.mode == 2 && !s.order && s.chain > 1) ? s.chain : 1; }
 __device__ __forceinline__ bool nm_lane_query(const NmPointSrc& s, long long Q, long long& q, long long& r, int& p, int it = 0) {
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256) void nm_knn_kernel(NmGridView g, NmPointSrc sr
 // ------------------------------------------------- K-NN + weights + projected signed distance
 // (models/mesh_grid.py:88-144 fused; nothing of shape [Q,8,3] is ever materialised)
 // Any output pointer may be null.  ds_out is indexed by q (compact).
+template <bool CHAIN>
 __global__ __launch_bounds__(256, 4) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
                                                           const float* __restrict__ verts,
                                                           const float* __restrict__ indicator, float w1,
@@ -326,7 +327,8 @@ __global__ __launch_bounds__(256, 4) void nm_distance_kernel(NmGridView g, NmPoi
     // 4-sample tiles of its 16 rays; from the second tile on every lane starts its search from a
     // proven bound -- the K-th-neighbour radius of the LAST sample of the previous tile on the same
     // ray plus the depth gap to it (triangle inequality along a unit direction) -- instead of +INF.
-    const int chain = nm_chain_len(src);
+    // (CHAIN = false is the plain single-tile kernel: no loop-carried state in its registers)
+    const int chain = CHAIN ? nm_chain_len(src) : 1;
     const int lane = threadIdx.x & 63;
     float prev_rad = NM_INF_F, prev_dep = 0.f;
     for (int it = 0; it < chain; ++it) {
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256, 4) void nm_distance_kernel(NmGridView g, NmPoi
             nm_fetch_point(src, r, p, x, y, z, dep);
             init = nm_init_bound(src, r, p);
         }
-        if (chain > 1) {
+        if (CHAIN) {
             const float pr = __shfl(prev_rad, lane | 3), pd = __shfl(prev_dep, lane | 3);
             if (it > 0 && pr < NM_INF_F) {
                 const float b = (pr + fabsf(dep - pd)) * 1.0001f + 1e-5f;

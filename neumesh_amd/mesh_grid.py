@@ -134,6 +134,32 @@ class MeshGrid(MeshPrimitive):
                        "nm_compute_distance")
         return (ds, idx, w, g) if want_grad else (ds, idx, w)
 
+    def compute_distance_interpolate(self, xyz, features, indicator_vector=None, indicator_weight=0.1):
+        """compute_distance_frnn(xyz) followed by interpolation(features, indices, weights)
+        (mesh_grid.py:88-144 + neumesh.py:11-13) as ONE kernel (nm_distance_interpolate): the wave that
+        found the neighbours gathers their rows.  features: (V, dim), dim % 4 == 0 (any width).
+        Inference only.  Returns (distance (N,1), indices (N,8), weights (N,8), interpolated (N,dim))."""
+        if torch.is_grad_enabled() and (xyz.requires_grad or features.requires_grad):
+            raise NotImplementedError("compute_distance_interpolate is the fused inference kernel; with autograd use "
+                                      "compute_distance + interpolation")
+        lib = _lib.load()
+        indicator = self.vertex_normals if indicator_vector is None else indicator_vector
+        q = xyz.detach().to(torch.float32).reshape(-1, 3).contiguous()
+        tab = features.detach().to(torch.float32).contiguous()
+        if tab.dim() != 2 or tab.shape[0] != self.vertices.shape[0]:
+            raise ValueError("features must be (V, dim)")
+        Q, dim = q.shape[0], tab.shape[1]
+        ind = indicator.detach().to(torch.float32).contiguous()
+        ds = torch.empty((Q, 1), dtype=torch.float32, device=q.device)
+        idx = torch.empty((Q, 8), dtype=torch.int64, device=q.device)
+        w = torch.empty((Q, 8), dtype=torch.float32, device=q.device)
+        feat = torch.empty((Q, dim), dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            _lib.check(lib.nm_distance_interpolate(self.grid.handle, _lib.ptr(q), Q, _lib.ptr(ind), float(indicator_weight),
+                                                   _lib.ptr(tab), dim, _lib.ptr(ds), _lib.ptr(idx), _lib.ptr(w), _lib.ptr(feat),
+                                                   _lib.current_stream(q.device)), "nm_distance_interpolate")
+        return ds, idx, w, feat
+
     def _compute_distance_autograd(self, xyz, K, indicator, indicator_weight):
         # K-NN on the HIP kernel (detached, like mesh_grid.py:121-122), the rest differentiable
         idx, d2 = knn(self.grid, xyz, K)

@@ -390,3 +390,59 @@ def test_render_frame_properties_dtu_scale(dtu_scale, cuda_device, torch_mod):
         else:
             os.environ["NEUMESH_CHAIN_TILES"] = old
     assert torch.equal(a_rgb, b_rgb) and torch.equal(a_depth, b_depth) and torch.equal(a_ex["normals_volume"], b_ex["normals_volume"])
+
+
+@pytest.mark.gpu
+def test_config5_stress_kernels_1M_vertices_256d(cuda_device, torch_mod):
+    """BASELINE config 5: V = 1 000 000 vertices, one 256-d feature table, kernels = K-NN +
+    gather-interpolate only (nm_distance_interpolate).  Coherent queries (points of adjacent camera
+    rays near the surface) and scattered ones, against the oracle: indices bit-exact, weights / ds /
+    interpolated features within fp32 rounding of the declared arithmetic; linearity of the
+    interpolation in the table as a size-independent property on 2^20 queries."""
+    torch = torch_mod
+    from neumesh_amd import synthetic
+    from neumesh_amd.mesh_grid import MeshGrid
+    from oracle import field as ofield
+    V, dim = 1_000_000, 256
+    mesh = synthetic.fibonacci_blob(V)
+    grid = MeshGrid(mesh, cuda_device)
+    gen = torch.Generator(device=cuda_device)
+    gen.manual_seed(5)
+    table = torch.randn((V, dim), generator=gen, device=cuda_device)
+    # coherent: 64x64 pixel window, one point per ray where the ray meets the r = 0.75 sphere (+ jitter)
+    H = W = 4096
+    c2w, K = synthetic.orbit_pose(2), synthetic.pinhole_intrinsics(H, W)
+    def window(r0, r1, c0, c1):  # rays of the pixel window [r0,r1) x [c0,c1), row-major, unit directions
+        o, d = synthetic.camera_rays(c2w, K, H, W, start=r0 * W, count=(r1 - r0) * W)
+        sel = (np.arange(r1 - r0)[:, None] * W + np.arange(c0, c1)[None, :]).reshape(-1)
+        return o[sel], orender.normalize(d[sel])
+
+    o, d = window(2000, 2064, 2000, 2064)
+    b = (o * d).sum(-1)
+    t_hit = -b - np.sqrt(np.maximum(b * b - ((o * o).sum(-1) - 0.75 ** 2), 0.0))
+    rng = np.random.default_rng(9)
+    q_coh = (o + (t_hit + rng.uniform(-0.02, 0.02, len(o)))[:, None] * d).astype(np.float32)
+    q_sct = (mesh.vertices[rng.integers(0, V, 2048)] + 0.05 * rng.standard_normal((2048, 3))).astype(np.float32)
+    q = np.concatenate([q_coh, q_sct])
+    with torch.no_grad():
+        ds, idx, w, feat = grid.compute_distance_interpolate(_t(q, cuda_device), table)
+    ridx, rd2 = oknn.knn_kdtree(q, mesh.vertices, 8)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+    dis = np.sqrt(rd2)
+    rw = (1.0 / (dis + np.float32(1e-7))).astype(np.float32)
+    rw = (rw / rw.sum(-1, keepdims=True)).astype(np.float32)
+    np.testing.assert_allclose(w.cpu().numpy(), rw, rtol=2e-6, atol=1e-7)
+    rows_needed = table[torch.from_numpy(ridx).to(cuda_device)].cpu().numpy().astype(np.float64)   # [Q,8,dim]
+    rfeat = (rows_needed * rw.astype(np.float64)[..., None]).sum(-2)
+    np.testing.assert_allclose(feat.cpu().numpy(), rfeat, atol=4e-6)
+    # size-independent property on 2^20 coherent queries: interpolation is linear in the table
+    # (same neighbours, same weights): f(2*T) == 2*f(T) bit for bit (scaling by 2 is exact)
+    o2, d2 = window(1536, 2560, 1536, 2560)
+    b2 = (o2 * d2).sum(-1)
+    t2 = -b2 - np.sqrt(np.maximum(b2 * b2 - ((o2 * o2).sum(-1) - 0.75 ** 2), 0.0))
+    q2 = _t((o2 + t2[:, None] * d2).astype(np.float32), cuda_device)
+    with torch.no_grad():
+        _, i1, w1_, f1 = grid.compute_distance_interpolate(q2, table)
+        _, i2, w2_, f2 = grid.compute_distance_interpolate(q2, table * 2.0)
+    assert torch.equal(i1, i2) and torch.equal(w1_, w2_) and torch.equal(f1 * 2.0, f2)
+    assert bool(torch.isfinite(f1).all()) and bool((w1_.sum(-1) - 1.0).abs().max() < 1e-5)
