@@ -446,3 +446,41 @@ def test_config5_stress_kernels_1M_vertices_256d(cuda_device, torch_mod):
         _, i2, w2_, f2 = grid.compute_distance_interpolate(q2, table * 2.0)
     assert torch.equal(i1, i2) and torch.equal(w1_, w2_) and torch.equal(f1 * 2.0, f2)
     assert bool(torch.isfinite(f1).all()) and bool((w1_.sum(-1) - 1.0).abs().max() < 1e-5)
+
+
+@pytest.mark.gpu
+def test_deformed_mesh_grid_swap_like_deform_model(cuda_device, torch_mod):
+    """editing/render_geometry_editing.py:37-67 (deform_model): a new MeshGrid is built on the deformed
+    mesh, assigned to model.mesh_grid, and the indicator vectors are replaced by a new nn.Parameter.
+    The render must then equal a model built on the deformed mesh from scratch, and match the oracle."""
+    torch = torch_mod
+    from neumesh_amd import MeshGrid, synthetic
+    from neumesh_amd.renderer import volume_render
+    mesh = common.scene_mesh(3000)
+    state = common.scene_state(mesh)
+    model = common.make_model(mesh, state, cuda_device)
+    # deformation: anisotropic stretch + shear of the vertices, normals transformed by the inverse transpose
+    A = np.array([[1.15, 0.10, 0.0], [0.0, 0.9, 0.05], [0.0, 0.0, 1.05]], np.float32)
+    dv = (mesh.vertices @ A.T).astype(np.float32)
+    dn = mesh.vertex_normals @ np.linalg.inv(A)
+    dn = (dn / np.linalg.norm(dn, axis=-1, keepdims=True)).astype(np.float32)
+    dmesh = synthetic.SyntheticMesh(dv, dn)
+    new_ind = synthetic.noisy_indicator(dn, 11)
+    o, d = synthetic.camera_rays(synthetic.orbit_pose(1), synthetic.pinhole_intrinsics(64, 64), 64, 64)
+    sel = np.arange(0, 64 * 64, 13)[:256]
+    o, d = o[sel], d[sel]
+    kw = dict(calc_normal=True, N_samples=64, N_importance=64, perturb=False, detailed_output=False, rayschunk=4096)
+    with torch.no_grad():
+        before = volume_render(_t(o, cuda_device), _t(d, cuda_device), model, **kw)[0].clone()
+        model.mesh_grid = MeshGrid(common.MeshObj(dmesh), cuda_device, distance_method=model.mesh_grid.distance_method)
+        model.indicator_vector = torch.nn.Parameter(_t(new_ind, cuda_device))
+        rgb, depth, ex = volume_render(_t(o, cuda_device), _t(d, cuda_device), model, **kw)
+    dstate = dict(state)
+    dstate["indicator_vector"] = new_ind
+    fresh = common.make_model(dmesh, dstate, cuda_device)
+    with torch.no_grad():
+        rgb2, depth2, ex2 = volume_render(_t(o, cuda_device), _t(d, cuda_device), fresh, **kw)
+    assert torch.equal(rgb, rgb2) and torch.equal(depth, depth2) and not torch.equal(rgb, before)
+    out = orender.render_rays(common.make_oracle(dmesh, dstate), o, d, orender.RenderConfig(calc_normal=True))
+    np.testing.assert_allclose(rgb.cpu().numpy(), out["rgb"], atol=1e-4)
+    np.testing.assert_allclose(ex["normals_volume"].cpu().numpy(), out["normals_volume"], atol=2e-4)
