@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 2
+#define NM_ABI_VERSION 3
 #define NM_MAX_K 32
 
 typedef struct nm_grid_s* nm_grid_t;    /* spatial index over the mesh vertices */
@@ -190,7 +190,8 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
  *                     -> xyz [R,P,3] = o + d * dirn
  *   nm_rays_bounds    renderer.py:88-102 from the probes' projected distances ds [R,G]
  *   nm_rays_upsample  merge the m samples appended last time, then draw n_new new depths into
- *                     d[:, n:n+n_new] (renderer.py:209-245,255-258; rend_util.py:276-319)
+ *                     d[:, n:n+n_new] (renderer.py:209-245,255-258; rend_util.py:276-319);
+ *                     perturb=True: the caller passes its torch.rand as u (rend_util.py:300-302)
  *   nm_rays_finalize  last merge + mid-point depths d_mid[:, :n-1] (renderer.py:266)
  *   nm_rays_composite renderer.py:278,302-333 */
 int nm_rays_setup(const float* rays_o, const float* rays_d, int64_t R, float radius, float* dirn,
@@ -201,6 +202,7 @@ int nm_rays_points(const float* rays_o, const float* dirn, int64_t R, int P, int
 int nm_rays_bounds(const float* ds_probe, int64_t R, int G, float thresh, const float* near_far_in,
                    float* near_far_out, nm_stream_t stream);
 int nm_rays_upsample(float* d, float* sdf, int64_t R, int cap, int n, int m, int it, int n_new,
+                     const float* u /* [R,n_new] uniform randoms = sample_pdf(det=False), or NULL = det=True */,
                      nm_stream_t stream);
 int nm_rays_finalize(float* d, float* sdf, int64_t R, int cap, int n, int m, float* d_mid,
                      nm_stream_t stream);

@@ -11,7 +11,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_K = 32
 
 
@@ -79,7 +79,7 @@ SIGNATURES = {
     "nm_rays_setup": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P, _P, _P]),
     "nm_rays_points": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P]),
     "nm_rays_bounds": (C.c_int, [_P, C.c_int64, C.c_int, C.c_float, _P, _P, _P]),
-    "nm_rays_upsample": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "nm_rays_upsample": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "nm_rays_finalize": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P]),
     "nm_rays_composite": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
     "nm_make_rays": (C.c_int, [C.POINTER(Camera), C.c_int64, C.c_int64, _P, _P, _P]),

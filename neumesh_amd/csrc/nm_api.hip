@@ -655,7 +655,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     if (c->N_importance > 0) {
         const int n_new = c->N_importance / c->N_upsample_iters;
         for (int it = 0; it < c->N_upsample_iters; ++it) {
-            hipLaunchKernelGGL(nm_rays_upsample_kernel, rgrid, rblock, ray_lds, stream, ws.d, ws.sdf, ws.slot, ws.radius, ws.bound, (long long)R, cap, n, pending, it, n_new);
+            hipLaunchKernelGGL(nm_rays_upsample_kernel, rgrid, rblock, ray_lds, stream, ws.d, ws.sdf, ws.slot, ws.radius, ws.bound, (long long)R, cap, n, pending, it, n_new, (const float*)nullptr);
             NM_LAUNCH_CHECK();
             src.mode = 1;
             src.P = n_new;
@@ -757,12 +757,12 @@ int nm_rays_bounds(const float* ds_probe, int64_t R, int G, float thresh, const 
     return 0;
 }
 
-int nm_rays_upsample(float* d, float* sdf, int64_t R, int cap, int n, int m, int it, int n_new, nm_stream_t stream_) {
+int nm_rays_upsample(float* d, float* sdf, int64_t R, int cap, int n, int m, int it, int n_new, const float* u, nm_stream_t stream_) {
     if (R < 0 || n < 2 || m < 0 || m > n || n + n_new > cap || cap > NM_MAX_SAMPLES || it < 0 || it > 20 || (R > 0 && (!d || !sdf))) return nm_fail("nm_rays_upsample: bad arguments");
     if (R == 0) return 0;
     size_t ray_lds = 0;
     if (nm_ray_lds_prepare(cap, &ray_lds)) return 1;
-    hipLaunchKernelGGL(nm_rays_upsample_kernel, dim3(nm_blocks(R, 64)), dim3(64), ray_lds, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (float*)nullptr, (long long)R, cap, n, m, it, n_new);
+    hipLaunchKernelGGL(nm_rays_upsample_kernel, dim3(nm_blocks(R, 64)), dim3(64), ray_lds, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (float*)nullptr, (long long)R, cap, n, m, it, n_new, u);
     NM_LAUNCH_CHECK();
     return 0;
 }

@@ -480,7 +480,8 @@ __device__ __forceinline__ void nm_ray_rows_store(const NmRayLds& l, float* __re
 // Launch: 64 threads per block, nm_ray_lds_bytes(cap) dynamic LDS.
 __global__ __launch_bounds__(64) void nm_rays_upsample_kernel(float* __restrict__ d, float* __restrict__ sdf, int* __restrict__ slot,
                                                               const float* __restrict__ radius, float* __restrict__ bound, long long R,
-                                                              int cap, int n, int m, int it, int n_new) {
+                                                              int cap, int n, int m, int it, int n_new,
+                                                              const float* __restrict__ u_rand) {
     extern __shared__ float nm_ray_smem[];
     const NmRayLds l = nm_ray_lds(nm_ray_smem, cap);
     const long long r0 = (long long)blockIdx.x * 64;
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(64) void nm_rays_upsample_kernel(float* __restrict_
     __syncthreads();
     if (r < R)
         nm_ray_upsample(dr, sr, n, it, n_new, dr + n, sr, sr, sl, (sl && radius) ? radius + r * cap : nullptr,
-                        bound ? bound + r * cap + n : nullptr);
+                        bound ? bound + r * cap + n : nullptr, u_rand ? u_rand + r * n_new : nullptr);
     nm_ray_rows_store(l, d, sdf, nullptr, r0, R, cap, n, n + n_new, false);  // the new depths
 }
 

@@ -95,10 +95,12 @@ NM_HD void nm_ray_bounds(const float* ds_probe, int stride, int G, float thresh,
 // slot[j], the position it was generated at) to its K-th nearest vertex; bound_new[i] then receives
 // an upper bound of the K-th-neighbour distance of the i-th new sample: radius of the sample just
 // below it on the same ray + the depth gap (triangle inequality, the direction is a unit vector).
+// u_rand (optional, [n_new]): the stratum positions of sample_pdf(det=False) (rend_util.py:300-302: the
+// caller's torch.rand), in any order; nullptr = det=True, u = linspace(0, 1, n_new).
 template <class SlotT = int>
 NM_HD void nm_ray_upsample(const float* d, const float* sdf, int n, int it, int n_new, float* d_new,
                            float* w, float* cdf, const SlotT* slot = nullptr, const float* radius = nullptr,
-                           float* bound_new = nullptr) {
+                           float* bound_new = nullptr, const float* u_rand = nullptr) {
     const float s = (float)(256 << it);
     float prev_dot = 0.f;
     double T = 1.0;      // cumprod accumulator (float64, rounded to fp32 per element like torch CPU)
@@ -135,7 +137,16 @@ NM_HD void nm_ray_upsample(const float* d, const float* sdf, int n, int it, int 
     }
     int lb = 0;  // searchsorted(cdf, u, right=False); u ascending => monotone lower bound
     for (int i = 0; i < n_new; ++i) {
-        const float u = nm_linspace01(i, n_new);
+        const float u = u_rand ? u_rand[i] : nm_linspace01(i, n_new);
+        if (u_rand) {  // unordered u: binary lower bound
+            int lo = 0, hi = n;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cdf[mid] < u) lo = mid + 1;
+                else hi = mid;
+            }
+            lb = lo;
+        }
         while (lb < n && cdf[lb] < u) ++lb;
         const int below = lb - 1 > 0 ? lb - 1 : 0;
         const int above = lb < n - 1 ? lb : n - 1;

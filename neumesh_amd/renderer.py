@@ -163,14 +163,32 @@ def render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg: _lib.RenderCfg, raysc
     return out
 
 
+class _RestoreGradMode:
+    """The staged renderer switches autograd off for the sample placement of every chunk and back on
+    for the differentiable tail; this puts the caller's mode back even if a stage raises."""
+
+    def __enter__(self):
+        self.mode = torch.is_grad_enabled()
+
+    def __exit__(self, *exc):
+        torch.set_grad_enabled(self.mode)
+        return False
+
+
 def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int, netchunk: int, detailed: bool = False,
-                       progress=None):
+                       progress=None, differentiable: bool = False, perturb: bool = False):
     """render_rayschunk (models/renderer.py:162-350) for ANY object that offers the field methods the
     reference's renderer calls -- compute_distance / forward_density_only / forward_with_nablas /
     forward / forward_s -- e.g. the editing tools' TextureEditableNeuMesh wrapper
     (editing/texture_neumesh/texture_neumesh.py:41-122).  Every per-ray stage runs as the same HIP
     kernel the fused path uses (C ABI nm_rays_*); between the stages the field is queried through the
-    model's own methods, in chunks of `netchunk` points like train_util.batchify_query."""
+    model's own methods, in chunks of `netchunk` points like train_util.batchify_query.
+
+    differentiable=True is the training form (trainer.py:75-81): the sample placement runs exactly as
+    above under torch.no_grad() (as in the reference, renderer.py:200-259), then the field is queried at
+    the final points WITH autograd and alpha / weights / compositing are torch ops (renderer.py:264-333),
+    so gradients reach every model parameter.  perturb=True draws the importance samples with
+    sample_pdf(det=False) (torch.rand handed to nm_rays_upsample)."""
     lib = _lib.load()
     dev = rays_o.device
     rays_o = rays_o.detach().float().reshape(-1, 3).contiguous()
@@ -191,12 +209,14 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
 
     chunks = []
     rng = range(0, Rall, max(1, int(rayschunk)))
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _RestoreGradMode():
         st = _lib.current_stream(dev)
         for i in (rng if progress is None else progress(rng)):
             ro, rd = rays_o[i:i + rayschunk].contiguous(), rays_d[i:i + rayschunk].contiguous()
             R = ro.shape[0]
             f32 = dict(dtype=torch.float32, device=dev)
+            grad_was = torch.is_grad_enabled()
+            torch.set_grad_enabled(False)   # sample placement never carries gradients (renderer.py:200)
             dirn, nf0 = torch.empty((R, 3), **f32), torch.empty((R, 2), **f32)
             _lib.check(lib.nm_rays_setup(_lib.ptr(ro), _lib.ptr(rd), R, cfg.obj_bounding_radius, _lib.ptr(dirn), _lib.ptr(nf0), st), "nm_rays_setup")
             nf = nf0
@@ -221,7 +241,8 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
             if Ni > 0:
                 n_new = Ni // iters
                 for it in range(iters):
-                    _lib.check(lib.nm_rays_upsample(_lib.ptr(d), _lib.ptr(sdf), R, N, n, pending, it, n_new, st), "nm_rays_upsample")
+                    u = torch.rand((R, n_new), **f32) if perturb else None
+                    _lib.check(lib.nm_rays_upsample(_lib.ptr(d), _lib.ptr(sdf), R, N, n, pending, it, n_new, _lib.ptr(u), st), "nm_rays_upsample")
                     pts = torch.empty((R, n_new, 3), **f32)
                     _lib.check(lib.nm_rays_points(_lib.ptr(ro), _lib.ptr(dirn), R, n_new, 1, None, _lib.ptr(d), N, n, None, _lib.ptr(pts), st), "nm_rays_points")
                     sdf[:, n:n + n_new] = query(model.forward_density_only, pts)[0].reshape(R, n_new)
@@ -230,6 +251,10 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
             _lib.check(lib.nm_rays_finalize(_lib.ptr(d), _lib.ptr(sdf), R, N, n, pending, _lib.ptr(dmid), st), "nm_rays_finalize")
             pts = torch.empty((R, N, 3), **f32)
             _lib.check(lib.nm_rays_points(_lib.ptr(ro), _lib.ptr(dirn), R, N, 1, None, _lib.ptr(d), N, 0, None, _lib.ptr(pts), st), "nm_rays_points")
+            torch.set_grad_enabled(grad_was)
+            if differentiable:
+                chunks.append(_composite_autograd(model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf))
+                continue
             nablas = None
             if cfg.calc_normal:
                 s_all, nablas = query(model.forward_with_nablas, pts)
@@ -260,6 +285,38 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
     return OrderedDict((k, torch.cat([c[k] for c in chunks], 0)) for k in chunks[0])
 
 
+def _composite_autograd(model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf):
+    """renderer.py:264-348 as differentiable torch ops on the (detached) sample depths d [R,N]."""
+    R, N = d.shape
+    nablas = None
+    if cfg.calc_normal:
+        sdf, nablas = query(model.forward_with_nablas, pts)
+    else:
+        sdf = query(model.forward_density_only, pts)[0]
+    sdf = sdf.reshape(R, N)
+    cdf, alpha = sdf_to_alpha(sdf, model.forward_s())
+    pm = ro[:, None, :] + dmid[:, :N - 1, None] * dirn[:, None, :]
+    view = dirn[:, None, :].expand(R, N - 1, 3)
+    _, radiance = query(lambda x, v: model.forward(x, v)[:2], pm, view)
+    w = alpha_to_w(alpha)
+    rgb = torch.sum(w[..., None] * radiance, dim=-2)
+    d_final = dmid[:, :N - 1]
+    depth = torch.sum(w / (w.sum(-1, keepdim=True) + 1e-10) * d_final, dim=-1)
+    acc = torch.sum(w, -1)
+    if cfg.white_bkgd:
+        rgb = rgb + (1.0 - acc[..., None])
+    ret = OrderedDict(rgb=rgb, depth_volume=depth, mask_volume=acc)
+    if cfg.calc_normal:
+        nn_ = torch.nn.functional.normalize(nablas[:, :N - 1], dim=-1)
+        ret["normals_volume"] = (nn_ * w[..., None]).sum(dim=-2)
+    if detailed:
+        if cfg.calc_normal:
+            ret["implicit_nablas"] = nablas
+        ret.update(implicit_surface=sdf, radiance=radiance, alpha=alpha, cdf=cdf, visibility_weights=w,
+                   d_final=d_final, d_all=d, near_far=nf)
+    return ret
+
+
 def volume_render(rays_o, rays_d, model, obj_bounding_radius=1.0, batched=False, batched_info={},
                   calc_normal=False, use_view_dirs=True, rayschunk=65536, netchunk=1048576, white_bkgd=False,
                   near_bypass: Optional[float] = None, far_bypass: Optional[float] = None, detailed_output=True,
@@ -272,13 +329,12 @@ def volume_render(rays_o, rays_d, model, obj_bounding_radius=1.0, batched=False,
         lead = [B, -1]
     else:
         lead = [-1]
-    if torch.is_grad_enabled() or perturb or samples_output or random_color_direction or not use_view_dirs:
+    if samples_output or random_color_direction or not use_view_dirs:
         raise NotImplementedError(
-            "neumesh_amd.volume_render implements the inference path of the reference's renderer (torch.no_grad(), "
-            "perturb=False, no samples_output / random_color_direction): what render.py and the editing renders call. "
-            "The training renderer (stratified sampling, autograd through the compositing) is the next row of "
-            "SURVEY.md section 8(f).")
-    fused = isinstance(model, NeuMesh)   # plain NeuMesh field: everything in one C call per chunk
+            "neumesh_amd.volume_render: samples_output / random_color_direction / use_view_dirs=False are not implemented "
+            "(unused by render.py, the editing renders and the default training configuration)")
+    training = torch.is_grad_enabled() or perturb   # trainer.py:75-81: autograd through the field + compositing
+    fused = isinstance(model, NeuMesh) and not training   # plain NeuMesh field, inference: one C call per chunk
     cfg = make_render_cfg(obj_bounding_radius, N_samples, N_importance, N_upsample_iters, bounded_near_far, calc_normal,
                           white_bkgd, near_bypass, far_bypass)
     progress = None
@@ -293,7 +349,8 @@ def volume_render(rays_o, rays_d, model, obj_bounding_radius=1.0, batched=False,
     if fused:
         ret = render_rays_fused(model, flat_o, flat_d, cfg, rayschunk, detailed=detailed_output, progress=progress)
     else:   # wrapper model (editing tools): per-ray stages on HIP, field through the wrapper's methods
-        ret = render_rays_staged(model, flat_o, flat_d, cfg, rayschunk, netchunk, detailed=detailed_output, progress=progress)
+        ret = render_rays_staged(model, flat_o, flat_d, cfg, rayschunk, netchunk, detailed=detailed_output, progress=progress,
+                                 differentiable=torch.is_grad_enabled(), perturb=perturb)
     for k in list(ret.keys()):
         v = ret[k]
         ret[k] = v.reshape(*lead, *v.shape[1:]) if batched else v

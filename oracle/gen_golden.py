@@ -191,6 +191,42 @@ def gen_render_fixture(tag, V, H, W, frame, seed=0, white_bkgd=False, n_samples=
     return model
 
 
+def gen_grad_fixture(tag, render_tag, V, mlp_state):
+    """Training-side parity: the reference renderer WITH autograd on the rays of an
+    existing render fixture, a fixed scalar loss, and d loss / d parameter for every model parameter."""
+    import torch
+    print(f"[{tag}] gradients of the reference renderer, rays of {render_tag}")
+    rf = np.load(os.path.join(GOLDEN, f"{render_tag}.npz"))
+    mesh = synthetic.fibonacci_blob(V)
+    model, kw, renderer, _ = harness.build_reference(mesh, seed=0, mlp_state=mlp_state)
+    rays_o, rays_d = rf["rays_o"], rf["rays_d"]
+    kw = dict(kw)
+    kw.update(rayschunk=rays_o.shape[0], white_bkgd=bool(rf["white_bkgd"]), N_samples=int(rf["N_samples"]),
+              N_importance=int(rf["N_samples"]), perturb=False, calc_normal=True)
+    rng = np.random.default_rng(77)
+    w_rgb = rng.uniform(0.5, 1.5, (rays_o.shape[0], 3)).astype(np.float32)
+    w_n = rng.uniform(-1.0, 1.0, (rays_o.shape[0], 3)).astype(np.float32)
+    model.train()
+    rgb, depth, ex = renderer(torch.from_numpy(rays_o)[None], torch.from_numpy(rays_d)[None], detailed_output=False, **kw)
+    loss = (rgb[0] * torch.from_numpy(w_rgb)).sum() + 0.1 * depth.sum() + 0.05 * ex["mask_volume"].sum() \
+        + 0.02 * (ex["normals_volume"][0] * torch.from_numpy(w_n)).sum()
+    loss.backward()
+    grads = {}   # large matrices: Frobenius norm + the 48 rows of largest gradient norm (keeps the fixture small)
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach().numpy().astype(np.float32)
+        grads["norm." + name] = np.float32(np.linalg.norm(g.astype(np.float64)))
+        if g.ndim == 2 and g.size > 4096:
+            rows = np.sort(np.argsort(-np.linalg.norm(g, axis=1))[:48]).astype(np.int32)
+            grads["rows." + name] = rows
+            g = g[rows]
+        grads["grad." + name] = g
+    print(f"    loss {float(loss):.6f}; {len(grads)} parameter gradients; |grad ln_s| = {abs(float(grads['grad.ln_s'])):.4e}")
+    np.savez_compressed(os.path.join(GOLDEN, f"{tag}.npz"), loss=np.float32(loss.item()), w_rgb=w_rgb, w_n=w_n,
+                        rgb=rgb[0].detach().numpy(), **grads)
+
+
 def gen_rays_fixture():
     """rend_util.get_rays of the reference (utils/rend_util.py:123-176) for a skewed pin-hole camera."""
     import torch
@@ -221,6 +257,7 @@ def main():
     gen_field_fixture("field_dup_v1200", V=1200, Q=512, seed=12, dup=64, mlp_state=sd)
     gen_render_fixture("render_v3000_dtu", V=3000, H=6, W=12, frame=3, mlp_state=sd)
     gen_render_fixture("render_v3000_lego", V=3000, H=4, W=12, frame=17, white_bkgd=True, n_samples=32, mlp_state=sd)
+    gen_grad_fixture("grad_v3000_dtu", "render_v3000_dtu", V=3000, mlp_state=sd)
     with open(os.path.join(GOLDEN, "REPORT.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
     print("all oracle-vs-reference checks passed; fixtures written to", GOLDEN)

@@ -84,16 +84,22 @@ def alpha_to_w(alpha):
     return (alpha * T[..., :-1]).astype(F32)
 
 
-def sample_pdf_det(bins, weights, n_importance: int, eps: float = 1e-5):
-    """utils/rend_util.py:276-319 with det=True."""
+def sample_pdf_det(bins, weights, n_importance: int, eps: float = 1e-5, u=None):
+    """utils/rend_util.py:276-319 with det=True; u [...,n_importance] given = det=False with the
+    caller's uniform randoms in place of torch.rand (:293-296)."""
     weights = weights + F32(1e-5)
     pdf = weights / np.sum(weights, axis=-1, keepdims=True, dtype=F32)
     cdf = np.empty(pdf.shape[:-1] + (pdf.shape[-1] + 1,), F32)
     cdf[..., 0] = 0
     cdf[..., 1:] = np.cumsum(pdf.astype(np.float64), axis=-1).astype(F32)  # float64 accumulator, see alpha_to_w
-    u = torch_linspace01(n_importance)
     flat_cdf = cdf.reshape(-1, cdf.shape[-1])
-    inds = np.stack([np.searchsorted(row, u, side="left") for row in flat_cdf]).reshape(cdf.shape[:-1] + (n_importance,))
+    if u is None:
+        u = torch_linspace01(n_importance)
+        inds = np.stack([np.searchsorted(row, u, side="left") for row in flat_cdf])
+    else:
+        u = np.ascontiguousarray(u, dtype=F32)
+        inds = np.stack([np.searchsorted(row, ur, side="left") for row, ur in zip(flat_cdf, u.reshape(-1, n_importance))])
+    inds = inds.reshape(cdf.shape[:-1] + (n_importance,))
     below = np.maximum(inds - 1, 0)
     above = np.minimum(inds, cdf.shape[-1] - 1)
     cdf_b = np.take_along_axis(cdf, below, axis=-1)
@@ -137,7 +143,7 @@ class RenderConfig:
     white_bkgd: bool = False
 
 
-def upsample_step(d, sdf, it: int, n_new: int):
+def upsample_step(d, sdf, it: int, n_new: int, u=None):
     """One iteration of the up-sampling loop, models/renderer.py:209-245 (weights -> d_fine)."""
     prev_sdf, next_sdf = sdf[..., :-1], sdf[..., 1:]
     prev_z, next_z = d[..., :-1], d[..., 1:]
@@ -153,7 +159,7 @@ def upsample_step(d, sdf, it: int, n_new: int):
     next_cdf = sigmoid(next_esti * s)
     alpha = (prev_cdf - next_cdf + F32(1e-5)) / (prev_cdf + F32(1e-5))
     w = alpha_to_w(alpha.astype(F32))
-    return sample_pdf_det(d, w, n_new), w
+    return sample_pdf_det(d, w, n_new, u=u), w
 
 
 def render_rays(field, rays_o, rays_d, cfg: RenderConfig = RenderConfig(), detailed: bool = False) -> Dict[str, np.ndarray]:

@@ -205,6 +205,13 @@ void hc_ray_bounds(const float* ds_probe, int64_t R, int G, float thresh, const 
 }
 
 // d, sdf: [R, cap] with the first n valid; writes d[:, n:n+n_new]
+// sample_pdf(det=False): the caller's uniform randoms u [R][n_new]
+void hc_ray_upsample_u(float* d, const float* sdf, int64_t R, int cap, int n, int it, int n_new, const float* u) {
+    float w[NM_MAX_SAMPLES], cdf[NM_MAX_SAMPLES];
+    for (int64_t r = 0; r < R; ++r)
+        nm_ray_upsample<int>(d + r * cap, sdf + r * cap, n, it, n_new, d + r * cap + n, w, cdf, nullptr, nullptr, nullptr, u + r * n_new);
+}
+
 void hc_ray_upsample(float* d, const float* sdf, int64_t R, int cap, int n, int it, int n_new) {
     for (int64_t r = 0; r < R; ++r) {
         float w[NM_MAX_SAMPLES], cdf[NM_MAX_SAMPLES];

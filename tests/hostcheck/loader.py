@@ -46,6 +46,7 @@ def load():
         lib.hc_ray_setup.argtypes = [f32p, f32p, C.c_int64, C.c_float, f32p, f32p]
         lib.hc_ray_bounds.argtypes = [f32p, C.c_int64, C.c_int, C.c_float, f32p, f32p]
         lib.hc_ray_upsample.argtypes = [f32p, f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.hc_ray_upsample_u.argtypes = [f32p, f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
         lib.hc_ray_merge.argtypes = [f32p, f32p, C.c_int64, C.c_int, C.c_int, C.c_int]
         lib.hc_ray_composite.argtypes = [f32p, f32p, C.c_int64, C.c_int, C.c_float, f32p, f32p, C.c_int, f32p, f32p, f32p, f32p]
         _lib = lib

@@ -189,6 +189,25 @@ def test_warm_started_search_is_exact_and_cheaper():
     assert n_nodes < cold[0] and n_verts < 0.9 * cold[1]   # mostly saves vertex visits / top-K insertions
 
 
+def test_upsample_with_random_u_follows_the_oracle():
+    """sample_pdf(det=False) (perturb=True, rend_util.py:293-296): the C++ stage with the caller's
+    uniform randoms vs the oracle's restatement with the same u (unordered u: binary lower bound)."""
+    lib = load()
+    rf = common.golden("render_v3000_dtu")
+    R, cap = len(rf["rays_o"]), 128
+    d = np.zeros((R, cap), np.float32); sdf = np.zeros((R, cap), np.float32)
+    d[:, :64], sdf[:, :64] = rf["d_coarse"], rf["sdf_coarse"]
+    rng = np.random.default_rng(21)
+    for it in range(3):
+        u = rng.random((R, 16), dtype=np.float32)
+        u[:, 0] = 0.0   # torch.rand's lower end ([0, 1)); in the flat tail of the cdf (increments of ~1e-7 per bin, u
+        #                beyond ~0.999 here) bin choice hinges on the last bit of the running sum, see oracle/compare.py
+        lib.hc_ray_upsample_u(P(d), P(sdf), R, cap, 64, it, 16, P(u))
+        o_fine, _ = orender.upsample_step(rf["d_coarse"], rf["sdf_coarse"], it, 16, u=u)
+        np.testing.assert_allclose(d[:, 64:80], o_fine, atol=3e-6)
+        assert (d[:, 64:80] >= rf["d_coarse"][:, :1] - 1e-6).all() and (d[:, 64:80] <= rf["d_coarse"][:, -1:] + 1e-6).all()
+
+
 def test_upsample_slot_tracking_and_bounds():
     """nm_rays_upsample_kernel's bookkeeping: slot[j] always names the generation position of the
     sample now at sorted position j, and the emitted warm-start bounds are valid upper bounds."""
