@@ -551,7 +551,12 @@ static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) 
     w.radius = (float*)take((size_t)R * N * 4);
     w.bound = (float*)take((size_t)R * N * 4);
     w.bound_mid = (float*)take((size_t)R * N * 4);
-    w.order = (unsigned short*)take((size_t)((R + 63) / 64) * 64 * (size_t)(c->N_importance > 0 ? c->N_importance / c->N_upsample_iters : 1) * 2);
+    {   // lane assignments of one pass: importance samples (64-ray groups) or mid-points (16-ray groups)
+        const size_t n_new = c->N_importance > 0 ? c->N_importance / c->N_upsample_iters : 1;
+        const size_t e_fine = (size_t)((R + 63) / 64) * ((64 * n_new + 63) & ~(size_t)63);
+        const size_t e_mid = (size_t)((R + 15) / 16) * ((16 * (size_t)(N - 1) + 63) & ~(size_t)63);
+        w.order = (unsigned short*)take((e_fine > e_mid ? e_fine : e_mid) * 2);
+    }
     w.slots = nm_carve(p + o, R * N, false);
     o += w.slots.bytes;
     w.pts = nm_carve(p + o, R * N, false);
@@ -666,12 +671,13 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
             src.out_stride = cap;
             src.out_off = n;
             src.order = nullptr;
-            if (64 * n_new <= 4096 && 64 * n_new <= 65536) {  // LDS sort capacity / 16-bit ids
+            if (64 * n_new <= 4096) {  // LDS sort capacity (ids are 16-bit)
                 int np2 = 64;
                 while (np2 < 64 * n_new) np2 <<= 1;
-                hipLaunchKernelGGL(nm_rays_order_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), (size_t)np2 * 8, stream, ws.d, (long long)R, cap, n, n_new, np2, ws.order);
+                hipLaunchKernelGGL(nm_rays_order_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), (size_t)np2 * 8, stream, ws.d, (long long)R, cap, n, n_new, 64, np2, ws.order);
                 NM_LAUNCH_CHECK();
                 src.order = ws.order;
+                src.order_rays = 64;
             }
             if (nm_launch_distance(g, src, (long long)R * n_new, t->indicator_vector, t->indicator_weight, ws.slots.ds, nullptr, nullptr, nullptr, want_grad ? ws.slots.grad : nullptr, stream, ws.radius, ga_slots)) return 1;
             const NmRecMap rm = {n_new, cap, n, nullptr};
@@ -691,6 +697,14 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     }
     // SDF + nabla + radiance at the N-1 mid-points (renderer.py:266-267, 279-282)
     src.order = nullptr;
+    if (16 * (N - 1) <= 4096 && !getenv("NEUMESH_NO_MID_ORDER")) {  // mid-points by depth buckets over 16 adjacent rays
+        int np2 = 64;
+        while (np2 < 16 * (N - 1)) np2 <<= 1;
+        hipLaunchKernelGGL(nm_rays_order_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), (size_t)np2 * 8, stream, ws.dmid, (long long)R, cap, 0, N - 1, 16, np2, ws.order);
+        NM_LAUNCH_CHECK();
+        src.order = ws.order;
+        src.order_rays = 16;
+    }
     src.mode = 1;
     src.P = N - 1;
     src.depth = ws.dmid;

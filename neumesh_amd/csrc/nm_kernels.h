@@ -28,9 +28,11 @@ struct NmPointSrc {
     // where the per-point outputs go: record index = q (compact) if out_stride == 0,
     // else r*out_stride + out_off + p (per-ray slots, so later stages can address them by slot)
     int out_stride, out_off;
-    // lane -> (ray, sample) assignment by depth buckets (optional, see nm_rays_order_kernel):
-    // order[group*64*P + j] = (ray - group*64)*P + p of the j-th sample of the 64-ray group
+    // lane -> (ray, sample) assignment by depth buckets (optional, see nm_rays_order_kernel): groups of
+    // order_rays adjacent rays, E = roundup(order_rays*P, 64) entries per group,
+    // order[group*E + j] = (ray - group*order_rays)*P + p of the j-th sample of the group (0xFFFF = padding)
     const unsigned short* order;
+    int order_rays;
     // mode 2 only: a wave walks `chain` consecutive 4-sample tiles of its 16 rays (0/1 = one tile) and
     // warm-starts every tile after the first from the tile before it (see nm_distance_kernel)
     int chain;
@@ -204,14 +206,15 @@ __device__ __forceinline__ bool nm_lane_query(const NmPointSrc& s, long long Q, 
     }
     const long long R = Q / s.P;  // uniform
     if (s.order) {
-        const long long grp = wave / s.P;
-        if (grp * 64 >= R) { q = r = 0; p = 0; return false; }
-        const unsigned id = s.order[wave * 64 + lane];  // wave*64 == grp*64*P + (wave - grp*P)*64
+        const long long wpg = ((long long)s.order_rays * s.P + 63) >> 6;  // waves per group
+        const long long grp = wave / wpg;
+        if (grp * s.order_rays >= R) { q = r = 0; p = 0; return false; }
+        const unsigned id = s.order[wave * 64 + lane];  // wave*64 == grp*E + (wave - grp*wpg)*64
         const unsigned rl = id / (unsigned)s.P;
-        r = grp * 64 + rl;
+        r = grp * s.order_rays + rl;
         p = (int)(id - rl * (unsigned)s.P);
         q = r * s.P + p;
-        return rl < 64u && r < R;
+        return id != 0xffffu && r < R;
     }
     const int chain = nm_chain_len(s);
     const long long tiles_p = ((s.P + 3) >> 2), groups_p = (tiles_p + chain - 1) / chain;
@@ -224,7 +227,7 @@ __device__ __forceinline__ bool nm_lane_query(const NmPointSrc& s, long long Q, 
 static inline unsigned nm_query_blocks(const NmPointSrc& s, long long Q) {
     long long waves;
     if (s.mode == 0) waves = (Q + 63) / 64;
-    else if (s.order) waves = ((Q / s.P + 63) / 64) * s.P;
+    else if (s.order) waves = ((Q / s.P + s.order_rays - 1) / s.order_rays) * (((long long)s.order_rays * s.P + 63) / 64);
     else {
         const int chain = (s.mode == 2 && s.chain > 1) ? s.chain : 1;
         waves = ((Q / s.P + 15) / 16) * (((s.P + 3) / 4 + chain - 1) / chain);
@@ -538,16 +541,18 @@ __global__ __launch_bounds__(64) void nm_rays_finalize_kernel(float* __restrict_
 // depth range and its cooperative K-NN traversal has to cover the union of 64 far-apart searches
 // (measured on the benchmark scene: 1778 node tests + 3609 vertex visits per wave).  Sorting the
 // 64*P samples of 64 adjacent rays by depth and cutting the list into P waves gives compact
-// footprints again (840 + 1289).  One workgroup per 64-ray group, bitonic sort in LDS on
+// footprints again (840 + 1289).  The same holds, less dramatically, for the N-1 mid-points of the
+// final sorted samples (16 rays x 4 consecutive ones: 828 + 1452; the 2032 mid-points of 16 rays
+// sorted by depth: 559 + 856).  One workgroup per group of G rays, bitonic sort in LDS on
 // (order-preserving depth key << 32 | id); which lane evaluates which sample changes no value.
 __global__ __launch_bounds__(256) void nm_rays_order_kernel(const float* __restrict__ d, long long R, int cap, int off,
-                                                            int P, int Npow2, unsigned short* __restrict__ order) {
+                                                            int P, int G, int Npow2, unsigned short* __restrict__ order) {
     extern __shared__ unsigned long long nm_sort_keys[];
     const long long grp = blockIdx.x;
-    const int n = 64 * P;
+    const int n = G * P, E = (n + 63) & ~63;
     for (int i = threadIdx.x; i < Npow2; i += 256) {
         const int rl = i / P;
-        const long long r = grp * 64 + rl;
+        const long long r = grp * G + rl;
         uint32_t key = 0xffffffffu;
         if (i < n && r < R) key = nm_float_key(d[r * cap + off + (i - rl * P)]);
         nm_sort_keys[i] = ((unsigned long long)key << 32) | (unsigned)i;
@@ -568,7 +573,10 @@ __global__ __launch_bounds__(256) void nm_rays_order_kernel(const float* __restr
             __syncthreads();
         }
     }
-    for (int i = threadIdx.x; i < n; i += 256) order[grp * n + i] = (unsigned short)(nm_sort_keys[i] & 0xffffu);
+    for (int i = threadIdx.x; i < E; i += 256) {
+        const unsigned id = (unsigned)(nm_sort_keys[i] & 0xffffffffu);  // valid ids sort before the padding (key ties break by id)
+        order[grp * E + i] = id < (unsigned)n ? (unsigned short)id : (unsigned short)0xffffu;
+    }
 }
 
 // sample points of a ray batch as an explicit [R,P,3] array (staged renderer: the field is queried
