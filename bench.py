@@ -217,6 +217,8 @@ def main():
     ap.add_argument("--mlp-precision", choices=["f16x2", "fp32"], default="f16x2",
                     help="MLP arithmetic: split-half f16 MFMA (default; 22-bit operands, fp32 accumulation) or fp32 MFMA")
     ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU-baseline sample (0 disables)")
+    ap.add_argument("--no-normals", action="store_true",
+                    help="calc_normal=False (SURVEY 8d config 2 asks for both): no nablas at the N sample points, no normals_volume")
     args = ap.parse_args()
     if args.workload == "stress5":
         return stress5(args)
@@ -241,7 +243,7 @@ def main():
 
     mesh, model = build_scene(args.V, dev)
     model.mlp_precision = args.mlp_precision
-    cfg = make_render_cfg(calc_normal=True)
+    cfg = make_render_cfg(calc_normal=not args.no_normals)
     n_rays = args.H * args.W
     total_steps = args.warmup + args.steps
     from neumesh_amd import synthetic
@@ -318,7 +320,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x2-split (22-bit operands, fp32 accumulate; K-NN and per-ray stages fp32)" if split else "f32", "data": "synthetic",
             "config": {"workload": f"S-DTU V={args.V} {args.H}x{args.W} rays/frame/GPU, 64+64 samples, bounded_near_far (256 probes), "
-                                   f"calc_normal, per ray 639 K-NN points (511 searched, 128 reused), 255 geometry-MLP evaluations with nablas (the reference's 128 forward-only ones at the same points are the value rows of these) + 127 colour-MLP",
+                                   + (f"calc_normal, per ray 639 K-NN points (511 searched, 128 reused), 255 geometry-MLP evaluations with nablas (the reference's 128 forward-only ones at the same points are the value rows of these) + 127 colour-MLP"
+                                    if not args.no_normals else "calc_normal=False, per ray 639 K-NN points (511 searched, 128 reused), 128 forward-only + 127 nabla geometry-MLP evaluations + 127 colour-MLP"),
                        "rayschunk": args.rayschunk or n_rays, "parallelism": f"rays sharded: {world} GPU(s) x 1 frame per step, 1 all-gather of pixels"},
             "roofline": {"bound": "mfma", "kernel": ({"geo_mlp": "nm_geo_mlp_h_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_h_kernel<true>",
                                                       "color_mlp": "nm_col_mlp_h_kernel"} if split else
