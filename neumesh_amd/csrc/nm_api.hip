@@ -600,17 +600,24 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     src.dstride = cap;
     const float* nf = ws.nf0;
     if (c->bounded_near_far) {  // renderer.py:66-102
-        src.mode = 2;
-        src.chain = nm_chain_tiles(R, c->probe_grid);
-        src.P = c->probe_grid;
-        src.nearfar = ws.nf0;
-        src.depth_out = nullptr;
-        src.bound = nullptr;
-        src.out_stride = 0;
-        src.out_off = 0;
-        if (nm_launch_distance(g, src, (long long)R * c->probe_grid, t->indicator_vector, t->indicator_weight, ws.probe, nullptr, nullptr, nullptr, nullptr, stream)) return 1;
-        hipLaunchKernelGGL(nm_rays_bounds_kernel, rgrid, rblock, 0, stream, ws.probe, (long long)R, c->probe_grid, c->probe_thresh, ws.nf0, ws.nf);
-        NM_LAUNCH_CHECK();
+        if (!getenv("NEUMESH_FULL_PROBES")) {  // first / last hit only (nm_probe_bounds_kernel)
+            NmProfScope prof(NM_K_DISTANCE, (long long)R * c->probe_grid, stream);  // probe decisions resolved (not all are searched)
+            hipLaunchKernelGGL(nm_probe_bounds_kernel, dim3(nm_blocks((R + 15) / 16, 4)), dim3(256), 0, stream, g->view, rays_o, ws.dirn, ws.nf0,
+                               (long long)R, c->probe_grid, c->probe_thresh, g->verts, t->indicator_vector, t->indicator_weight, ws.nf);
+            NM_LAUNCH_CHECK();
+        } else {  // every probe, then the reduction (the staged API's form; kept for A/B measurements)
+            src.mode = 2;
+            src.chain = nm_chain_tiles(R, c->probe_grid);
+            src.P = c->probe_grid;
+            src.nearfar = ws.nf0;
+            src.depth_out = nullptr;
+            src.bound = nullptr;
+            src.out_stride = 0;
+            src.out_off = 0;
+            if (nm_launch_distance(g, src, (long long)R * c->probe_grid, t->indicator_vector, t->indicator_weight, ws.probe, nullptr, nullptr, nullptr, nullptr, stream)) return 1;
+            hipLaunchKernelGGL(nm_rays_bounds_kernel, rgrid, rblock, 0, stream, ws.probe, (long long)R, c->probe_grid, c->probe_thresh, ws.nf0, ws.nf);
+            NM_LAUNCH_CHECK();
+        }
         nf = ws.nf;
     }
     if (c->near_bypass >= 0.f || c->far_bypass >= 0.f) {  // renderer.py:172-175

@@ -400,6 +400,104 @@ __global__ __launch_bounds__(256, 4) void nm_distance_kernel(NmGridView g, NmPoi
     }
 }
 
+// ---------------------------------------------------- bounded near/far straight from the probes
+// compute_bounded_near_far (renderer.py:66-102) needs, per ray, only the FIRST and the LAST of the
+// P regular probes whose projected distance is below the threshold (min / max of the masked depths;
+// the depths increase with the probe index).  Every point inside the object has ds < 0, so for a
+// ray that crosses it most probes lie BETWEEN those two and are never evaluated here: a wave owns 16
+// rays, walks their probes forward (4 per ray per step, warm-started from the step before, as in the
+// chained tiles above) until every ray has its first hit, then backward from the far end until every
+// ray has its last one.  Results are the reference's exactly: the same probes decide, the skipped
+// ones cannot change a min / max.  Replaces a P-probe K-NN pass + the reduction kernel + the
+// [R,P] probe array.
+__global__ __launch_bounds__(256, 4) void nm_probe_bounds_kernel(NmGridView g, const float* __restrict__ rays_o,
+                                                                 const float* __restrict__ dirn, const float* __restrict__ nearfar0,
+                                                                 long long R, int P, float thresh, const float* __restrict__ verts,
+                                                                 const float* __restrict__ indicator, float w1,
+                                                                 float* __restrict__ nearfar) {
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63, sub = lane & 3, quad = lane & ~3;
+    const long long r = wave * 16 + (lane >> 2);
+    const bool valid = r < R;
+    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, n0 = 0.f, f0 = 1.f;
+    if (valid) {
+        ox = rays_o[3 * r]; oy = rays_o[3 * r + 1]; oz = rays_o[3 * r + 2];
+        dx = dirn[3 * r]; dy = dirn[3 * r + 1]; dz = dirn[3 * r + 2];
+        n0 = nearfar0[2 * r]; f0 = nearfar0[2 * r + 1];
+    }
+    const int T = (P + 3) >> 2;
+    int first_idx = -1, last_idx = -1;
+    // one step: probe p of this lane's ray; returns ds (and the K-th-neighbour radius for the next warm start)
+    auto probe = [&](int p, bool act, float init, float& dep, float& rad) -> float {
+        dep = nm_lerp_depth(n0, f0, nm_linspace01(p < P ? p : P - 1, P));
+        const float x = nm_add(ox, nm_mul(dep, dx)), y = nm_add(oy, nm_mul(dep, dy)), z = nm_add(oz, nm_mul(dep, dz));
+        unsigned long long kk[8];
+        nm_knn_wave<8>(g, x, y, z, act, kk, init);
+        float bd[8], wk[8];
+        int bi[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            bd[k] = nm_key_d2(kk[k]);
+            bi[k] = nm_key_idx(kk[k]);
+        }
+        rad = (act && bi[7] != 0x7fffffff) ? nm_sqrt(bd[7]) : NM_INF_F;
+        return act ? nm_projected_distance8(x, y, z, bd, bi, verts, indicator, w1, wk, nullptr) : NM_INF_F;
+    };
+    // ---- forward: first hit
+    {
+        float prev_rad = NM_INF_F, prev_dep = 0.f;
+        for (int t = 0; t < T; ++t) {
+            if (!__any(valid && first_idx < 0)) break;
+            const int p = 4 * t + sub;
+            const bool act = valid && first_idx < 0 && p < P;
+            const float pr = __shfl(prev_rad, quad | 3), pd = __shfl(prev_dep, quad | 3);
+            float dep, rad, init = NM_INF_F;
+            // (the depth is needed for the bound before the search: same formula as inside probe())
+            const float dep_here = nm_lerp_depth(n0, f0, nm_linspace01(p < P ? p : P - 1, P));
+            if (t > 0 && pr < NM_INF_F) {
+                const float b = (pr + fabsf(dep_here - pd)) * 1.0001f + 1e-5f;
+                init = b * b;
+            }
+            const float ds = probe(p, act, init, dep, rad);
+            prev_rad = rad;
+            prev_dep = dep;
+            const unsigned hm = (unsigned)((__ballot(act && ds < thresh) >> quad) & 0xfull);
+            if (hm && first_idx < 0) first_idx = 4 * t + __builtin_ctz(hm);
+        }
+    }
+    // ---- backward: last hit (strictly after the first one; none => the first one is also the last)
+    {
+        float prev_rad = NM_INF_F, prev_dep = 0.f;
+        bool started = false;
+        for (int t = T - 1; t >= 0; --t) {
+            if (first_idx >= 0 && last_idx < 0 && 4 * t + 3 <= first_idx) last_idx = first_idx;  // nothing left above the first hit
+            if (!__any(valid && first_idx >= 0 && last_idx < 0)) break;
+            const int p = 4 * t + sub;
+            const bool act = valid && first_idx >= 0 && last_idx < 0 && p < P && p > first_idx;
+            const float pr = __shfl(prev_rad, quad), pd = __shfl(prev_dep, quad);
+            float dep, rad, init = NM_INF_F;
+            const float dep_here = nm_lerp_depth(n0, f0, nm_linspace01(p < P ? p : P - 1, P));
+            if (started && pr < NM_INF_F) {
+                const float b = (pr + fabsf(dep_here - pd)) * 1.0001f + 1e-5f;
+                init = b * b;
+            }
+            const float ds = probe(p, act, init, dep, rad);
+            prev_rad = rad;
+            prev_dep = dep;
+            started = true;
+            const unsigned hm = (unsigned)((__ballot(act && ds < thresh) >> quad) & 0xfull);
+            if (hm && first_idx >= 0 && last_idx < 0) last_idx = 4 * t + (31 - __builtin_clz(hm));
+            if (first_idx >= 0 && last_idx < 0 && 4 * t <= first_idx) last_idx = first_idx;  // this tile held the first hit
+        }
+        if (first_idx >= 0 && last_idx < 0) last_idx = first_idx;
+    }
+    if (valid && sub == 0) {
+        const float mn = first_idx >= 0 ? nm_lerp_depth(n0, f0, nm_linspace01(first_idx, P)) : 1e10f;
+        const float mx = first_idx >= 0 ? nm_lerp_depth(n0, f0, nm_linspace01(last_idx, P)) : -1e10f;
+        nm_ray_bounds_finish(mn, mx, n0, f0, nearfar + 2 * r, nearfar + 2 * r + 1);
+    }
+}
+
 // ------------------------------------------------------------------------- per-ray kernels
 __global__ void nm_rays_setup_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, long long R,
                                      float radius, float* __restrict__ dirn, float* __restrict__ nearfar) {

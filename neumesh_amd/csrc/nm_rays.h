@@ -66,6 +66,18 @@ NM_HD void nm_ray_setup(const float* o, const float* d_in, float radius, float* 
     *far_ = fmaxf(nm_add(mid, radius), radius);
 }
 
+// renderer.py:93-102 given the smallest / largest probe depth with ds < thresh (1e10 / -1e10: none)
+NM_HD void nm_ray_bounds_finish(float mn, float mx, float near0, float far0, float* near_, float* far_) {
+    float n = (mn > 1e5f) ? near0 : mn;
+    float f = (mx < -1e5f) ? far0 : mx;
+    if (nm_sub(f, n) < 0.1f) {
+        f = nm_add(f, 0.05f);
+        n = nm_sub(n, 0.05f);
+    }
+    *near_ = n;
+    *far_ = f;
+}
+
 // renderer.py:88-102: ds_probe[i] is the projected distance at depth lerp(near0, far0, t_i).
 NM_HD void nm_ray_bounds(const float* ds_probe, int stride, int G, float thresh, float near0, float far0,
                          float* near_, float* far_) {
@@ -77,14 +89,7 @@ NM_HD void nm_ray_bounds(const float* ds_probe, int stride, int G, float thresh,
             mx = fmaxf(mx, d);
         }
     }
-    float n = (mn > 1e5f) ? near0 : mn;
-    float f = (mx < -1e5f) ? far0 : mx;
-    if (nm_sub(f, n) < 0.1f) {
-        f = nm_add(f, 0.05f);
-        n = nm_sub(n, 0.05f);
-    }
-    *near_ = n;
-    *far_ = f;
+    nm_ray_bounds_finish(mn, mx, near0, far0, near_, far_);
 }
 
 // One up-sampling iteration (renderer.py:209-245 + rend_util.py:276-319, det=True):

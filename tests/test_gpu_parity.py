@@ -390,6 +390,19 @@ def test_render_frame_properties_dtu_scale(dtu_scale, cuda_device, torch_mod):
         else:
             os.environ["NEUMESH_CHAIN_TILES"] = old
     assert torch.equal(a_rgb, b_rgb) and torch.equal(a_depth, b_depth) and torch.equal(a_ex["normals_volume"], b_ex["normals_volume"])
+    # bounded near/far from the first / last hit only (nm_probe_bounds_kernel) == all 256 probes + reduction
+    kwd = dict(kw, detailed_output=True)
+    try:
+        with torch.no_grad():
+            os.environ["NEUMESH_FULL_PROBES"] = "1"
+            c_rgb, _, c_ex = volume_render(_t(o, cuda_device), _t(d, cuda_device), model, rayschunk=16384, **kwd)
+            os.environ.pop("NEUMESH_FULL_PROBES")
+            d_rgb, _, d_ex = volume_render(_t(o, cuda_device), _t(d, cuda_device), model, rayschunk=16384, **kwd)
+    finally:
+        os.environ.pop("NEUMESH_FULL_PROBES", None)
+    assert torch.equal(c_ex["near_far"], d_ex["near_far"]) and torch.equal(c_rgb, d_rgb) and torch.equal(c_rgb, b_rgb)
+    nf = d_ex["near_far"].cpu().numpy()
+    assert (nf[:, 1] > nf[:, 0]).all() and len(np.unique(nf[:, 0])) > 100   # a mix of hit / grazing / missing rays
 
 
 @pytest.mark.gpu
