@@ -44,17 +44,21 @@ static int nm_fail(const char* fmt, ...) {
 // of HIP events recorded on the SAME stream the kernel is launched on; nm_profile_read sums the
 // elapsed times per kernel kind.  Event records do not serialise anything; disabled by default.
 enum { NM_K_DISTANCE = 0, NM_K_GEO = 1, NM_K_GEO_NABLA = 2, NM_K_COLOR = 3, NM_K_KINDS = 4 };
-struct NmProfRec { hipEvent_t a, b; int kind; long long units; };
+// `counted` launches (the mid-point pass with the zero-weight skip) process a data-dependent number
+// of points: the order kernel adds it to a device counter, which nm_profile_read adds to the units.
+struct NmProfRec { hipEvent_t a, b; int kind; long long units; bool counted; };
 static bool g_prof_on = false;
 static std::vector<NmProfRec> g_prof;
+static unsigned long long* g_prof_counter = nullptr;  // device
 struct NmProfScope {
     NmProfRec r;
     hipStream_t s;
     bool on;
-    NmProfScope(int kind, long long units, hipStream_t stream) : s(stream), on(g_prof_on) {
+    NmProfScope(int kind, long long units, hipStream_t stream, bool counted = false) : s(stream), on(g_prof_on) {
         if (!on) return;
         r.kind = kind;
         r.units = units;
+        r.counted = counted;
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(r.a, s);
     }
@@ -195,9 +199,9 @@ static const NmGather NM_NO_GATHER = {nullptr, 0, nullptr, nullptr, 0, nullptr};
 
 static int nm_launch_distance(nm_grid_t g, const NmPointSrc& src, long long Q, const float* indicator, float w1,
                               float* ds, int* idx32, long long* idx64, float* w, float* grad, hipStream_t stream,
-                              float* radius = nullptr, NmGather ga = NM_NO_GATHER) {
+                              float* radius = nullptr, NmGather ga = NM_NO_GATHER, bool counted = false) {
     if (Q <= 0) return 0;
-    NmProfScope prof(NM_K_DISTANCE, Q, stream);
+    NmProfScope prof(NM_K_DISTANCE, counted ? 0 : Q, stream, counted);
     if (nm_chain_len(src) > 1)
         hipLaunchKernelGGL(nm_distance_kernel<true>, dim3(nm_query_blocks(src, Q)), dim3(256), 0, stream, g->view, src, Q, g->verts,
                            indicator, w1, ds, idx32, idx64, w, grad, radius, ga.geo_table, ga.gdim, ga.fg, ga.col_table, ga.cdim, ga.ft);
@@ -409,39 +413,41 @@ static int nm_check_field_args(nm_field_t f, nm_grid_t g, const nm_field_tables*
     return 0;
 }
 
+static const NmSlotMap NM_NO_SLOTS = {nullptr, 0, 0, 0};
+
 static int nm_launch_geo(nm_field_t f, const float* fg, const float* ds, const float* grad, long long P, bool nabla,
                          float* sdf, int Pper, int stride, int off, float* nabla_out, hipStream_t stream,
-                         NmRecMap rmap = NM_COMPACT, int nabla_slotted = 0) {
+                         NmRecMap rmap = NM_COMPACT, int nabla_slotted = 0, NmSlotMap smap = NM_NO_SLOTS, bool counted = false) {
     if (P <= 0) return 0;
-    NmProfScope prof(nabla ? NM_K_GEO_NABLA : NM_K_GEO, P, stream);
+    NmProfScope prof(nabla ? NM_K_GEO_NABLA : NM_K_GEO, counted ? 0 : P, stream, counted);
     if (f->precision == 1) {
-        if (nabla) hipLaunchKernelGGL((nm_geo_mlp_h_kernel<true>), dim3(nm_blocks(P, 32)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted);
-        else hipLaunchKernelGGL((nm_geo_mlp_h_kernel<false>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted);
+        if (nabla) hipLaunchKernelGGL((nm_geo_mlp_h_kernel<true>), dim3(nm_blocks(P, 32)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap);
+        else hipLaunchKernelGGL((nm_geo_mlp_h_kernel<false>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap);
         NM_LAUNCH_CHECK();
         return 0;
     }
     if (nabla) {
         hipLaunchKernelGGL((nm_geo_mlp_kernel<true, false>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo, fg, ds,
-                           grad, rmap, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr, nabla_slotted);
+                           grad, rmap, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr, nabla_slotted, smap);
     } else {
         hipLaunchKernelGGL((nm_geo_mlp_kernel<false, false>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->geo, fg, ds,
-                           grad, rmap, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr, nabla_slotted);
+                           grad, rmap, P, sdf, Pper, stride, off, nabla_out, (float*)nullptr, nabla_slotted, smap);
     }
     NM_LAUNCH_CHECK();
     return 0;
 }
 
 static int nm_launch_col(nm_field_t f, const float* ft, const float* ds, const float* nabla, const float* dirs, int dir_div,
-                         long long P, float* rgb, hipStream_t stream) {
+                         long long P, float* rgb, hipStream_t stream, NmSlotMap smap = NM_NO_SLOTS, bool counted = false) {
     if (P <= 0) return 0;
-    NmProfScope prof(NM_K_COLOR, P, stream);
+    NmProfScope prof(NM_K_COLOR, counted ? 0 : P, stream, counted);
     if (f->precision == 1) {
-        hipLaunchKernelGGL(nm_col_mlp_h_kernel, dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h, ft, ds, nabla, dirs, dir_div, P, rgb);
+        hipLaunchKernelGGL(nm_col_mlp_h_kernel, dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h, ft, ds, nabla, dirs, dir_div, P, rgb, smap);
         NM_LAUNCH_CHECK();
         return 0;
     }
     hipLaunchKernelGGL((nm_col_mlp_kernel<false>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->col, ft, ds, nabla, dirs,
-                       dir_div, P, rgb, (float*)nullptr);
+                       dir_div, P, rgb, (float*)nullptr, smap);
     NM_LAUNCH_CHECK();
     return 0;
 }
@@ -507,6 +513,17 @@ static int nm_chain_tiles(long long R, int P) {
     return c < 1 ? 1 : (int)c;
 }
 
+// Rays per depth-bucket group of the mid-point pass: 32 (4064 samples sorted in 32 KiB of LDS; with the
+// zero-weight samples dropped, ~1700 of them remain, i.e. the sample density of a 14-ray group), fewer
+// when the per-ray sample count is larger; 0 = no ordering (lists longer than the 4096-key sort).
+static int nm_mid_group_rays(int N) {
+    const char* e = getenv("NEUMESH_MID_GROUP");
+    int g = e ? atoi(e) : 32;
+    if (g != 16 && g != 32) g = 32;
+    while (g >= 16 && g * (N - 1) > 4096) g >>= 1;
+    return g >= 16 ? g : 0;
+}
+
 // the per-ray kernels keep 64 rays' rows in dynamic LDS (nm_ray_lds_bytes(cap) > 64 KiB for cap >= 110)
 static int nm_ray_lds_prepare(int cap, size_t* bytes) {
     *bytes = nm_ray_lds_bytes(cap);
@@ -546,7 +563,10 @@ static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) 
     w.probe = (float*)take((size_t)R * (c->bounded_near_far ? c->probe_grid : 1) * 4);
     w.rgb_mid = (float*)take((size_t)R * N * 12);
     w.nab_pts = (float*)take((size_t)R * N * 12);
-    w.nab_mid = (float*)take((size_t)R * N * 12);
+    // mid-point list positions: an upper bound over the group sizes nm_mid_group_rays can pick
+    const long long slots16 = ((R + 15) / 16) * (((long long)16 * (N - 1) + 63) & ~63LL), slots32 = ((R + 31) / 32) * (((long long)32 * (N - 1) + 63) & ~63LL);
+    const long long mid_slots = slots16 > slots32 ? slots16 : slots32;
+    w.nab_mid = (float*)take((size_t)(mid_slots > R * N ? mid_slots : R * N) * 12);
     w.slot = (int*)take((size_t)R * N * 4);
     w.radius = (float*)take((size_t)R * N * 4);
     w.bound = (float*)take((size_t)R * N * 4);
@@ -554,12 +574,13 @@ static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) 
     {   // lane assignments of one pass: importance samples (64-ray groups) or mid-points (16-ray groups)
         const size_t n_new = c->N_importance > 0 ? c->N_importance / c->N_upsample_iters : 1;
         const size_t e_fine = (size_t)((R + 63) / 64) * ((64 * n_new + 63) & ~(size_t)63);
-        const size_t e_mid = (size_t)((R + 15) / 16) * ((16 * (size_t)(N - 1) + 63) & ~(size_t)63);
+        const size_t e16 = (size_t)((R + 15) / 16) * ((16 * (size_t)(N - 1) + 63) & ~(size_t)63), e32 = (size_t)((R + 31) / 32) * ((32 * (size_t)(N - 1) + 63) & ~(size_t)63);
+        const size_t e_mid = e16 > e32 ? e16 : e32;
         w.order = (unsigned short*)take((e_fine > e_mid ? e_fine : e_mid) * 2);
     }
     w.slots = nm_carve(p + o, R * N, false);
     o += w.slots.bytes;
-    w.pts = nm_carve(p + o, R * N, false);
+    w.pts = nm_carve(p + o, mid_slots > R * N ? mid_slots : R * N, false);
     o += w.pts.bytes;
     w.bytes = o;
     return w;
@@ -664,6 +685,9 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     int n = c->N_samples, pending = 0;
     size_t ray_lds = 0;
     if (nm_ray_lds_prepare(cap, &ray_lds)) return 1;
+    const int mid_g = nm_mid_group_rays(N);  // rays per depth-bucket group of the mid-point pass
+    const bool use_order = mid_g > 0 && !getenv("NEUMESH_NO_MID_ORDER");
+    const bool skip_zero = use_order && !(dbg && dbg->radiance) && !getenv("NEUMESH_NO_ZERO_SKIP");  // all radiances requested => evaluate all
     if (c->N_importance > 0) {
         const int n_new = c->N_importance / c->N_upsample_iters;
         for (int it = 0; it < c->N_upsample_iters; ++it) {
@@ -681,7 +705,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
             if (64 * n_new <= 4096) {  // LDS sort capacity (ids are 16-bit)
                 int np2 = 64;
                 while (np2 < 64 * n_new) np2 <<= 1;
-                hipLaunchKernelGGL(nm_rays_order_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), (size_t)np2 * 8, stream, ws.d, (long long)R, cap, n, n_new, 64, np2, ws.order);
+                hipLaunchKernelGGL(nm_rays_order_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), (size_t)np2 * 8, stream, ws.d, (long long)R, cap, n, n_new, 64, np2, ws.order, (const float*)nullptr, (unsigned long long*)nullptr);
                 NM_LAUNCH_CHECK();
                 src.order = ws.order;
                 src.order_rays = 64;
@@ -693,7 +717,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
             pending = n_new;
         }
     }
-    hipLaunchKernelGGL(nm_rays_finalize_kernel, rgrid, rblock, ray_lds, stream, ws.d, ws.sdf, ws.slot, ws.radius, (long long)R, cap, n, pending, ws.dmid, ws.bound_mid);
+    hipLaunchKernelGGL(nm_rays_finalize_kernel, rgrid, rblock, ray_lds, stream, ws.d, ws.sdf, ws.slot, ws.radius, (long long)R, cap, n, pending, ws.dmid, ws.bound_mid, t->s, skip_zero ? ws.bound : (float*)nullptr);
     NM_LAUNCH_CHECK();
     // SDF (+ nablas) at all N sample points (renderer.py:264, 271-276): no new search and no new
     // MLP pass -- the SDF values merged above ARE forward_with_nablas(pts)[0] (same points, same
@@ -702,15 +726,31 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
         hipLaunchKernelGGL(nm_permute_rows3_kernel, dim3(nm_blocks(R * N, 256)), dim3(256), 0, stream, nab_slot, ws.slot, (long long)R, cap, N, ws.nab_pts);
         NM_LAUNCH_CHECK();
     }
-    // SDF + nabla + radiance at the N-1 mid-points (renderer.py:266-267, 279-282)
+    // SDF + nabla + radiance at the N-1 mid-points (renderer.py:266-267, 279-282).
+    // The mid-points are handed to the waves by depth buckets over 16 adjacent rays (ws.order), and
+    // those whose visibility weight is EXACTLY zero are dropped from the list: their colour would be
+    // multiplied by 0 in the compositing sum (nm_ray_composite), so neither their K-NN search nor their
+    // geometry / colour MLPs can change a bit of the result (alpha = 0 wherever the SDF does not
+    // decrease along the ray: more than half of the mid-points on the benchmark scene).  With the list
+    // in use, records and nablas are stored at list positions and the colours scattered back.
     src.order = nullptr;
-    if (16 * (N - 1) <= 4096 && !getenv("NEUMESH_NO_MID_ORDER")) {  // mid-points by depth buckets over 16 adjacent rays
+    src.out_by_slot = 0;
+    NmSlotMap smap = NM_NO_SLOTS;
+    long long mid_pts = (long long)R * (N - 1);
+    if (use_order) {
         int np2 = 64;
-        while (np2 < 16 * (N - 1)) np2 <<= 1;
-        hipLaunchKernelGGL(nm_rays_order_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), (size_t)np2 * 8, stream, ws.dmid, (long long)R, cap, 0, N - 1, 16, np2, ws.order);
+        while (np2 < mid_g * (N - 1)) np2 <<= 1;
+        hipLaunchKernelGGL(nm_rays_order_kernel, dim3((unsigned)((R + mid_g - 1) / mid_g)), dim3(256), (size_t)np2 * 8, stream, ws.dmid, (long long)R, cap, 0, N - 1, mid_g, np2, ws.order,
+                           skip_zero ? (const float*)ws.bound : (const float*)nullptr, (skip_zero && g_prof_on) ? g_prof_counter : (unsigned long long*)nullptr);
         NM_LAUNCH_CHECK();
         src.order = ws.order;
-        src.order_rays = 16;
+        src.order_rays = mid_g;
+        src.out_by_slot = 1;
+        smap.order = ws.order;
+        smap.G = mid_g;
+        smap.P = N - 1;
+        smap.E = (mid_g * (N - 1) + 63) & ~63;
+        mid_pts = ((long long)(R + mid_g - 1) / mid_g) * smap.E;  // list positions (incl. padding)
     }
     src.mode = 1;
     src.P = N - 1;
@@ -722,10 +762,10 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     src.out_off = 0;
     {
         const NmGather ga_mid = {t->geometry_features, f->geo.gdim, ws.pts.fg, t->color_features, f->col.cdim, ws.pts.ft};
-        if (nm_launch_distance(g, src, (long long)R * (N - 1), t->indicator_vector, t->indicator_weight, ws.pts.ds, nullptr, nullptr, nullptr, ws.pts.grad, stream, nullptr, ga_mid)) return 1;
+        if (nm_launch_distance(g, src, (long long)R * (N - 1), t->indicator_vector, t->indicator_weight, ws.pts.ds, nullptr, nullptr, nullptr, ws.pts.grad, stream, nullptr, ga_mid, skip_zero)) return 1;
     }
-    if (nm_launch_geo(f, ws.pts.fg, ws.pts.ds, ws.pts.grad, (long long)R * (N - 1), true, nullptr, 1, 1, 0, ws.nab_mid, stream)) return 1;
-    if (nm_launch_col(f, ws.pts.ft, ws.pts.ds, ws.nab_mid, ws.dirn, N - 1, (long long)R * (N - 1), ws.rgb_mid, stream)) return 1;
+    if (nm_launch_geo(f, ws.pts.fg, ws.pts.ds, ws.pts.grad, mid_pts, true, nullptr, 1, 1, 0, ws.nab_mid, stream, NM_COMPACT, 0, smap, skip_zero)) return 1;
+    if (nm_launch_col(f, ws.pts.ft, ws.pts.ds, ws.nab_mid, ws.dirn, N - 1, mid_pts, ws.rgb_mid, stream, smap, skip_zero)) return 1;
     // alpha + compositing (renderer.py:278, 302-333)
     hipLaunchKernelGGL(nm_rays_composite_kernel, rgrid, rblock, 0, stream, ws.sdf, ws.d, (long long)R, cap, N, t->s, ws.rgb_mid,
                        c->calc_normal ? ws.nab_pts : (const float*)nullptr, c->white_bkgd, rgb, depth, acc, c->calc_normal ? normals : (float*)nullptr);
@@ -793,7 +833,7 @@ int nm_rays_finalize(float* d, float* sdf, int64_t R, int cap, int n, int m, flo
     if (R == 0) return 0;
     size_t ray_lds = 0;
     if (nm_ray_lds_prepare(cap, &ray_lds)) return 1;
-    hipLaunchKernelGGL(nm_rays_finalize_kernel, dim3(nm_blocks(R, 64)), dim3(64), ray_lds, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (long long)R, cap, n, m, d_mid, (float*)nullptr);
+    hipLaunchKernelGGL(nm_rays_finalize_kernel, dim3(nm_blocks(R, 64)), dim3(64), ray_lds, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (long long)R, cap, n, m, d_mid, (float*)nullptr, 0.f, (float*)nullptr);
     NM_LAUNCH_CHECK();
     return 0;
 }
@@ -828,6 +868,10 @@ int nm_make_rays(const nm_camera* cam, int64_t first_pixel, int64_t count, float
 int nm_profile_enable(int on) {
     for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
+    if (on) {
+        if (!g_prof_counter) NM_HIP(hipMalloc((void**)&g_prof_counter, sizeof(unsigned long long)));
+        NM_HIP(hipMemset(g_prof_counter, 0, sizeof(unsigned long long)));
+    }
     g_prof_on = on != 0;
     return 0;
 }
@@ -836,6 +880,7 @@ int nm_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* unit
     if (kind < 0 || kind >= NM_K_KINDS || !total_ms || !launches || !units) return nm_fail("nm_profile_read: bad arguments");
     double ms = 0.0;
     int64_t n = 0, u = 0;
+    bool counted = false;
     for (auto& r : g_prof) {
         if (r.kind != kind) continue;
         if (hipEventSynchronize(r.b) != hipSuccess) return nm_fail("nm_profile_read: event sync failed");
@@ -844,6 +889,12 @@ int nm_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* unit
         ms += e;
         n += 1;
         u += r.units;
+        counted = counted || r.counted;
+    }
+    if (counted && g_prof_counter) {  // every counted kind processes the same points once per frame
+        unsigned long long c = 0;
+        NM_HIP(hipMemcpy(&c, g_prof_counter, sizeof(c), hipMemcpyDeviceToHost));
+        u += (int64_t)c;
     }
     *total_ms = ms;
     *launches = n;
@@ -909,10 +960,10 @@ int nm_selfcheck_field(nm_field_t f, nm_grid_t g, const nm_field_tables* t, cons
     const NmGather ga = {t->geometry_features, f->geo.gdim, s.fg, t->color_features, f->col.cdim, s.ft};
     if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr, s.grad, stream, nullptr, ga)) return 1;
     hipLaunchKernelGGL((nm_geo_mlp_kernel<true, true>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo, s.fg, s.ds, s.grad,
-                       NM_COMPACT, (long long)P, sdf, 1, 1, 0, nabla, valu_tmp, 0);
+                       NM_COMPACT, (long long)P, sdf, 1, 1, 0, nabla, valu_tmp, 0, NM_NO_SLOTS);
     NM_LAUNCH_CHECK();
     hipLaunchKernelGGL((nm_col_mlp_kernel<true>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->col, s.ft, s.ds, nabla,
-                       view_dirs, 1, (long long)P, rgb, valu_tmp);
+                       view_dirs, 1, (long long)P, rgb, valu_tmp, NM_NO_SLOTS);
     NM_LAUNCH_CHECK();
     return 0;
 }

@@ -33,6 +33,7 @@ struct NmPointSrc {
     // order[group*E + j] = (ray - group*order_rays)*P + p of the j-th sample of the group (0xFFFF = padding)
     const unsigned short* order;
     int order_rays;
+    int out_by_slot;  // (with order) per-point outputs go to record index = position in the order list
     // mode 2 only: a wave walks `chain` consecutive 4-sample tiles of its 16 rays (0/1 = one tile) and
     // warm-starts every tile after the first from the tile before it (see nm_distance_kernel)
     int chain;
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(256, 4) void nm_distance_kernel(NmGridView g, NmPoi
         long long o = 0;
         if (active) {
             ds = nm_projected_distance8(x, y, z, bd, bi, verts, indicator, w1, wk, grad_out ? gr : nullptr);
-            o = nm_out_index(src, q, r, p);
+            o = (src.order && src.out_by_slot) ? (long long)blockIdx.x * blockDim.x + threadIdx.x : nm_out_index(src, q, r, p);
         } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -603,7 +604,8 @@ __global__ __launch_bounds__(64) void nm_rays_upsample_kernel(float* __restrict_
 // final merge + mid-point depths (renderer.py:255-258, :266) + warm-start bounds of the mid-points
 __global__ __launch_bounds__(64) void nm_rays_finalize_kernel(float* __restrict__ d, float* __restrict__ sdf, int* __restrict__ slot,
                                                               const float* __restrict__ radius, long long R, int cap, int n, int m,
-                                                              float* __restrict__ d_mid, float* __restrict__ bound_mid) {
+                                                              float* __restrict__ d_mid, float* __restrict__ bound_mid,
+                                                              float s_val, float* __restrict__ w_mid) {
     extern __shared__ float nm_ray_smem[];
     const NmRayLds l = nm_ray_lds(nm_ray_smem, cap);
     const long long r0 = (long long)blockIdx.x * 64;
@@ -613,9 +615,18 @@ __global__ __launch_bounds__(64) void nm_rays_finalize_kernel(float* __restrict_
     if (r < R && m > 0) nm_ray_merge(l.d + threadIdx.x * l.S, l.s + threadIdx.x * l.S, n - m, m, sl);
     if (m > 0 || slot) nm_ray_rows_store(l, d, sdf, slot, r0, R, cap, 0, n, true);
     __syncthreads();
+    const int lane = threadIdx.x;
+    // visibility weights of the mid-points (in place of the sdf row), for the zero-weight skip of the
+    // mid-point pass: the SAME function the compositing kernel evaluates later
+    if (w_mid) {
+        if (r < R) nm_ray_weights(l.s + threadIdx.x * l.S, n, s_val, l.s + threadIdx.x * l.S);
+        __syncthreads();
+        for (int rr = 0; rr < 64 && r0 + rr < R; ++rr)
+            for (int j = lane; j + 1 < n; j += 64) w_mid[(r0 + rr) * cap + j] = l.s[rr * l.S + j];
+        __syncthreads();
+    }
     // the sdf rows are no longer needed in LDS: reuse them for the radius rows (coalesced loads)
     const bool warm = slot && radius && bound_mid;
-    const int lane = threadIdx.x;
     if (warm) {
         for (int rr = 0; rr < 64 && r0 + rr < R; ++rr)
             for (int j = lane; j < n; j += 64) l.s[rr * l.S + j] = radius[(r0 + rr) * cap + j];
@@ -643,8 +654,11 @@ __global__ __launch_bounds__(64) void nm_rays_finalize_kernel(float* __restrict_
 // final sorted samples (16 rays x 4 consecutive ones: 828 + 1452; the 2032 mid-points of 16 rays
 // sorted by depth: 559 + 856).  One workgroup per group of G rays, bitonic sort in LDS on
 // (order-preserving depth key << 32 | id); which lane evaluates which sample changes no value.
+// wgt (optional, [R][cap]): samples with wgt == 0 are dropped (they sort behind the valid ones and come
+// out as padding); counter (optional): += number of kept samples.
 __global__ __launch_bounds__(256) void nm_rays_order_kernel(const float* __restrict__ d, long long R, int cap, int off,
-                                                            int P, int G, int Npow2, unsigned short* __restrict__ order) {
+                                                            int P, int G, int Npow2, unsigned short* __restrict__ order,
+                                                            const float* __restrict__ wgt, unsigned long long* __restrict__ counter) {
     extern __shared__ unsigned long long nm_sort_keys[];
     const long long grp = blockIdx.x;
     const int n = G * P, E = (n + 63) & ~63;
@@ -652,8 +666,15 @@ __global__ __launch_bounds__(256) void nm_rays_order_kernel(const float* __restr
         const int rl = i / P;
         const long long r = grp * G + rl;
         uint32_t key = 0xffffffffu;
-        if (i < n && r < R) key = nm_float_key(d[r * cap + off + (i - rl * P)]);
-        nm_sort_keys[i] = ((unsigned long long)key << 32) | (unsigned)i;
+        unsigned id = (unsigned)i;
+        if (i < n && r < R) {
+            key = nm_float_key(d[r * cap + off + (i - rl * P)]);
+            if (wgt && wgt[r * cap + off + (i - rl * P)] == 0.0f) {  // dropped: behind every valid key, id out of range
+                key = 0xffffffffu;
+                id = 0xffffu;
+            }
+        }
+        nm_sort_keys[i] = ((unsigned long long)key << 32) | id;
     }
     __syncthreads();
     for (int k = 2; k <= Npow2; k <<= 1) {
@@ -671,9 +692,16 @@ __global__ __launch_bounds__(256) void nm_rays_order_kernel(const float* __restr
             __syncthreads();
         }
     }
+    int kept = 0;
     for (int i = threadIdx.x; i < E; i += 256) {
         const unsigned id = (unsigned)(nm_sort_keys[i] & 0xffffffffu);  // valid ids sort before the padding (key ties break by id)
-        order[grp * E + i] = id < (unsigned)n ? (unsigned short)id : (unsigned short)0xffffu;
+        const bool ok = id < (unsigned)n && (nm_sort_keys[i] >> 32) != 0xffffffffull;
+        order[grp * E + i] = ok ? (unsigned short)id : (unsigned short)0xffffu;
+        kept += ok ? 1 : 0;
+    }
+    if (counter) {
+        for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
+        if ((threadIdx.x & 63) == 0 && kept) atomicAdd(counter, (unsigned long long)kept);
     }
 }
 

@@ -91,6 +91,23 @@ __device__ __forceinline__ long long nm_rec_index_local(const NmRecMap& m, const
     return r * m.stride + (m.slot ? (long long)m.slot[r * m.stride + m.off + p] : m.off + p);
 }
 
+// Point lists addressed through a depth-bucket order (nm_rays_order_kernel): point q = position in
+// the list; groups of G rays own E consecutive positions, valid entries first, 0xFFFF = no point.
+// order == nullptr: plain lists (every q < npts is a point).
+struct NmSlotMap {
+    const unsigned short* order;
+    int G, P, E;
+};
+__device__ __forceinline__ bool nm_slot_valid(const NmSlotMap& m, long long q) { return !m.order || m.order[q] != 0xffffu; }
+// (ray, sample) of position q; ray0 = first ray of q's group = (q / E) * G, which is the same for a whole
+// workgroup tile (tiles never straddle groups), so the caller computes it once from the tile base
+__device__ __forceinline__ void nm_slot_ray(const NmSlotMap& m, long long q, long long ray0, long long& ray, int& p) {
+    const unsigned id = m.order[q];
+    const unsigned rl = id / (unsigned)m.P;
+    ray = ray0 + rl;
+    p = (int)(id - rl * (unsigned)m.P);
+}
+
 struct NmGeoParams {
     NmLayer layer[NM_MAX_LAYERS];
     int D;
@@ -318,11 +335,12 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, con
                                                             const float* __restrict__ ds, const float* __restrict__ grad,
                                                             NmRecMap rmap, long long npts, float* __restrict__ sdf_out, int P,
                                                             int stride, int off, float* __restrict__ nabla_out,
-                                                            float* __restrict__ valu_tmp, int nabla_slotted) {
+                                                            float* __restrict__ valu_tmp, int nabla_slotted, NmSlotMap smap) {
     __shared__ __attribute__((aligned(16))) float act[NM_ROWS * NM_LDS_STRIDE + NM_ROWS];
     float* red = act + NM_ROWS * NM_LDS_STRIDE;
     constexpr int PTS = NABLA ? 32 : 64;
     const long long base = (long long)blockIdx.x * PTS;
+    if (smap.order && smap.order[base] == 0xffffu) return;  // no point in this tile (valid entries lead each group)
     const NmDivBase rdiv = nm_div_base(base, rmap.stride ? rmap.P : 1), odiv = nm_div_base(base, P);
     nm_phase_stamp(0);
     const int Kpad0 = prm.layer[0].Kpad;
@@ -335,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, con
         float* row = act + p * NM_LDS_STRIDE;
         float* trow = act + (32 + p) * NM_LDS_STRIDE;
         // zero padding columns (and the whole row of out-of-range points)
-        if (q >= npts) {
+        if (q >= npts || !nm_slot_valid(smap, q)) {
             for (int c = j; c < Kpad0; c += 8) row[c] = 0.f;
             if (NABLA) for (int c = j; c < Kpad0; c += 8) trow[c] = 0.f;
             continue;
@@ -391,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void nm_geo_mlp_kernel(NmGeoParams prm, con
     __syncthreads();
     if (threadIdx.x < PTS) {
         const long long q = base + threadIdx.x;
-        if (q < npts) {
+        if (q < npts && nm_slot_valid(smap, q)) {
             const float sdf = red[threadIdx.x] + prm.bd;
             long long orow;
             int op;
@@ -419,11 +437,13 @@ template <bool VALU_CHECK>
 __global__ __launch_bounds__(256, 2) void nm_col_mlp_kernel(NmColParams prm, const float* __restrict__ ft_rec,
                                                             const float* __restrict__ ds, const float* __restrict__ nabla,
                                                             const float* __restrict__ dirs, int dir_div, long long npts,
-                                                            float* __restrict__ rgb_out, float* __restrict__ valu_tmp) {
+                                                            float* __restrict__ rgb_out, float* __restrict__ valu_tmp, NmSlotMap smap) {
     __shared__ __attribute__((aligned(16))) float act[NM_ROWS * NM_LDS_STRIDE + 3 * NM_ROWS];
     float* red = act + NM_ROWS * NM_LDS_STRIDE;
     const long long base = (long long)blockIdx.x * NM_ROWS;
+    if (smap.order && smap.order[base] == 0xffffu) return;  // no point in this tile
     const NmDivBase ddiv = nm_div_base(base, dir_div);
+    const long long ray0 = smap.order ? (base / smap.E) * smap.G : 0;  // uniform: one division per workgroup
     nm_phase_stamp(0);
     const int Kpad0 = prm.layer[0].Kpad;
     const int o_d = prm.use_nabla ? 3 : 0;             // start of embed_d
@@ -434,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void nm_col_mlp_kernel(NmColParams prm, con
         const int p = task >> 3, j = task & 7;
         const long long q = base + p;
         float* row = act + p * NM_LDS_STRIDE;
-        if (q >= npts) {
+        if (q >= npts || !nm_slot_valid(smap, q)) {
             for (int c = j; c < Kpad0; c += 8) row[c] = 0.f;
             continue;
         }
@@ -457,7 +477,8 @@ __global__ __launch_bounds__(256, 2) void nm_col_mlp_kernel(NmColParams prm, con
         {
             long long ray;
             int unused_p;
-            nm_div_local(ddiv, p, ray, unused_p);
+            if (smap.order) nm_slot_ray(smap, q, ray0, ray, unused_p);
+            else nm_div_local(ddiv, p, ray, unused_p);
             const float* dv = dirs + ray * 3;
             if (j == 1) {
                 row[o_v] = dv[0];
@@ -509,9 +530,16 @@ __global__ __launch_bounds__(256, 2) void nm_col_mlp_kernel(NmColParams prm, con
     if (threadIdx.x < NM_ROWS * 3) {
         const int p = threadIdx.x / 3, c = threadIdx.x % 3;
         const long long q = base + p;
-        if (q < npts) {
+        if (q < npts && nm_slot_valid(smap, q)) {
             const float z = red[threadIdx.x] + prm.brgb[c];
-            rgb_out[q * 3 + c] = __fdiv_rn(1.0f, 1.0f + expf(-z));
+            long long oq = q;  // ordered lists: the colour goes back to its (ray, sample) position
+            if (smap.order) {
+                long long ray;
+                int sp;
+                nm_slot_ray(smap, q, ray0, ray, sp);
+                oq = ray * smap.P + sp;
+            }
+            rgb_out[oq * 3 + c] = __fdiv_rn(1.0f, 1.0f + expf(-z));
         }
     }
     nm_phase_stamp(15);

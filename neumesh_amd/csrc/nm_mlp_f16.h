@@ -306,11 +306,12 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
                                                               const float* __restrict__ ds, const float* __restrict__ grad,
                                                               NmRecMap rmap, long long npts, float* __restrict__ sdf_out, int P,
                                                               int stride, int off, float* __restrict__ nabla_out,
-                                                              int nabla_slotted) {
+                                                              int nabla_slotted, NmSlotMap smap) {
     __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE + 2 * NM_ROWS + NM_EXP_LDS_PAD];
     float* red = reinterpret_cast<float*>(tile + 2 * NM_H_PLANE);
     constexpr int PTS = NABLA ? 32 : 64;
     const long long base = (long long)blockIdx.x * PTS;
+    if (smap.order && smap.order[base] == 0xffffu) return;  // no point in this tile (valid entries lead each group)
     const NmDivBase rdiv = nm_div_base(base, rmap.stride ? rmap.P : 1), odiv = nm_div_base(base, P);
     nm_phase_stamp(0);
     NmBFrag<NM_H_CT> pre0, pre1;
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
         const int p = task >> 3, j = task & 7;
         in_ds[rd] = 0.f;
         in_fg[rd][0] = in_fg[rd][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (base + p < npts) {
+        if (base + p < npts && nm_slot_valid(smap, base + p)) {
             const long long rq = nm_rec_index_local(rmap, rdiv, base, p);
             in_ds[rd] = ds[rq];
             if (j < nchunk) in_fg[rd][0] = *reinterpret_cast<const float4*>(fg_rec + rq * prm.gdim + 4 * j);
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
         const int sel = ROUNDS > 1 ? rd : 0;
         const float dsv = sel ? in_ds[ROUNDS - 1] : in_ds[0];
         const float4 fg0 = sel ? in_fg[ROUNDS - 1][0] : in_fg[0][0], fg1 = sel ? in_fg[ROUNDS - 1][1] : in_fg[0][1];
-        if (q >= npts) {
+        if (q >= npts || !nm_slot_valid(smap, q)) {
             for (int c = j; c < Kpad0; c += 8) {
                 tile[p * NM_H_STRIDE + c] = (_Float16)0.0f;
                 tile[NM_H_PLANE + p * NM_H_STRIDE + c] = (_Float16)0.0f;
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
     __syncthreads();
     if (threadIdx.x < PTS) {
         const long long q = base + threadIdx.x;
-        if (q < npts) {
+        if (q < npts && nm_slot_valid(smap, q)) {
             const float sdf = red[threadIdx.x] + prm.bd;
             long long orow;
             int op;
@@ -426,11 +427,13 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
 __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_h_kernel(NmColParamsH prm, const float* __restrict__ ft_rec,
                                                               const float* __restrict__ ds, const float* __restrict__ nabla,
                                                               const float* __restrict__ dirs, int dir_div, long long npts,
-                                                              float* __restrict__ rgb_out) {
+                                                              float* __restrict__ rgb_out, NmSlotMap smap) {
     __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE + 6 * NM_ROWS + NM_EXP_LDS_PAD];
     float* red = reinterpret_cast<float*>(tile + 2 * NM_H_PLANE);
     const long long base = (long long)blockIdx.x * NM_ROWS;
+    if (smap.order && smap.order[base] == 0xffffu) return;  // no point in this tile
     const NmDivBase ddiv = nm_div_base(base, dir_div);
+    const long long ray0 = smap.order ? (base / smap.E) * smap.G : 0;  // uniform: one division per workgroup
     nm_phase_stamp(0);
     NmBFrag<NM_H_CT> pre0, pre1;
     nm_prefetch_b<NM_H_CT>(prm.layer[0], pre0, pre1);  // in flight during the input phase
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
         in_nb[rd][0] = in_nb[rd][1] = in_nb[rd][2] = 0.f;
         in_dv[rd][0] = in_dv[rd][1] = in_dv[rd][2] = 0.f;
         in_ft[rd][0] = in_ft[rd][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < npts) {
+        if (q < npts && nm_slot_valid(smap, q)) {
             in_ds[rd] = ds[q];
             if (j == 0 && prm.use_nabla) {
                 in_nb[rd][0] = nabla[q * 3 + 0];
@@ -460,7 +463,8 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
             }
             long long ray;
             int unused_p;
-            nm_div_local(ddiv, p, ray, unused_p);
+            if (smap.order) nm_slot_ray(smap, q, ray0, ray, unused_p);
+            else nm_div_local(ddiv, p, ray, unused_p);
             in_dv[rd][0] = dirs[ray * 3 + 0];
             in_dv[rd][1] = dirs[ray * 3 + 1];
             in_dv[rd][2] = dirs[ray * 3 + 2];
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
         const float nb[3] = {sel ? in_nb[ROUNDS - 1][0] : in_nb[0][0], sel ? in_nb[ROUNDS - 1][1] : in_nb[0][1], sel ? in_nb[ROUNDS - 1][2] : in_nb[0][2]};
         const float dv[3] = {sel ? in_dv[ROUNDS - 1][0] : in_dv[0][0], sel ? in_dv[ROUNDS - 1][1] : in_dv[0][1], sel ? in_dv[ROUNDS - 1][2] : in_dv[0][2]};
         const float4 ft0 = sel ? in_ft[ROUNDS - 1][0] : in_ft[0][0], ft1 = sel ? in_ft[ROUNDS - 1][1] : in_ft[0][1];
-        if (q >= npts) {
+        if (q >= npts || !nm_slot_valid(smap, q)) {
             for (int c = j; c < Kpad0; c += 8) {
                 tile[p * NM_H_STRIDE + c] = (_Float16)0.0f;
                 tile[NM_H_PLANE + p * NM_H_STRIDE + c] = (_Float16)0.0f;
@@ -552,9 +556,16 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
     if (threadIdx.x < NM_ROWS * 3) {
         const int p = threadIdx.x / 3, c = threadIdx.x % 3;
         const long long q = base + p;
-        if (q < npts) {
+        if (q < npts && nm_slot_valid(smap, q)) {
             const float z = red[threadIdx.x] + prm.brgb[c];
-            rgb_out[q * 3 + c] = __fdiv_rn(1.0f, 1.0f + expf(-z));
+            long long oq = q;  // ordered lists: the colour goes back to its (ray, sample) position
+            if (smap.order) {
+                long long ray;
+                int sp;
+                nm_slot_ray(smap, q, ray0, ray, sp);
+                oq = ray * smap.P + sp;
+            }
+            rgb_out[oq * 3 + c] = __fdiv_rn(1.0f, 1.0f + expf(-z));
         }
     }
     nm_phase_stamp(15);

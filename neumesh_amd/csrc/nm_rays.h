@@ -190,24 +190,37 @@ NM_HD void nm_ray_merge(float* d, float* sdf, int n, int m, SlotT* slot = nullpt
     }
 }
 
-// renderer.py:278 + :302-333.  sdf[N], d[N] sorted; rgb_mid [N-1,3]; nablas [N,3] or nullptr.
-// out: rgb[3], depth, acc, normals[3] (if nablas).
-NM_HD void nm_ray_composite(const float* sdf, const float* d, int N, float s, const float* rgb_mid,
-                            const float* nablas, int white_bkgd, float* rgb, float* depth, float* acc,
-                            float* normals, float* w_scratch) {
-    double T = 1.0;
+// sdf_to_alpha (renderer.py:17-24) + visibility weights (renderer.py:49-63, :306): w[j], j < N-1.
+// w may alias sdf (w[j] is written after sdf[j] and sdf[j+1] have been read).
+NM_HD void nm_ray_weights(const float* sdf, int N, float s, float* w) {
+    double T = 1.0;  // cumprod accumulator (float64, rounded to fp32 per element like torch CPU)
     float cdf_j = nm_sigmoid(nm_mul(sdf[0], s));
-    float r = 0.f, g = 0.f, b = 0.f, wsum = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
     for (int j = 0; j + 1 < N; ++j) {
         const float cdf_n = nm_sigmoid(nm_mul(sdf[j + 1], s));
         const float alpha = fmaxf(nm_div(nm_sub(cdf_j, cdf_n), nm_add(cdf_j, 1e-10f)), 0.0f);
-        const float w = nm_mul(alpha, (float)T);
+        w[j] = nm_mul(alpha, (float)T);
         T *= (double)nm_add(nm_sub(1.0f, alpha), 1e-10f);
         cdf_j = cdf_n;
-        w_scratch[j] = w;
-        r = nm_add(r, nm_mul(w, rgb_mid[3 * j + 0]));
-        g = nm_add(g, nm_mul(w, rgb_mid[3 * j + 1]));
-        b = nm_add(b, nm_mul(w, rgb_mid[3 * j + 2]));
+    }
+}
+
+// renderer.py:278 + :302-333.  sdf[N], d[N] sorted; rgb_mid [N-1,3]; nablas [N,3] or nullptr.
+// out: rgb[3], depth, acc, normals[3] (if nablas).
+// A mid-point whose weight is exactly 0 (alpha = 0 wherever the SDF does not decrease along the ray)
+// contributes w*c = 0 for any finite colour, and x + 0 == x: its colour is never read, so the fused
+// renderer does not evaluate the field there at all (nm_render_rays; bit-identical result).
+NM_HD void nm_ray_composite(const float* sdf, const float* d, int N, float s, const float* rgb_mid,
+                            const float* nablas, int white_bkgd, float* rgb, float* depth, float* acc,
+                            float* normals, float* w_scratch) {
+    nm_ray_weights(sdf, N, s, w_scratch);
+    float r = 0.f, g = 0.f, b = 0.f, wsum = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+    for (int j = 0; j + 1 < N; ++j) {
+        const float w = w_scratch[j];
+        if (w != 0.0f) {
+            r = nm_add(r, nm_mul(w, rgb_mid[3 * j + 0]));
+            g = nm_add(g, nm_mul(w, rgb_mid[3 * j + 1]));
+            b = nm_add(b, nm_mul(w, rgb_mid[3 * j + 2]));
+        }
         wsum = nm_add(wsum, w);
         if (nablas) {
             const float ax = nablas[3 * j], ay = nablas[3 * j + 1], az = nablas[3 * j + 2];
