@@ -403,6 +403,24 @@ def test_render_frame_properties_dtu_scale(dtu_scale, cuda_device, torch_mod):
     assert torch.equal(c_ex["near_far"], d_ex["near_far"]) and torch.equal(c_rgb, d_rgb) and torch.equal(c_rgb, b_rgb)
     nf = d_ex["near_far"].cpu().numpy()
     assert (nf[:, 1] > nf[:, 0]).all() and len(np.unique(nf[:, 0])) > 100   # a mix of hit / grazing / missing rays
+    # mid-points of weight exactly 0 are not evaluated (default) == every mid-point evaluated; and the
+    # depth-bucket lists (16- or 32-ray groups, or none) only decide which lane computes what
+    variants = []
+    try:
+        with torch.no_grad():
+            for env in ({"NEUMESH_NO_ZERO_SKIP": "1"}, {"NEUMESH_MID_GROUP": "16"}, {"NEUMESH_NO_MID_ORDER": "1"}):
+                os.environ.update(env)
+                variants.append(volume_render(_t(o, cuda_device), _t(d, cuda_device), model, rayschunk=16384, **kw))
+                for k in env:
+                    os.environ.pop(k)
+    finally:
+        for k in ("NEUMESH_NO_ZERO_SKIP", "NEUMESH_MID_GROUP", "NEUMESH_NO_MID_ORDER"):
+            os.environ.pop(k, None)
+    for v_rgb, v_depth, v_ex in variants:
+        assert torch.equal(v_rgb, b_rgb) and torch.equal(v_depth, b_depth) and torch.equal(v_ex["mask_volume"], b_ex["mask_volume"])
+        assert torch.equal(v_ex["normals_volume"], b_ex["normals_volume"])
+    w = d_ex["visibility_weights"]
+    assert 0.2 < float((w == 0).float().mean()) < 0.9   # the skip is exercised: a large share of exact zeros
 
 
 @pytest.mark.gpu
