@@ -768,7 +768,8 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     if (nm_launch_col(f, ws.pts.ft, ws.pts.ds, ws.nab_mid, ws.dirn, N - 1, mid_pts, ws.rgb_mid, stream, smap, skip_zero)) return 1;
     // alpha + compositing (renderer.py:278, 302-333)
     hipLaunchKernelGGL(nm_rays_composite_kernel, rgrid, rblock, 0, stream, ws.sdf, ws.d, (long long)R, cap, N, t->s, ws.rgb_mid,
-                       c->calc_normal ? ws.nab_pts : (const float*)nullptr, c->white_bkgd, rgb, depth, acc, c->calc_normal ? normals : (float*)nullptr);
+                       c->calc_normal ? ws.nab_pts : (const float*)nullptr, c->white_bkgd, rgb, depth, acc, c->calc_normal ? normals : (float*)nullptr,
+                       skip_zero ? (const float*)ws.bound : (const float*)nullptr);
     NM_LAUNCH_CHECK();
     if (dbg) {
         if (dbg->near_far) NM_HIP(hipMemcpyAsync(dbg->near_far, nf, (size_t)R * 8, hipMemcpyDeviceToDevice, stream));
@@ -842,7 +843,7 @@ int nm_rays_composite(const float* sdf, const float* d, int64_t R, int cap, int 
                       int white_bkgd, float* rgb, float* depth, float* acc, float* normals, nm_stream_t stream_) {
     if (R < 0 || N < 2 || N > cap || N > NM_MAX_SAMPLES || (R > 0 && (!sdf || !d || !rgb_mid || !rgb || !depth || !acc))) return nm_fail("nm_rays_composite: bad arguments");
     if (R == 0) return 0;
-    hipLaunchKernelGGL(nm_rays_composite_kernel, dim3(nm_blocks(R, 64)), dim3(64), 0, (hipStream_t)stream_, sdf, d, (long long)R, cap, N, s, rgb_mid, nablas, white_bkgd, rgb, depth, acc, normals);
+    hipLaunchKernelGGL(nm_rays_composite_kernel, dim3(nm_blocks(R, 64)), dim3(64), 0, (hipStream_t)stream_, sdf, d, (long long)R, cap, N, s, rgb_mid, nablas, white_bkgd, rgb, depth, acc, normals, (const float*)nullptr);
     NM_LAUNCH_CHECK();
     return 0;
 }

@@ -723,13 +723,13 @@ __global__ void nm_rays_composite_kernel(const float* __restrict__ sdf, const fl
                                          int cap, int N, float s, const float* __restrict__ rgb_mid,
                                          const float* __restrict__ nablas, int white_bkgd, float* __restrict__ rgb,
                                          float* __restrict__ depth, float* __restrict__ acc,
-                                         float* __restrict__ normals) {
+                                         float* __restrict__ normals, const float* __restrict__ evaluated_w) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     float w[NM_MAX_SAMPLES];
     nm_ray_composite(sdf + r * cap, d + r * cap, N, s, rgb_mid + r * (long long)(N - 1) * 3,
                      nablas ? nablas + r * (long long)N * 3 : nullptr, white_bkgd, rgb + 3 * r, depth + r, acc + r,
-                     normals ? normals + 3 * r : nullptr, w);
+                     normals ? normals + 3 * r : nullptr, w, evaluated_w ? evaluated_w + r * cap : nullptr);
 }
 
 // rend_util.get_rays for a contiguous pixel range (utils/rend_util.py:95-118,123-176)

@@ -211,12 +211,15 @@ NM_HD void nm_ray_weights(const float* sdf, int N, float s, float* w) {
 // renderer does not evaluate the field there at all (nm_render_rays; bit-identical result).
 NM_HD void nm_ray_composite(const float* sdf, const float* d, int N, float s, const float* rgb_mid,
                             const float* nablas, int white_bkgd, float* rgb, float* depth, float* acc,
-                            float* normals, float* w_scratch) {
+                            float* normals, float* w_scratch, const float* evaluated_w = nullptr) {
+    // evaluated_w (optional): the weight array the caller used to decide which mid-points to evaluate
+    // (same function, same inputs => same values; reading the decision from it keeps "not evaluated"
+    // and "not read" the same set by construction)
     nm_ray_weights(sdf, N, s, w_scratch);
     float r = 0.f, g = 0.f, b = 0.f, wsum = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
     for (int j = 0; j + 1 < N; ++j) {
         const float w = w_scratch[j];
-        if (w != 0.0f) {
+        if ((evaluated_w ? evaluated_w[j] : w) != 0.0f) {
             r = nm_add(r, nm_mul(w, rgb_mid[3 * j + 0]));
             g = nm_add(g, nm_mul(w, rgb_mid[3 * j + 1]));
             b = nm_add(b, nm_mul(w, rgb_mid[3 * j + 2]));
