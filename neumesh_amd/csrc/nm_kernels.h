@@ -577,6 +577,51 @@ __device__ __forceinline__ void nm_ray_rows_store(const NmRayLds& l, float* __re
     }
 }
 
+// In-place merge of the sorted prefix d[0..n0) with the m <= MAXM samples appended behind it, for the
+// usual case that the appended samples are themselves ascending (inverse-CDF samples of ascending u
+// are): the tail is held in registers and the two runs are merged from the back, so every element
+// moves once (<= n0 + m LDS moves, against ~m*n0/2 for the insertion sort of nm_ray_merge).  Same
+// result as nm_ray_merge -- stable, tail after equal prefix elements, slot of a tail element = its
+// position.  Returns false (nothing touched) if the tail is longer than MAXM or not ascending
+// (perturb=True): the caller falls back to nm_ray_merge.
+template <int MAXM>
+__device__ __forceinline__ bool nm_ray_merge_sorted_tail(float* d, float* sdf, int n0, int m, unsigned char* slot) {
+    if (m > MAXM) return false;
+    float td[MAXM], ts[MAXM];
+#pragma unroll
+    for (int i = 0; i < MAXM; ++i) {
+        td[i] = i < m ? d[n0 + i] : 0.f;
+        ts[i] = i < m ? sdf[n0 + i] : 0.f;
+    }
+    bool ascending = true;
+#pragma unroll
+    for (int i = 1; i < MAXM; ++i) ascending = ascending && !(i < m && td[i] < td[i - 1]);
+    if (!ascending) return false;
+    int p = n0 - 1, t = m - 1;
+    float dp = p >= 0 ? d[p] : 0.f;
+    for (int k = n0 + m - 1; t >= 0; --k) {
+        float tv = td[0], tsv = ts[0];
+#pragma unroll
+        for (int i = 1; i < MAXM; ++i) {  // register file has no dynamic index: select
+            tv = (t == i) ? td[i] : tv;
+            tsv = (t == i) ? ts[i] : tsv;
+        }
+        if (p >= 0 && dp > tv) {
+            d[k] = dp;
+            sdf[k] = sdf[p];
+            if (slot) slot[k] = slot[p];
+            --p;
+            dp = p >= 0 ? d[p] : 0.f;
+        } else {
+            d[k] = tv;
+            sdf[k] = tsv;
+            if (slot) slot[k] = (unsigned char)(n0 + t);
+            --t;
+        }
+    }
+    return true;
+}
+
 // merge the m samples appended by the previous iteration, then draw n_new new ones (+ their
 // warm-start bounds from the cached K-th-neighbour radius of the neighbouring samples).
 // Launch: 64 threads per block, nm_ray_lds_bytes(cap) dynamic LDS.
@@ -592,7 +637,7 @@ __global__ __launch_bounds__(64) void nm_rays_upsample_kernel(float* __restrict_
     float* dr = l.d + threadIdx.x * l.S;
     float* sr = l.s + threadIdx.x * l.S;
     unsigned char* sl = slot ? l.slot + threadIdx.x * l.SB : nullptr;
-    if (r < R && m > 0) nm_ray_merge(dr, sr, n - m, m, sl);
+    if (r < R && m > 0 && !nm_ray_merge_sorted_tail<16>(dr, sr, n - m, m, sl)) nm_ray_merge(dr, sr, n - m, m, sl);
     if (m > 0 || slot) nm_ray_rows_store(l, d, sdf, slot, r0, R, cap, 0, n, true);  // merged rows (+ identity slots)
     __syncthreads();
     if (r < R)
@@ -612,7 +657,8 @@ __global__ __launch_bounds__(64) void nm_rays_finalize_kernel(float* __restrict_
     const long long r = r0 + threadIdx.x;
     nm_ray_rows_load(l, d, sdf, slot, m == 0, r0, R, cap, n);
     unsigned char* sl = slot ? l.slot + threadIdx.x * l.SB : nullptr;
-    if (r < R && m > 0) nm_ray_merge(l.d + threadIdx.x * l.S, l.s + threadIdx.x * l.S, n - m, m, sl);
+    if (r < R && m > 0 && !nm_ray_merge_sorted_tail<16>(l.d + threadIdx.x * l.S, l.s + threadIdx.x * l.S, n - m, m, sl))
+        nm_ray_merge(l.d + threadIdx.x * l.S, l.s + threadIdx.x * l.S, n - m, m, sl);
     if (m > 0 || slot) nm_ray_rows_store(l, d, sdf, slot, r0, R, cap, 0, n, true);
     __syncthreads();
     const int lane = threadIdx.x;
