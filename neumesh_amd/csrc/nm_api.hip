@@ -513,14 +513,15 @@ static int nm_chain_tiles(long long R, int P) {
     return c < 1 ? 1 : (int)c;
 }
 
-// Rays per depth-bucket group of the mid-point pass: 32 (4064 samples sorted in 32 KiB of LDS; with the
-// zero-weight samples dropped, ~1700 of them remain, i.e. the sample density of a 14-ray group), fewer
-// when the per-ray sample count is larger; 0 = no ordering (lists longer than the 4096-key sort).
+// Rays per depth-bucket group of the mid-point pass: 64 (8128 samples sorted in 64 KiB of LDS; with the
+// zero-weight samples dropped ~3500 of them remain, i.e. the sample density of a 28-ray group; measured
+// K-NN time per frame: 16 rays 240 ms, 32 rays 233 ms, 64 rays 210 ms), fewer when the per-ray sample
+// count is larger; 0 = no ordering (lists longer than the 8192-key sort).
 static int nm_mid_group_rays(int N) {
     const char* e = getenv("NEUMESH_MID_GROUP");
-    int g = e ? atoi(e) : 32;
-    if (g != 16 && g != 32) g = 32;
-    while (g >= 16 && g * (N - 1) > 4096) g >>= 1;
+    int g = e ? atoi(e) : 64;
+    if (g != 16 && g != 32 && g != 64) g = 64;
+    while (g >= 16 && g * (N - 1) > 8192) g >>= 1;
     return g >= 16 ? g : 0;
 }
 
@@ -565,7 +566,8 @@ static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) 
     w.nab_pts = (float*)take((size_t)R * N * 12);
     // mid-point list positions: an upper bound over the group sizes nm_mid_group_rays can pick
     const long long slots16 = ((R + 15) / 16) * (((long long)16 * (N - 1) + 63) & ~63LL), slots32 = ((R + 31) / 32) * (((long long)32 * (N - 1) + 63) & ~63LL);
-    const long long mid_slots = slots16 > slots32 ? slots16 : slots32;
+    const long long slots64 = ((R + 63) / 64) * (((long long)64 * (N - 1) + 63) & ~63LL);
+    const long long mid_slots = slots16 > slots32 ? (slots16 > slots64 ? slots16 : slots64) : (slots32 > slots64 ? slots32 : slots64);
     w.nab_mid = (float*)take((size_t)(mid_slots > R * N ? mid_slots : R * N) * 12);
     w.slot = (int*)take((size_t)R * N * 4);
     w.radius = (float*)take((size_t)R * N * 4);
@@ -575,7 +577,8 @@ static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) 
         const size_t n_new = c->N_importance > 0 ? c->N_importance / c->N_upsample_iters : 1;
         const size_t e_fine = (size_t)((R + 63) / 64) * ((64 * n_new + 63) & ~(size_t)63);
         const size_t e16 = (size_t)((R + 15) / 16) * ((16 * (size_t)(N - 1) + 63) & ~(size_t)63), e32 = (size_t)((R + 31) / 32) * ((32 * (size_t)(N - 1) + 63) & ~(size_t)63);
-        const size_t e_mid = e16 > e32 ? e16 : e32;
+        const size_t e64 = (size_t)((R + 63) / 64) * ((64 * (size_t)(N - 1) + 63) & ~(size_t)63);
+        const size_t e_mid = e16 > e32 ? (e16 > e64 ? e16 : e64) : (e32 > e64 ? e32 : e64);
         w.order = (unsigned short*)take((e_fine > e_mid ? e_fine : e_mid) * 2);
     }
     w.slots = nm_carve(p + o, R * N, false);

@@ -408,7 +408,7 @@ def test_render_frame_properties_dtu_scale(dtu_scale, cuda_device, torch_mod):
     variants = []
     try:
         with torch.no_grad():
-            for env in ({"NEUMESH_NO_ZERO_SKIP": "1"}, {"NEUMESH_MID_GROUP": "16"}, {"NEUMESH_NO_MID_ORDER": "1"}):
+            for env in ({"NEUMESH_NO_ZERO_SKIP": "1"}, {"NEUMESH_MID_GROUP": "16"}, {"NEUMESH_MID_GROUP": "32"}, {"NEUMESH_NO_MID_ORDER": "1"}):
                 os.environ.update(env)
                 variants.append(volume_render(_t(o, cuda_device), _t(d, cuda_device), model, rayschunk=16384, **kw))
                 for k in env:
