@@ -4,6 +4,7 @@
 // -ffp-contract=off keeps the declared K-NN arithmetic (no FMA contraction); fused multiply-adds
 // are written explicitly (fmaf / MFMA) where they are wanted.
 #include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>  // library primitive for the one plain sort of the path (ray order)
 
 #include <cstdarg>
 #include <cstdio>
@@ -541,6 +542,11 @@ static int nm_ray_lds_prepare(int cap, size_t* bytes) {
 
 struct NmWorkspace {
     float *dirn, *nf0, *nf, *d, *sdf, *dmid, *probe;
+    float *rays_o_s, *rays_d_s;   // rays in spatial processing order
+    unsigned *key_in, *key_out;   // Morton keys before / after the sort
+    int *perm_in, *perm;          // perm[i] = caller's index of the i-th ray in processing order
+    void* sort_tmp;
+    size_t sort_tmp_bytes;
     float *rgb_mid, *nab_pts, *nab_mid;
     int* slot;                    // [R][N] generation position of the sample at each sorted position
     float *radius, *bound, *bound_mid;  // [R][N] K-th-neighbour distance per slot; warm-start bounds
@@ -555,6 +561,15 @@ static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) 
     char* p = (char*)base;
     size_t o = 0;
     auto take = [&](size_t bytes) { char* r = p + o; o += nm_align(bytes); return r; };
+    w.rays_o_s = (float*)take((size_t)R * 12);
+    w.rays_d_s = (float*)take((size_t)R * 12);
+    w.key_in = (unsigned*)take((size_t)R * 4);
+    w.key_out = (unsigned*)take((size_t)R * 4);
+    w.perm_in = (int*)take((size_t)R * 4);
+    w.perm = (int*)take((size_t)R * 4);
+    w.sort_tmp_bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, w.sort_tmp_bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, (size_t)R, 0, 30);
+    w.sort_tmp = (void*)take(w.sort_tmp_bytes);
     w.dirn = (float*)take((size_t)R * 12);
     w.nf0 = (float*)take((size_t)R * 8);
     w.nf = (float*)take((size_t)R * 8);
@@ -614,6 +629,21 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     const int N = c->N_samples + c->N_importance, cap = N;
     const dim3 rgrid(nm_blocks(R, 64)), rblock(64);
 
+    // processing order: rays sorted by the Morton code of their closest approach to the scene centre (see
+    // nm_ray_keys_kernel); with debug outputs requested the caller's order is kept (they are per-ray arrays)
+    const int* perm = nullptr;
+    if (!dbg && R >= 256 && !getenv("NEUMESH_NO_RAY_SORT")) {
+        hipLaunchKernelGGL(nm_ray_keys_kernel, dim3(nm_blocks(R, 256)), dim3(256), 0, stream, rays_o, rays_d, (long long)R,
+                           1.0f / fmaxf(c->obj_bounding_radius, 1e-6f), ws.key_in, ws.perm_in);
+        NM_LAUNCH_CHECK();
+        size_t tmp = ws.sort_tmp_bytes;
+        NM_HIP(rocprim::radix_sort_pairs(ws.sort_tmp, tmp, (const unsigned*)ws.key_in, ws.key_out, (const int*)ws.perm_in, ws.perm, (size_t)R, 0, 30, stream));
+        hipLaunchKernelGGL(nm_ray_gather_kernel, dim3(nm_blocks(R, 256)), dim3(256), 0, stream, rays_o, rays_d, ws.perm, (long long)R, ws.rays_o_s, ws.rays_d_s);
+        NM_LAUNCH_CHECK();
+        rays_o = ws.rays_o_s;
+        rays_d = ws.rays_d_s;
+        perm = ws.perm;
+    }
     // rays: normalise directions, sphere near/far (renderer.py:153, rend_util.py:179-199)
     hipLaunchKernelGGL(nm_rays_setup_kernel, rgrid, rblock, 0, stream, rays_o, rays_d, (long long)R, c->obj_bounding_radius, ws.dirn, ws.nf0);
     NM_LAUNCH_CHECK();
@@ -772,7 +802,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     // alpha + compositing (renderer.py:278, 302-333)
     hipLaunchKernelGGL(nm_rays_composite_kernel, rgrid, rblock, 0, stream, ws.sdf, ws.d, (long long)R, cap, N, t->s, ws.rgb_mid,
                        c->calc_normal ? ws.nab_pts : (const float*)nullptr, c->white_bkgd, rgb, depth, acc, c->calc_normal ? normals : (float*)nullptr,
-                       skip_zero ? (const float*)ws.bound : (const float*)nullptr);
+                       skip_zero ? (const float*)ws.bound : (const float*)nullptr, perm);
     NM_LAUNCH_CHECK();
     if (dbg) {
         if (dbg->near_far) NM_HIP(hipMemcpyAsync(dbg->near_far, nf, (size_t)R * 8, hipMemcpyDeviceToDevice, stream));
@@ -846,7 +876,7 @@ int nm_rays_composite(const float* sdf, const float* d, int64_t R, int cap, int 
                       int white_bkgd, float* rgb, float* depth, float* acc, float* normals, nm_stream_t stream_) {
     if (R < 0 || N < 2 || N > cap || N > NM_MAX_SAMPLES || (R > 0 && (!sdf || !d || !rgb_mid || !rgb || !depth || !acc))) return nm_fail("nm_rays_composite: bad arguments");
     if (R == 0) return 0;
-    hipLaunchKernelGGL(nm_rays_composite_kernel, dim3(nm_blocks(R, 64)), dim3(64), 0, (hipStream_t)stream_, sdf, d, (long long)R, cap, N, s, rgb_mid, nablas, white_bkgd, rgb, depth, acc, normals, (const float*)nullptr);
+    hipLaunchKernelGGL(nm_rays_composite_kernel, dim3(nm_blocks(R, 64)), dim3(64), 0, (hipStream_t)stream_, sdf, d, (long long)R, cap, N, s, rgb_mid, nablas, white_bkgd, rgb, depth, acc, normals, (const float*)nullptr, (const int*)nullptr);
     NM_LAUNCH_CHECK();
     return 0;
 }

@@ -769,13 +769,58 @@ __global__ void nm_rays_composite_kernel(const float* __restrict__ sdf, const fl
                                          int cap, int N, float s, const float* __restrict__ rgb_mid,
                                          const float* __restrict__ nablas, int white_bkgd, float* __restrict__ rgb,
                                          float* __restrict__ depth, float* __restrict__ acc,
-                                         float* __restrict__ normals, const float* __restrict__ evaluated_w) {
+                                         float* __restrict__ normals, const float* __restrict__ evaluated_w,
+                                         const int* __restrict__ perm) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
+    const long long ro = perm ? perm[r] : r;  // rays were processed in spatial order: results go back to the caller's order
     float w[NM_MAX_SAMPLES];
     nm_ray_composite(sdf + r * cap, d + r * cap, N, s, rgb_mid + r * (long long)(N - 1) * 3,
-                     nablas ? nablas + r * (long long)N * 3 : nullptr, white_bkgd, rgb + 3 * r, depth + r, acc + r,
-                     normals ? normals + 3 * r : nullptr, w, evaluated_w ? evaluated_w + r * cap : nullptr);
+                     nablas ? nablas + r * (long long)N * 3 : nullptr, white_bkgd, rgb + 3 * ro, depth + ro, acc + ro,
+                     normals ? normals + 3 * ro : nullptr, w, evaluated_w ? evaluated_w + r * cap : nullptr);
+}
+
+// ---------------------------------------------------------- spatial processing order of the rays
+// Every K-NN pass hands 16 or 64 CONSECUTIVE rays to a wave / a depth-bucket group, so their footprint
+// is only compact if consecutive rays are neighbours in space in both image directions.  A caller's
+// rays are row-major pixels (a 64-ray group = a 64x1 pixel strip); sorted by the Morton code of each
+// ray's point of closest approach to the scene centre the same group is an ~8x8 pixel patch, whose
+// cooperative traversals open ~40 % fewer nodes / vertices (host emulation, importance samples:
+// 840 + 1289 -> 498 + 929 per wave).  Rays are independent, results are scattered back (perm).
+__global__ void nm_ray_keys_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, long long R, float inv_extent,
+                                   unsigned* __restrict__ keys, int* __restrict__ idx) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float ox = rays_o[3 * r], oy = rays_o[3 * r + 1], oz = rays_o[3 * r + 2];
+    const float dx = rays_d[3 * r], dy = rays_d[3 * r + 1], dz = rays_d[3 * r + 2];
+    const float dd = fmaxf(dx * dx + dy * dy + dz * dz, 1e-24f);
+    const float t = -(ox * dx + oy * dy + oz * dz) / dd;
+    const float c[3] = {ox + t * dx, oy + t * dy, oz + t * dz};
+    unsigned code = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float u = c[a] * inv_extent * 0.5f + 0.5f;  // [-extent, extent] -> [0, 1]
+        u = !(u > 0.f) ? 0.f : (u > 1.f ? 1.f : u);  // (NaN -> 0)
+        unsigned q = (unsigned)(u * 1023.0f);
+        q = (q | (q << 16)) & 0x030000ffu;
+        q = (q | (q << 8)) & 0x0300f00fu;
+        q = (q | (q << 4)) & 0x030c30c3u;
+        q = (q | (q << 2)) & 0x09249249u;
+        code |= q << a;
+    }
+    keys[r] = code;
+    idx[r] = (int)r;
+}
+__global__ void nm_ray_gather_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d, const int* __restrict__ perm,
+                                     long long R, float* __restrict__ o_s, float* __restrict__ d_s) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const long long s = perm[r];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        o_s[3 * r + a] = rays_o[3 * s + a];
+        d_s[3 * r + a] = rays_d[3 * s + a];
+    }
 }
 
 // rend_util.get_rays for a contiguous pixel range (utils/rend_util.py:95-118,123-176)
