@@ -518,6 +518,14 @@ static int nm_chain_tiles(long long R, int P) {
 // zero-weight samples dropped ~3500 of them remain, i.e. the sample density of a 28-ray group; measured
 // K-NN time per frame: 16 rays 240 ms, 32 rays 233 ms, 64 rays 210 ms), fewer when the per-ray sample
 // count is larger; 0 = no ordering (lists longer than the 8192-key sort).
+// Rays per depth-bucket group of an importance-sample pass (n_new samples per ray, <= 8192 keys per sort)
+static int nm_fine_group_rays(int n_new) {
+    const char* e = getenv("NEUMESH_FINE_GROUP");
+    int g = e ? atoi(e) : 128;   // (Morton-ordered rays: 64 -> 170 ms of K-NN per frame, 128..512 -> 166 ms)
+    if (g != 64 && g != 128 && g != 256 && g != 512) g = 128;
+    while (g >= 64 && g * n_new > 8192) g >>= 1;
+    return g >= 64 ? g : 0;
+}
 static int nm_mid_group_rays(int N) {
     const char* e = getenv("NEUMESH_MID_GROUP");
     int g = e ? atoi(e) : 64;
@@ -590,7 +598,7 @@ static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) 
     w.bound_mid = (float*)take((size_t)R * N * 4);
     {   // lane assignments of one pass: importance samples (64-ray groups) or mid-points (16-ray groups)
         const size_t n_new = c->N_importance > 0 ? c->N_importance / c->N_upsample_iters : 1;
-        const size_t e_fine = (size_t)((R + 63) / 64) * ((64 * n_new + 63) & ~(size_t)63);
+        const size_t e_fine = (size_t)(R + 512) * n_new + 64;  // any group size: ceil(R/g)*g*n_new <= (R+g)*n_new (g*n_new is a multiple of 64)
         const size_t e16 = (size_t)((R + 15) / 16) * ((16 * (size_t)(N - 1) + 63) & ~(size_t)63), e32 = (size_t)((R + 31) / 32) * ((32 * (size_t)(N - 1) + 63) & ~(size_t)63);
         const size_t e64 = (size_t)((R + 63) / 64) * ((64 * (size_t)(N - 1) + 63) & ~(size_t)63);
         const size_t e_mid = e16 > e32 ? (e16 > e64 ? e16 : e64) : (e32 > e64 ? e32 : e64);
@@ -735,13 +743,14 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
             src.out_stride = cap;
             src.out_off = n;
             src.order = nullptr;
-            if (64 * n_new <= 4096) {  // LDS sort capacity (ids are 16-bit)
+            const int fine_g = nm_fine_group_rays(n_new);
+            if (fine_g > 0) {
                 int np2 = 64;
-                while (np2 < 64 * n_new) np2 <<= 1;
-                hipLaunchKernelGGL(nm_rays_order_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), (size_t)np2 * 8, stream, ws.d, (long long)R, cap, n, n_new, 64, np2, ws.order, (const float*)nullptr, (unsigned long long*)nullptr);
+                while (np2 < fine_g * n_new) np2 <<= 1;
+                hipLaunchKernelGGL(nm_rays_order_kernel, dim3((unsigned)((R + fine_g - 1) / fine_g)), dim3(256), (size_t)np2 * 8, stream, ws.d, (long long)R, cap, n, n_new, fine_g, np2, ws.order, (const float*)nullptr, (unsigned long long*)nullptr);
                 NM_LAUNCH_CHECK();
                 src.order = ws.order;
-                src.order_rays = 64;
+                src.order_rays = fine_g;
             }
             if (nm_launch_distance(g, src, (long long)R * n_new, t->indicator_vector, t->indicator_weight, ws.slots.ds, nullptr, nullptr, nullptr, want_grad ? ws.slots.grad : nullptr, stream, ws.radius, ga_slots)) return 1;
             const NmRecMap rm = {n_new, cap, n, nullptr};
