@@ -568,3 +568,56 @@ def test_training_render_forward_and_gradients_match_reference(small, cuda_devic
         c = volume_render(o, d, model, **dict(kw, perturb=True))[0]
     assert torch.equal(a, b) and not torch.equal(a, c)
     assert float((a - rgb0).abs().mean()) < 0.05 and bool(torch.isfinite(a).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(N_samples=32, N_importance=32, N_upsample_iters=4, calc_normal=False, white_bkgd=True, bounded_near_far=True),
+    dict(N_samples=48, N_importance=24, N_upsample_iters=3, calc_normal=True, white_bkgd=False, bounded_near_far=False),
+    dict(N_samples=64, N_importance=0, N_upsample_iters=4, calc_normal=True, white_bkgd=False, bounded_near_far=True),
+    dict(N_samples=96, N_importance=96, N_upsample_iters=2, calc_normal=True, white_bkgd=True, bounded_near_far=True),
+])
+def test_fused_renderer_equals_staged_renderer_other_configs(dtu_scale, cuda_device, torch_mod, cfg):
+    """Ragged ray counts and sampling configurations other than the headline one (lego-style 32+32 /
+    white background, no importance samples, 3 or 2 up-sampling iterations, sphere near/far, 192 samples per
+    ray): the fused renderer -- spatial ray order, first/last-hit probes, depth-bucket lists, zero-weight
+    skip -- against the staged renderer, which runs every stage plainly through the model's methods."""
+    torch = torch_mod
+    from neumesh_amd import synthetic
+    from neumesh_amd.renderer import volume_render
+    mesh, state, model = dtu_scale
+
+    class Plain:   # exposes only the field methods => volume_render takes the staged path
+        def __init__(self, m):
+            self.m = m
+
+        def compute_distance(self, xyz):
+            return self.m.compute_distance(xyz)
+
+        def forward_density_only(self, xyz):
+            return self.m.forward_density_only(xyz)
+
+        def forward_with_nablas(self, xyz):
+            return self.m.forward_with_nablas(xyz)
+
+        def forward_s(self):
+            return self.m.forward_s()
+
+        def forward(self, xyz, view_dirs):
+            return self.m.forward(xyz, view_dirs)
+
+    H = W = 800
+    o, d = synthetic.camera_rays(synthetic.orbit_pose(9), synthetic.pinhole_intrinsics(H, W), H, W, start=390 * W, count=20 * W)
+    sel = np.arange(0, 20 * W, 7)[:1999]   # 1999 rays: not a multiple of 16 / 64, grazing and missing rays included
+    o, d = _t(o[sel], cuda_device), _t(d[sel], cuda_device)
+    kw = dict(cfg, perturb=False, detailed_output=False)
+    with torch.no_grad():
+        rgb_f, depth_f, ex_f = volume_render(o, d, model, rayschunk=1999, **kw)
+        rgb_c, depth_c, ex_c = volume_render(o, d, model, rayschunk=777, **kw)     # three chunks on two streams
+        rgb_s, depth_s, ex_s = volume_render(o, d, Plain(model), rayschunk=1000, **kw)
+    for a, b in ((rgb_f, rgb_c), (depth_f, depth_c), (ex_f["mask_volume"], ex_c["mask_volume"]),
+                 (rgb_f, rgb_s), (depth_f, depth_s), (ex_f["mask_volume"], ex_s["mask_volume"])):
+        assert torch.equal(a, b)
+    if cfg["calc_normal"]:
+        assert torch.equal(ex_f["normals_volume"], ex_s["normals_volume"]) and torch.equal(ex_f["normals_volume"], ex_c["normals_volume"])
+    assert bool(torch.isfinite(rgb_f).all()) and float(rgb_f.min()) >= 0.0 and float(rgb_f.max()) <= 1.0 + 1e-5
