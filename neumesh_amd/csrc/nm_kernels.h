@@ -291,6 +291,27 @@ __global__ __launch_bounds__(256) void nm_interp_kernel(const float* __restrict_
     nm_gather_interp(table, dim, bi, wk, active, q, out);
 }
 
+// Upper bound of the squared K-th-neighbour distance of (x,y,z) from 8 KNOWN vertices (the neighbours of
+// a nearby query): their largest exact distance to the new query.  Far from the surface the K-NN set
+// barely changes between consecutive samples of a ray, so this is within a hair of the true radius,
+// whereas "radius of the previous sample + step" (triangle inequality) over-covers the surface cap by a
+// factor that grows with the distance to the surface.  `src_lane` holds the indices; all lanes call.
+__device__ __forceinline__ float nm_bound_from_neighbours(const float* __restrict__ verts, const int (&nbr)[8], int src_lane,
+                                                          bool usable, float x, float y, float z) {
+    float worst = 0.f;
+    bool ok = usable;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = __shfl(nbr[k], src_lane);
+        ok = ok && i != 0x7fffffff;
+        if (ok) {
+            const float vx = verts[3 * (size_t)i], vy = verts[3 * (size_t)i + 1], vz = verts[3 * (size_t)i + 2];
+            worst = fmaxf(worst, nm_dist2(x, y, z, vx, vy, vz));
+        }
+    }
+    return ok ? worst : NM_INF_F;
+}
+
 // ----------------------------------------------------------------------------- plain K-NN
 template <int K>
 __global__ __launch_bounds__(256) void nm_knn_kernel(NmGridView g, NmPointSrc src, long long Q, int Kout,
@@ -335,6 +356,7 @@ __global__ __launch_bounds__(256, 4) void nm_distance_kernel(NmGridView g, NmPoi
     const int chain = CHAIN ? nm_chain_len(src) : 1;
     const int lane = threadIdx.x & 63;
     float prev_rad = NM_INF_F, prev_dep = 0.f;
+    int prev_bi[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
     for (int it = 0; it < chain; ++it) {
         long long q, r;
         int p;
@@ -350,6 +372,9 @@ __global__ __launch_bounds__(256, 4) void nm_distance_kernel(NmGridView g, NmPoi
                 const float b = (pr + fabsf(dep - pd)) * 1.0001f + 1e-5f;
                 init = fminf(init, b * b);
             }
+            // ... and from the exact distances to that sample's 8 neighbours (usually far tighter)
+            const float nb = nm_bound_from_neighbours(verts, prev_bi, lane | 3, it > 0 && active, x, y, z);
+            init = fminf(init, nb);
         }
         float bd[8], wk[8], gr[3];
         int bi[8];
@@ -364,6 +389,10 @@ __global__ __launch_bounds__(256, 4) void nm_distance_kernel(NmGridView g, NmPoi
         }
         prev_rad = (active && bi[7] != 0x7fffffff) ? nm_sqrt(bd[7]) : NM_INF_F;
         prev_dep = dep;
+        if (CHAIN) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) prev_bi[k] = active ? bi[k] : 0x7fffffff;
+        }
         float ds = 0.f;
         long long o = 0;
         if (active) {
@@ -429,9 +458,12 @@ __global__ __launch_bounds__(256, 4) void nm_probe_bounds_kernel(NmGridView g, c
     const int T = (P + 3) >> 2;
     int first_idx = -1, last_idx = -1;
     // one step: probe p of this lane's ray; returns ds (and the K-th-neighbour radius for the next warm start)
-    auto probe = [&](int p, bool act, float init, float& dep, float& rad) -> float {
+    int nbr[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};  // of this lane's last probe
+    // src_lane: the lane of this ray whose last probe is the closest one already evaluated (-1: none)
+    auto probe = [&](int p, bool act, float init, int src_lane, float& dep, float& rad) -> float {
         dep = nm_lerp_depth(n0, f0, nm_linspace01(p < P ? p : P - 1, P));
         const float x = nm_add(ox, nm_mul(dep, dx)), y = nm_add(oy, nm_mul(dep, dy)), z = nm_add(oz, nm_mul(dep, dz));
+        if (src_lane >= 0) init = fminf(init, nm_bound_from_neighbours(verts, nbr, src_lane, act, x, y, z));
         unsigned long long kk[8];
         nm_knn_wave<8>(g, x, y, z, act, kk, init);
         float bd[8], wk[8];
@@ -440,6 +472,7 @@ __global__ __launch_bounds__(256, 4) void nm_probe_bounds_kernel(NmGridView g, c
         for (int k = 0; k < 8; ++k) {
             bd[k] = nm_key_d2(kk[k]);
             bi[k] = nm_key_idx(kk[k]);
+            nbr[k] = act ? bi[k] : 0x7fffffff;
         }
         rad = (act && bi[7] != 0x7fffffff) ? nm_sqrt(bd[7]) : NM_INF_F;
         return act ? nm_projected_distance8(x, y, z, bd, bi, verts, indicator, w1, wk, nullptr) : NM_INF_F;
@@ -459,7 +492,7 @@ __global__ __launch_bounds__(256, 4) void nm_probe_bounds_kernel(NmGridView g, c
                 const float b = (pr + fabsf(dep_here - pd)) * 1.0001f + 1e-5f;
                 init = b * b;
             }
-            const float ds = probe(p, act, init, dep, rad);
+            const float ds = probe(p, act, init, t > 0 ? (quad | 3) : -1, dep, rad);
             prev_rad = rad;
             prev_dep = dep;
             const unsigned hm = (unsigned)((__ballot(act && ds < thresh) >> quad) & 0xfull);
@@ -482,7 +515,7 @@ __global__ __launch_bounds__(256, 4) void nm_probe_bounds_kernel(NmGridView g, c
                 const float b = (pr + fabsf(dep_here - pd)) * 1.0001f + 1e-5f;
                 init = b * b;
             }
-            const float ds = probe(p, act, init, dep, rad);
+            const float ds = probe(p, act, init, started ? quad : -1, dep, rad);
             prev_rad = rad;
             prev_dep = dep;
             started = true;
