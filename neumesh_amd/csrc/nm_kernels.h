@@ -338,8 +338,11 @@ __global__ __launch_bounds__(256) void nm_knn_kernel(NmGridView g, NmPointSrc sr
 // ------------------------------------------------- K-NN + weights + projected signed distance
 // (models/mesh_grid.py:88-144 fused; nothing of shape [Q,8,3] is ever materialised)
 // Any output pointer may be null.  ds_out is indexed by q (compact).
+// Occupancy: 6 waves per SIMD (<= 85 VGPRs; the distance epilogue spills a little).  The traversal is
+// bound by scalar-load latency, so waves per SIMD matter more than registers: K-NN time per frame with 4
+// waves 156 ms, 5: 141, 6: 136, 7: 155 (spills reach the traversal), 8: 540.
 template <bool CHAIN>
-__global__ __launch_bounds__(256, 4) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
+__global__ __launch_bounds__(256, 6) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
                                                           const float* __restrict__ verts,
                                                           const float* __restrict__ indicator, float w1,
                                                           float* __restrict__ ds_out, int* __restrict__ idx32_out,
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256, 4) void nm_distance_kernel(NmGridView g, NmPoi
 // ray has its last one.  Results are the reference's exactly: the same probes decide, the skipped
 // ones cannot change a min / max.  Replaces a P-probe K-NN pass + the reduction kernel + the
 // [R,P] probe array.
-__global__ __launch_bounds__(256, 4) void nm_probe_bounds_kernel(NmGridView g, const float* __restrict__ rays_o,
+__global__ __launch_bounds__(256, 6) void nm_probe_bounds_kernel(NmGridView g, const float* __restrict__ rays_o,
                                                                  const float* __restrict__ dirn, const float* __restrict__ nearfar0,
                                                                  long long R, int P, float thresh, const float* __restrict__ verts,
                                                                  const float* __restrict__ indicator, float w1,
