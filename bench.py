@@ -70,7 +70,7 @@ def frame_rays(frame, H, W):
     return synthetic.camera_rays(synthetic.orbit_pose(frame), synthetic.pinhole_intrinsics(H, W), H, W)
 
 
-def cpu_baseline(mesh, model, H, W, n_rays, gpu_rgb_frame0, rays0=None):
+def cpu_baseline(mesh, model, H, W, n_rays, gpu_rgb_frame0, rays0=None, samples=128, white_bkgd=False, calc_normal=True):
     """Oracle (CPU restatement of the reference) on a strided sample of frame 0's rays."""
     from oracle import compare, field as ofield, knn as oknn, render as orender
     state = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
@@ -80,13 +80,13 @@ def cpu_baseline(mesh, model, H, W, n_rays, gpu_rgb_frame0, rays0=None):
     orc.knn_fn = lambda q, v, K: oknn.knn_kdtree(q, v, K, tree=tree)
     o, d = frame_rays(0, H, W) if rays0 is None else rays0   # the very rays the GPU rendered
     sel = np.linspace(0, H * W - 1, n_rays).astype(np.int64)
-    cfg = orender.RenderConfig(calc_normal=True)
+    cfg = orender.RenderConfig(calc_normal=calc_normal, white_bkgd=white_bkgd, N_samples=samples // 2, N_importance=samples // 2)
     orender.render_rays(orc, o[sel[:8]], d[sel[:8]], cfg)  # warm caches / thread pools
     t = time.perf_counter()
     out = orender.render_rays(orc, o[sel], d[sel], cfg)
     dt = time.perf_counter() - t
     res = {"value": n_rays / dt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
-           "sample": f"{n_rays} rays strided over frame 0 of the same 800x800x128 workload, {dt:.1f} s; numpy fp32 oracle + "
+           "sample": f"{n_rays} rays strided over frame 0 of the same {H}x{W}x{samples} workload, {dt:.1f} s; numpy fp32 oracle + "
                      f"scipy cKDTree candidates re-ranked with the declared fp32 arithmetic (BLAS/OpenMP threads = all cores)"}
     parity = None
     if gpu_rgb_frame0 is not None:
@@ -217,6 +217,8 @@ def main():
     ap.add_argument("--mlp-precision", choices=["f16x2", "fp32"], default="f16x2",
                     help="MLP arithmetic: split-half f16 MFMA (default; 22-bit operands, fp32 accumulation) or fp32 MFMA")
     ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU-baseline sample (0 disables)")
+    ap.add_argument("--samples", type=int, default=128, help="samples per ray, half coarse / half importance (BASELINE configs[2], lego: 64)")
+    ap.add_argument("--white-bkgd", action="store_true", help="white background compositing (NeRF-synthetic scenes, BASELINE configs[2])")
     ap.add_argument("--no-normals", action="store_true",
                     help="calc_normal=False (SURVEY 8d config 2 asks for both): no nablas at the N sample points, no normals_volume")
     args = ap.parse_args()
@@ -243,7 +245,10 @@ def main():
 
     mesh, model = build_scene(args.V, dev)
     model.mlp_precision = args.mlp_precision
-    cfg = make_render_cfg(calc_normal=not args.no_normals)
+    if args.samples < 8 or args.samples % 8:
+        raise SystemExit("--samples must be a multiple of 8 (two halves, four up-sampling iterations)")
+    cfg = make_render_cfg(calc_normal=not args.no_normals, N_samples=args.samples // 2, N_importance=args.samples // 2,
+                          white_bkgd=args.white_bkgd)
     n_rays = args.H * args.W
     total_steps = args.warmup + args.steps
     from neumesh_amd import synthetic
@@ -314,14 +319,14 @@ def main():
         mlp_ms = sum(prof[k]["ms"] for k in ("geo_mlp", "geo_mlp_tangent", "color_mlp"))
         kd = prof["knn_distance"]
         out = {
-            "metric": "rays/sec at 800x800x128 samples (DTU scan63 shape, synthetic scene S-DTU)",
+            "metric": f"rays/sec at {args.H}x{args.W}x{args.samples} samples (DTU scan63 shape, synthetic scene S-DTU)",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_frame": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x2-split (22-bit operands, fp32 accumulate; K-NN and per-ray stages fp32)" if split else "f32", "data": "synthetic",
-            "config": {"workload": f"S-DTU V={args.V} {args.H}x{args.W} rays/frame/GPU, 64+64 samples, bounded_near_far (256 probes), "
-                                   + (f"calc_normal, per ray 639 K-NN points (511 searched, 128 reused), 255 geometry-MLP evaluations with nablas (the reference's 128 forward-only ones at the same points are the value rows of these) + 127 colour-MLP"
-                                    if not args.no_normals else "calc_normal=False, per ray 639 K-NN points (511 searched, 128 reused), 128 forward-only + 127 nabla geometry-MLP evaluations + 127 colour-MLP"),
+            "config": {"workload": f"S-DTU V={args.V} {args.H}x{args.W} rays/frame/GPU, {args.samples // 2}+{args.samples // 2} samples{', white background' if args.white_bkgd else ''}, bounded_near_far (256 probes), "
+                                   + (f"calc_normal, per ray {256 + 3 * args.samples - 1} K-NN points ({256 + 2 * args.samples - 1} searched at most, {args.samples} reused), {2 * args.samples - 1} geometry-MLP evaluations with nablas (the reference's {args.samples} forward-only ones at the same points are the value rows of these) + {args.samples - 1} colour-MLP; probes between the first and last hit and mid-points of weight 0 are not evaluated"
+                                    if not args.no_normals else f"calc_normal=False, per ray {256 + 3 * args.samples - 1} K-NN points ({256 + 2 * args.samples - 1} searched at most, {args.samples} reused), {args.samples} forward-only + {args.samples - 1} nabla geometry-MLP evaluations + {args.samples - 1} colour-MLP; probes between the first and last hit and mid-points of weight 0 are not evaluated"),
                        "rayschunk": args.rayschunk or n_rays, "parallelism": f"rays sharded: {world} GPU(s) x 1 frame per step, 1 all-gather of pixels"},
             "roofline": {"bound": "mfma", "kernel": ({"geo_mlp": "nm_geo_mlp_h_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_h_kernel<true>",
                                                       "color_mlp": "nm_col_mlp_h_kernel"} if split else
@@ -344,7 +349,8 @@ def main():
         if world == 1 and args.cpu_rays > 0:
             try:
                 rays0 = (rays[0][0].cpu().numpy(), rays[0][1].cpu().numpy())
-                base, parity = cpu_baseline(mesh, model, args.H, args.W, args.cpu_rays, rgb0, rays0)
+                base, parity = cpu_baseline(mesh, model, args.H, args.W, args.cpu_rays, rgb0, rays0, samples=args.samples,
+                                            white_bkgd=args.white_bkgd, calc_normal=not args.no_normals)
                 out["cpu_baseline"] = base
                 if parity:
                     out["parity_vs_oracle"] = parity
