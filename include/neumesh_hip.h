@@ -9,6 +9,10 @@
  *   - every entry point that launches work takes an explicit stream (hipStream_t passed as
  *     void*), enqueues asynchronously and does NOT synchronise (exception: nm_grid_create and
  *     nm_field_create/update, one-off setup calls, which synchronise the stream).
+ *   - the library reads no environment variables: every switch is an argument (nm_render_cfg.flags
+ *     and the tuning fields next to it).  Calls on different handles / streams may come from
+ *     different threads; the only process-wide state is the profiling log (nm_profile_*), which
+ *     is mutex-protected and meant for one measuring thread.
  *   - return value: 0 = ok, non-zero = error; nm_last_error() gives a thread-local message.
  *   - all floating point is IEEE fp32; K-NN indices are int64 at this boundary because the
  *     reference indexes tensors with them (models/mesh_grid.py:126,134-136;
@@ -35,7 +39,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 3
+#define NM_ABI_VERSION 4
 #define NM_MAX_K 32
 
 typedef struct nm_grid_s* nm_grid_t;    /* spatial index over the mesh vertices */
@@ -158,7 +162,23 @@ typedef struct nm_render_cfg {
     int32_t probe_grid;          /* 256 (compute_bounded_near_far sample_grid) */
     float probe_thresh;          /* 0.1 (distance_thresh) */
     float near_bypass, far_bypass; /* < 0 => unset */
+    uint32_t flags;              /* NM_RENDER_* bits, 0 = defaults */
+    int32_t chain_tiles;         /* regular-grid passes: max 4-sample tiles a wave chains; 0 = default (32) */
+    int32_t fine_group_rays;     /* rays per depth-bucket group of an importance pass: 64/128/256/512; 0 = default (128) */
+    int32_t mid_group_rays;      /* rays per depth-bucket group of the mid-point pass: 16/32/64; 0 = default (64) */
 } nm_render_cfg;
+
+/* nm_render_cfg.flags.  None of them changes a result bit (tests compare the variants); they select
+ * the evaluation strategy, mostly for A/B measurements:
+ *   FULL_PROBES   evaluate all probe_grid probes of compute_bounded_near_far (renderer.py:79-102)
+ *                 instead of only those before the first / after the last one below the threshold
+ *   NO_ZERO_SKIP  evaluate the mid-points whose visibility weight is exactly 0 as well
+ *   NO_RAY_SORT   process the rays in the caller's order (default: Morton order of closest approach)
+ *   NO_MID_ORDER  hand the mid-points to waves as (16 rays x 4 samples) tiles, not by depth buckets */
+#define NM_RENDER_FULL_PROBES 1u
+#define NM_RENDER_NO_ZERO_SKIP 2u
+#define NM_RENDER_NO_RAY_SORT 4u
+#define NM_RENDER_NO_MID_ORDER 8u
 
 int64_t nm_render_workspace_bytes(const nm_render_cfg* cfg, int64_t R);
 
@@ -225,18 +245,21 @@ int nm_make_rays(const nm_camera* cam, int64_t first_pixel, int64_t count, float
                  float* rays_d, nm_stream_t stream);
 
 /* -------------------------------------------------------------------------- instrumentation
- * Launches `iters` back-to-back passes of one internal kernel on `stream`, bracketed by HIP
- * events recorded on that same stream; returns the average duration in milliseconds.
- * which: 0 = K-NN+distance, 1 = geometry MLP (density only), 2 = geometry MLP (+tangent),
- *        3 = colour MLP.  Used by bench.py for the roofline figure. */
-/* In-stream timing of the hot kernels inside ordinary calls (nm_render_rays, nm_field_*):
+ * In-stream timing of the hot kernels inside ordinary calls (nm_render_rays, nm_field_*):
  * nm_profile_enable(1) clears the log and starts bracketing every launch of the K-NN/distance,
  * geometry-MLP (without / with tangent) and colour-MLP kernels with HIP events recorded on the
  * launch stream; nm_profile_read(kind) waits for those events and returns the summed kernel
- * time, the number of launches and the number of points processed.  kind: as `which` below. */
+ * time, the number of launches and the number of points processed.
+ * kind: 0 = K-NN+distance (units = points actually SEARCHED: probes skipped by the first/last-hit
+ *           walk and zero-weight mid-points are not counted),
+ *       1 = geometry MLP (density only), 2 = geometry MLP (+tangent), 3 = colour MLP.
+ * Process-wide log, mutex-protected; intended for one measuring thread (bench.py). */
 int nm_profile_enable(int on);
 int nm_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* units);
 
+/* Launches `iters` back-to-back passes of one internal kernel on `stream`, bracketed by HIP
+ * events recorded on that same stream; returns the average duration in milliseconds.
+ * which: as `kind` above (the MLP kernels get their inputs from one untimed K-NN pass). */
 int nm_time_kernel(nm_field_t f, nm_grid_t g, const nm_field_tables* t, int which,
                    const float* xyz, const float* view_dirs, int64_t P, void* scratch,
                    int iters, float* avg_ms, nm_stream_t stream);

@@ -11,7 +11,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_K = 32
 
 
@@ -41,7 +41,13 @@ class RenderCfg(C.Structure):
     _fields_ = [("obj_bounding_radius", C.c_float), ("N_samples", C.c_int32), ("N_importance", C.c_int32),
                 ("N_upsample_iters", C.c_int32), ("bounded_near_far", C.c_int32), ("calc_normal", C.c_int32),
                 ("white_bkgd", C.c_int32), ("probe_grid", C.c_int32), ("probe_thresh", C.c_float),
-                ("near_bypass", C.c_float), ("far_bypass", C.c_float)]
+                ("near_bypass", C.c_float), ("far_bypass", C.c_float),
+                ("flags", C.c_uint32), ("chain_tiles", C.c_int32), ("fine_group_rays", C.c_int32),
+                ("mid_group_rays", C.c_int32)]
+
+
+# nm_render_cfg.flags (include/neumesh_hip.h)
+RENDER_FULL_PROBES, RENDER_NO_ZERO_SKIP, RENDER_NO_RAY_SORT, RENDER_NO_MID_ORDER = 1, 2, 4, 8
 
 
 class Camera(C.Structure):

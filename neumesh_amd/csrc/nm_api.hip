@@ -6,9 +6,11 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>  // library primitive for the one plain sort of the path (ray order)
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -44,29 +46,43 @@ static int nm_fail(const char* fmt, ...) {
 // When enabled (nm_profile_enable), every launch of the four hot kernels is bracketed by a pair
 // of HIP events recorded on the SAME stream the kernel is launched on; nm_profile_read sums the
 // elapsed times per kernel kind.  Event records do not serialise anything; disabled by default.
+// The log is the library's only process-wide state: one mutex guards it (the hot path takes it only
+// while profiling is on -- `on` is an atomic flag read first).
 enum { NM_K_DISTANCE = 0, NM_K_GEO = 1, NM_K_GEO_NABLA = 2, NM_K_COLOR = 3, NM_K_KINDS = 4 };
-// `counted` launches (the mid-point pass with the zero-weight skip) process a data-dependent number
-// of points: the order kernel adds it to a device counter, which nm_profile_read adds to the units.
-struct NmProfRec { hipEvent_t a, b; int kind; long long units; bool counted; };
-static bool g_prof_on = false;
-static std::vector<NmProfRec> g_prof;
-static unsigned long long* g_prof_counter = nullptr;  // device
+// Launches that process a data-dependent number of points add it to a device counter instead of
+// `units`: counter 0 = mid-points kept by the zero-weight skip (the order kernel counts them; the
+// K-NN, geometry and colour launches of the mid-point pass each process exactly those), counter 1 =
+// probes actually searched by nm_probe_bounds_kernel.
+enum { NM_CNT_NONE = -1, NM_CNT_MID = 0, NM_CNT_PROBE = 1, NM_CNT_N = 2 };
+struct NmProfRec { hipEvent_t a, b; int kind; long long units; int counter; };
+struct NmProfState {
+    std::atomic<bool> on{false};
+    std::mutex mu;
+    std::vector<NmProfRec> recs;
+    unsigned long long* counters = nullptr;  // device, NM_CNT_N entries (on the device profiling was enabled on)
+};
+static NmProfState g_prof;
+static unsigned long long* nm_prof_counter(int which) {
+    return (g_prof.on.load(std::memory_order_relaxed) && g_prof.counters) ? g_prof.counters + which : nullptr;
+}
 struct NmProfScope {
     NmProfRec r;
     hipStream_t s;
     bool on;
-    NmProfScope(int kind, long long units, hipStream_t stream, bool counted = false) : s(stream), on(g_prof_on) {
+    NmProfScope(int kind, long long units, hipStream_t stream, int counter = NM_CNT_NONE) : s(stream), on(g_prof.on.load(std::memory_order_relaxed)) {
         if (!on) return;
         r.kind = kind;
         r.units = units;
-        r.counted = counted;
-        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
+        r.counter = counter;
+        if (hipEventCreate(&r.a) != hipSuccess) { on = false; return; }
+        if (hipEventCreate(&r.b) != hipSuccess) { (void)hipEventDestroy(r.a); on = false; return; }
         (void)hipEventRecord(r.a, s);
     }
     ~NmProfScope() {
         if (!on) return;
         (void)hipEventRecord(r.b, s);
-        g_prof.push_back(r);
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        g_prof.recs.push_back(r);
     }
 };
 
@@ -202,7 +218,7 @@ static int nm_launch_distance(nm_grid_t g, const NmPointSrc& src, long long Q, c
                               float* ds, int* idx32, long long* idx64, float* w, float* grad, hipStream_t stream,
                               float* radius = nullptr, NmGather ga = NM_NO_GATHER, bool counted = false) {
     if (Q <= 0) return 0;
-    NmProfScope prof(NM_K_DISTANCE, counted ? 0 : Q, stream, counted);
+    NmProfScope prof(NM_K_DISTANCE, counted ? 0 : Q, stream, counted ? NM_CNT_MID : NM_CNT_NONE);
     if (nm_chain_len(src) > 1)
         hipLaunchKernelGGL(nm_distance_kernel<true>, dim3(nm_query_blocks(src, Q)), dim3(256), 0, stream, g->view, src, Q, g->verts,
                            indicator, w1, ds, idx32, idx64, w, grad, radius, ga.geo_table, ga.gdim, ga.fg, ga.col_table, ga.cdim, ga.ft);
@@ -269,6 +285,7 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
     if (need > f->blob_floats) {
         if (f->blob) hipFree(f->blob);
         f->blob = nullptr;
+        f->blob_floats = 0;
         NM_HIP(hipMalloc((void**)&f->blob, need * sizeof(float)));
         f->blob_floats = need;
     }
@@ -325,6 +342,7 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
         if (need_h > f->blob_h_halves) {
             if (f->blob_h) hipFree(f->blob_h);
             f->blob_h = nullptr;
+            f->blob_h_halves = 0;
             NM_HIP(hipMalloc((void**)&f->blob_h, need_h * sizeof(_Float16)));
             f->blob_h_halves = need_h;
         }
@@ -358,8 +376,7 @@ int nm_field_create(const nm_field_desc* desc, nm_stream_t stream, nm_field_t* o
     if (nm_field_validate(desc)) return 1;
     nm_field_s* f = new nm_field_s();
     if (nm_field_pack(f, desc, (hipStream_t)stream)) {
-        if (f->blob) hipFree(f->blob);
-        delete f;
+        nm_field_destroy(f);  // frees both weight blobs
         return 1;
     }
     *out = f;
@@ -420,7 +437,7 @@ static int nm_launch_geo(nm_field_t f, const float* fg, const float* ds, const f
                          float* sdf, int Pper, int stride, int off, float* nabla_out, hipStream_t stream,
                          NmRecMap rmap = NM_COMPACT, int nabla_slotted = 0, NmSlotMap smap = NM_NO_SLOTS, bool counted = false) {
     if (P <= 0) return 0;
-    NmProfScope prof(nabla ? NM_K_GEO_NABLA : NM_K_GEO, counted ? 0 : P, stream, counted);
+    NmProfScope prof(nabla ? NM_K_GEO_NABLA : NM_K_GEO, counted ? 0 : P, stream, counted ? NM_CNT_MID : NM_CNT_NONE);
     if (f->precision == 1) {
         if (nabla) hipLaunchKernelGGL((nm_geo_mlp_h_kernel<true>), dim3(nm_blocks(P, 32)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap);
         else hipLaunchKernelGGL((nm_geo_mlp_h_kernel<false>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap);
@@ -441,7 +458,7 @@ static int nm_launch_geo(nm_field_t f, const float* fg, const float* ds, const f
 static int nm_launch_col(nm_field_t f, const float* ft, const float* ds, const float* nabla, const float* dirs, int dir_div,
                          long long P, float* rgb, hipStream_t stream, NmSlotMap smap = NM_NO_SLOTS, bool counted = false) {
     if (P <= 0) return 0;
-    NmProfScope prof(NM_K_COLOR, counted ? 0 : P, stream, counted);
+    NmProfScope prof(NM_K_COLOR, counted ? 0 : P, stream, counted ? NM_CNT_MID : NM_CNT_NONE);
     if (f->precision == 1) {
         hipLaunchKernelGGL(nm_col_mlp_h_kernel, dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h, ft, ds, nabla, dirs, dir_div, P, rgb, smap);
         NM_LAUNCH_CHECK();
@@ -502,33 +519,30 @@ int nm_field_color(nm_field_t f, const float* color_features, const float* ds, c
 // 4-sample tiles a wave chains along its rays in the regular-grid passes (probes, coarse samples):
 // as long as possible (measured on the 800x800 frame: 1 -> 414 ms of K-NN, 8 -> 374, 32 -> 361), but
 // never so long that the launch has fewer than ~4 waves per SIMD of the whole chip.
-static int nm_chain_tiles(long long R, int P) {
-    const char* e = getenv("NEUMESH_CHAIN_TILES");  // upper limit (tests compare 1 against the default)
-    int vmax = e ? atoi(e) : 32;
-    if (vmax < 1) vmax = 1;
+static int nm_chain_tiles(const nm_render_cfg* c, long long R, int P) {
+    int vmax = c->chain_tiles > 0 ? c->chain_tiles : 32;  // upper limit (tests compare 1 against the default)
     if (vmax > 64) vmax = 64;
     const long long tiles_p = (P + 3) / 4, total = ((R + 15) / 16) * tiles_p;
-    long long c = total / 16384;
-    if (c > vmax) c = vmax;
-    if (c > tiles_p) c = tiles_p;
-    return c < 1 ? 1 : (int)c;
+    long long ch = total / 16384;
+    if (ch > vmax) ch = vmax;
+    if (ch > tiles_p) ch = tiles_p;
+    return ch < 1 ? 1 : (int)ch;
 }
 
-// Rays per depth-bucket group of the mid-point pass: 64 (8128 samples sorted in 64 KiB of LDS; with the
-// zero-weight samples dropped ~3500 of them remain, i.e. the sample density of a 28-ray group; measured
-// K-NN time per frame: 16 rays 240 ms, 32 rays 233 ms, 64 rays 210 ms), fewer when the per-ray sample
-// count is larger; 0 = no ordering (lists longer than the 8192-key sort).
-// Rays per depth-bucket group of an importance-sample pass (n_new samples per ray, <= 8192 keys per sort)
-static int nm_fine_group_rays(int n_new) {
-    const char* e = getenv("NEUMESH_FINE_GROUP");
-    int g = e ? atoi(e) : 128;   // (Morton-ordered rays: 64 -> 170 ms of K-NN per frame, 128..512 -> 166 ms)
+// Rays per depth-bucket group of an importance-sample pass (n_new samples per ray, <= 8192 keys per sort;
+// Morton-ordered rays: 64 -> 170 ms of K-NN per frame, 128..512 -> 166 ms)
+static int nm_fine_group_rays(const nm_render_cfg* c, int n_new) {
+    int g = c->fine_group_rays;
     if (g != 64 && g != 128 && g != 256 && g != 512) g = 128;
     while (g >= 64 && g * n_new > 8192) g >>= 1;
     return g >= 64 ? g : 0;
 }
-static int nm_mid_group_rays(int N) {
-    const char* e = getenv("NEUMESH_MID_GROUP");
-    int g = e ? atoi(e) : 64;
+// Rays per depth-bucket group of the mid-point pass: 64 (8128 samples sorted in 64 KiB of LDS; with the
+// zero-weight samples dropped ~3500 of them remain, i.e. the sample density of a 28-ray group; measured
+// K-NN time per frame: 16 rays 240 ms, 32 rays 233 ms, 64 rays 210 ms), fewer when the per-ray sample
+// count is larger; 0 = no ordering (lists longer than the 8192-key sort).
+static int nm_mid_group_rays(const nm_render_cfg* c, int N) {
+    int g = c->mid_group_rays;
     if (g != 16 && g != 32 && g != 64) g = 64;
     while (g >= 16 && g * (N - 1) > 8192) g >>= 1;
     return g >= 16 ? g : 0;
@@ -539,11 +553,16 @@ static int nm_ray_lds_prepare(int cap, size_t* bytes) {
     *bytes = nm_ray_lds_bytes(cap);
     if (cap > NM_MAX_SAMPLES) return nm_fail("per-ray stages: %d samples per ray (limit %d)", cap, NM_MAX_SAMPLES);
     if (*bytes > 160 * 1024) return nm_fail("per-ray stages: %d samples per ray need %zu bytes of LDS (limit 160 KiB)", cap, *bytes);
-    static size_t granted = 0;
-    if (*bytes > granted) {
+    // the dynamic-LDS limit is a per-device function attribute: remember what each device was granted
+    static std::mutex mu;
+    static size_t granted[64] = {0};
+    int dev = 0;
+    NM_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 64 || *bytes > granted[dev]) {
         NM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nm_rays_upsample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)*bytes));
         NM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nm_rays_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)*bytes));
-        granted = *bytes;
+        if (dev >= 0 && dev < 64) granted[dev] = *bytes;
     }
     return 0;
 }
@@ -638,9 +657,9 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     const dim3 rgrid(nm_blocks(R, 64)), rblock(64);
 
     // processing order: rays sorted by the Morton code of their closest approach to the scene centre (see
-    // nm_ray_keys_kernel); with debug outputs requested the caller's order is kept (they are per-ray arrays)
+    // nm_ray_keys_kernel); per-ray outputs (pixels, debug arrays) go back to the caller's order through perm
     const int* perm = nullptr;
-    if (!dbg && R >= 256 && !getenv("NEUMESH_NO_RAY_SORT")) {
+    if (R >= 256 && !(c->flags & NM_RENDER_NO_RAY_SORT)) {
         hipLaunchKernelGGL(nm_ray_keys_kernel, dim3(nm_blocks(R, 256)), dim3(256), 0, stream, rays_o, rays_d, (long long)R,
                            1.0f / fmaxf(c->obj_bounding_radius, 1e-6f), ws.key_in, ws.perm_in);
         NM_LAUNCH_CHECK();
@@ -662,14 +681,15 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     src.dstride = cap;
     const float* nf = ws.nf0;
     if (c->bounded_near_far) {  // renderer.py:66-102
-        if (!getenv("NEUMESH_FULL_PROBES")) {  // first / last hit only (nm_probe_bounds_kernel)
-            NmProfScope prof(NM_K_DISTANCE, (long long)R * c->probe_grid, stream);  // probe decisions resolved (not all are searched)
+        if (!(c->flags & NM_RENDER_FULL_PROBES)) {  // first / last hit only (nm_probe_bounds_kernel)
+            NmProfScope prof(NM_K_DISTANCE, 0, stream, NM_CNT_PROBE);  // units = probes actually searched (device counter)
             hipLaunchKernelGGL(nm_probe_bounds_kernel, dim3(nm_blocks((R + 15) / 16, 4)), dim3(256), 0, stream, g->view, rays_o, ws.dirn, ws.nf0,
-                               (long long)R, c->probe_grid, c->probe_thresh, g->verts, t->indicator_vector, t->indicator_weight, ws.nf);
+                               (long long)R, c->probe_grid, c->probe_thresh, g->verts, t->indicator_vector, t->indicator_weight, ws.nf,
+                               nm_prof_counter(NM_CNT_PROBE));
             NM_LAUNCH_CHECK();
         } else {  // every probe, then the reduction (the staged API's form; kept for A/B measurements)
             src.mode = 2;
-            src.chain = nm_chain_tiles(R, c->probe_grid);
+            src.chain = nm_chain_tiles(c, R, c->probe_grid);
             src.P = c->probe_grid;
             src.nearfar = ws.nf0;
             src.depth_out = nullptr;
@@ -699,7 +719,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     const bool want_grad = c->calc_normal != 0;
     const NmGather ga_slots = {t->geometry_features, f->geo.gdim, ws.slots.fg, nullptr, 0, nullptr};
     src.mode = 2;
-    src.chain = nm_chain_tiles(R, c->N_samples);
+    src.chain = nm_chain_tiles(c, R, c->N_samples);
     src.P = c->N_samples;
     src.nearfar = nf;
     src.depth_out = ws.d;
@@ -719,16 +739,16 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
         if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, want_grad ? ws.slots.grad : nullptr, (long long)R * c->N_samples, want_grad, ws.sdf, c->N_samples, cap, 0, nab_slot, stream, rm, 1)) return 1;
     }
     if (dbg && dbg->sdf_coarse) {
-        hipLaunchKernelGGL(nm_copy_strided_kernel, dim3(nm_blocks(R * c->N_samples, 256)), dim3(256), 0, stream, ws.sdf, (long long)R, c->N_samples, cap, dbg->sdf_coarse);
+        hipLaunchKernelGGL(nm_rows_out_kernel, dim3(nm_blocks(R * c->N_samples, 256)), dim3(256), 0, stream, ws.sdf, (long long)R, c->N_samples, cap, perm, dbg->sdf_coarse);
         NM_LAUNCH_CHECK();
     }
     // hierarchical up-sampling (renderer.py:208-258)
     int n = c->N_samples, pending = 0;
     size_t ray_lds = 0;
     if (nm_ray_lds_prepare(cap, &ray_lds)) return 1;
-    const int mid_g = nm_mid_group_rays(N);  // rays per depth-bucket group of the mid-point pass
-    const bool use_order = mid_g > 0 && !getenv("NEUMESH_NO_MID_ORDER");
-    const bool skip_zero = use_order && !(dbg && dbg->radiance) && !getenv("NEUMESH_NO_ZERO_SKIP");  // all radiances requested => evaluate all
+    const int mid_g = nm_mid_group_rays(c, N);  // rays per depth-bucket group of the mid-point pass
+    const bool use_order = mid_g > 0 && !(c->flags & NM_RENDER_NO_MID_ORDER);
+    const bool skip_zero = use_order && !(dbg && dbg->radiance) && !(c->flags & NM_RENDER_NO_ZERO_SKIP);  // all radiances requested => evaluate all
     if (c->N_importance > 0) {
         const int n_new = c->N_importance / c->N_upsample_iters;
         for (int it = 0; it < c->N_upsample_iters; ++it) {
@@ -743,7 +763,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
             src.out_stride = cap;
             src.out_off = n;
             src.order = nullptr;
-            const int fine_g = nm_fine_group_rays(n_new);
+            const int fine_g = nm_fine_group_rays(c, n_new);
             if (fine_g > 0) {
                 int np2 = 64;
                 while (np2 < fine_g * n_new) np2 <<= 1;
@@ -783,7 +803,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
         int np2 = 64;
         while (np2 < mid_g * (N - 1)) np2 <<= 1;
         hipLaunchKernelGGL(nm_rays_order_kernel, dim3((unsigned)((R + mid_g - 1) / mid_g)), dim3(256), (size_t)np2 * 8, stream, ws.dmid, (long long)R, cap, 0, N - 1, mid_g, np2, ws.order,
-                           skip_zero ? (const float*)ws.bound : (const float*)nullptr, (skip_zero && g_prof_on) ? g_prof_counter : (unsigned long long*)nullptr);
+                           skip_zero ? (const float*)ws.bound : (const float*)nullptr, skip_zero ? nm_prof_counter(NM_CNT_MID) : (unsigned long long*)nullptr);
         NM_LAUNCH_CHECK();
         src.order = ws.order;
         src.order_rays = mid_g;
@@ -813,12 +833,16 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
                        c->calc_normal ? ws.nab_pts : (const float*)nullptr, c->white_bkgd, rgb, depth, acc, c->calc_normal ? normals : (float*)nullptr,
                        skip_zero ? (const float*)ws.bound : (const float*)nullptr, perm);
     NM_LAUNCH_CHECK();
-    if (dbg) {
-        if (dbg->near_far) NM_HIP(hipMemcpyAsync(dbg->near_far, nf, (size_t)R * 8, hipMemcpyDeviceToDevice, stream));
-        if (dbg->d_all) NM_HIP(hipMemcpyAsync(dbg->d_all, ws.d, (size_t)R * N * 4, hipMemcpyDeviceToDevice, stream));
-        if (dbg->sdf_all) NM_HIP(hipMemcpyAsync(dbg->sdf_all, ws.sdf, (size_t)R * N * 4, hipMemcpyDeviceToDevice, stream));
-        if (dbg->nablas_all && c->calc_normal) NM_HIP(hipMemcpyAsync(dbg->nablas_all, ws.nab_pts, (size_t)R * N * 12, hipMemcpyDeviceToDevice, stream));
-        if (dbg->radiance) NM_HIP(hipMemcpyAsync(dbg->radiance, ws.rgb_mid, (size_t)R * (N - 1) * 12, hipMemcpyDeviceToDevice, stream));
+    if (dbg) {  // per-ray debug rows, back in the caller's ray order
+        auto rows_out = [&](const float* src, int n, int src_stride, float* dst) {
+            hipLaunchKernelGGL(nm_rows_out_kernel, dim3(nm_blocks(R * n, 256)), dim3(256), 0, stream, src, (long long)R, n, src_stride, perm, dst);
+        };
+        if (dbg->near_far) rows_out(nf, 2, 2, dbg->near_far);
+        if (dbg->d_all) rows_out(ws.d, N, cap, dbg->d_all);
+        if (dbg->sdf_all) rows_out(ws.sdf, N, cap, dbg->sdf_all);
+        if (dbg->nablas_all && c->calc_normal) rows_out(ws.nab_pts, 3 * N, 3 * N, dbg->nablas_all);
+        if (dbg->radiance) rows_out(ws.rgb_mid, 3 * (N - 1), 3 * (N - 1), dbg->radiance);
+        NM_LAUNCH_CHECK();
     }
     return 0;
 }
@@ -909,22 +933,26 @@ int nm_make_rays(const nm_camera* cam, int64_t first_pixel, int64_t count, float
 
 // ======================================================================== instrumentation
 int nm_profile_enable(int on) {
-    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-    g_prof.clear();
-    if (on) {
-        if (!g_prof_counter) NM_HIP(hipMalloc((void**)&g_prof_counter, sizeof(unsigned long long)));
-        NM_HIP(hipMemset(g_prof_counter, 0, sizeof(unsigned long long)));
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.on.store(false);
+    for (auto& r : g_prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.recs.clear();
+    if (g_prof.counters) { (void)hipFree(g_prof.counters); g_prof.counters = nullptr; }
+    if (on) {  // counters live on the CURRENT device: profile one device at a time
+        NM_HIP(hipMalloc((void**)&g_prof.counters, NM_CNT_N * sizeof(unsigned long long)));
+        NM_HIP(hipMemset(g_prof.counters, 0, NM_CNT_N * sizeof(unsigned long long)));
+        g_prof.on.store(true);
     }
-    g_prof_on = on != 0;
     return 0;
 }
 
 int nm_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* units) {
     if (kind < 0 || kind >= NM_K_KINDS || !total_ms || !launches || !units) return nm_fail("nm_profile_read: bad arguments");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     double ms = 0.0;
     int64_t n = 0, u = 0;
-    bool counted = false;
-    for (auto& r : g_prof) {
+    bool used[NM_CNT_N] = {false, false};
+    for (auto& r : g_prof.recs) {
         if (r.kind != kind) continue;
         if (hipEventSynchronize(r.b) != hipSuccess) return nm_fail("nm_profile_read: event sync failed");
         float e = 0.f;
@@ -932,12 +960,13 @@ int nm_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* unit
         ms += e;
         n += 1;
         u += r.units;
-        counted = counted || r.counted;
+        if (r.counter >= 0 && r.counter < NM_CNT_N) used[r.counter] = true;
     }
-    if (counted && g_prof_counter) {  // every counted kind processes the same points once per frame
-        unsigned long long c = 0;
-        NM_HIP(hipMemcpy(&c, g_prof_counter, sizeof(c), hipMemcpyDeviceToHost));
-        u += (int64_t)c;
+    if (g_prof.counters && (used[0] || used[1])) {  // every kind that used a counter processed those points once
+        unsigned long long c[NM_CNT_N] = {0, 0};
+        NM_HIP(hipMemcpy(c, g_prof.counters, sizeof(c), hipMemcpyDeviceToHost));
+        for (int i = 0; i < NM_CNT_N; ++i)
+            if (used[i]) u += (int64_t)c[i];
     }
     *total_ms = ms;
     *launches = n;
@@ -947,9 +976,14 @@ int nm_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* unit
 
 // debug: install (or clear, with NULL) the device buffer the MLP kernels write phase timestamps to
 int nm_debug_phase_log(void* device_buf_32x16_i64) {
+#ifdef NM_PHASE_STAMPS
     long long* p = (long long*)device_buf_32x16_i64;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_nm_phase_log), &p, sizeof(p)) != hipSuccess) return nm_fail("nm_debug_phase_log: hipMemcpyToSymbol failed");
     return 0;
+#else
+    (void)device_buf_32x16_i64;
+    return nm_fail("nm_debug_phase_log: this build has no phase stamps (build with -DNM_PHASE_STAMPS, see tools/mlp_phases.py)");
+#endif
 }
 
 int nm_time_kernel(nm_field_t f, nm_grid_t g, const nm_field_tables* t, int which, const float* xyz, const float* view_dirs,

@@ -447,7 +447,8 @@ __global__ __launch_bounds__(256, 6) void nm_probe_bounds_kernel(NmGridView g, c
                                                                  const float* __restrict__ dirn, const float* __restrict__ nearfar0,
                                                                  long long R, int P, float thresh, const float* __restrict__ verts,
                                                                  const float* __restrict__ indicator, float w1,
-                                                                 float* __restrict__ nearfar) {
+                                                                 float* __restrict__ nearfar,
+                                                                 unsigned long long* __restrict__ searched) {
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63, sub = lane & 3, quad = lane & ~3;
     const long long r = wave * 16 + (lane >> 2);
@@ -460,6 +461,7 @@ __global__ __launch_bounds__(256, 6) void nm_probe_bounds_kernel(NmGridView g, c
     }
     const int T = (P + 3) >> 2;
     int first_idx = -1, last_idx = -1;
+    unsigned n_searched = 0;  // probes this wave searched (profiling: one atomic per wave at the end)
     // one step: probe p of this lane's ray; returns ds (and the K-th-neighbour radius for the next warm start)
     int nbr[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};  // of this lane's last probe
     // src_lane: the lane of this ray whose last probe is the closest one already evaluated (-1: none)
@@ -467,6 +469,7 @@ __global__ __launch_bounds__(256, 6) void nm_probe_bounds_kernel(NmGridView g, c
         dep = nm_lerp_depth(n0, f0, nm_linspace01(p < P ? p : P - 1, P));
         const float x = nm_add(ox, nm_mul(dep, dx)), y = nm_add(oy, nm_mul(dep, dy)), z = nm_add(oz, nm_mul(dep, dz));
         if (src_lane >= 0) init = fminf(init, nm_bound_from_neighbours(verts, nbr, src_lane, act, x, y, z));
+        if (searched) n_searched += (unsigned)__popcll(__ballot(act));
         unsigned long long kk[8];
         nm_knn_wave<8>(g, x, y, z, act, kk, init);
         float bd[8], wk[8];
@@ -533,6 +536,7 @@ __global__ __launch_bounds__(256, 6) void nm_probe_bounds_kernel(NmGridView g, c
         const float mx = first_idx >= 0 ? nm_lerp_depth(n0, f0, nm_linspace01(last_idx, P)) : -1e10f;
         nm_ray_bounds_finish(mn, mx, n0, f0, nearfar + 2 * r, nearfar + 2 * r + 1);
     }
+    if (searched && lane == 0 && n_searched) atomicAdd(searched, (unsigned long long)n_searched);
 }
 
 // ------------------------------------------------------------------------- per-ray kernels
@@ -910,10 +914,14 @@ __global__ void nm_permute_rows3_kernel(const float* __restrict__ src, const int
     dst[e * 3 + 2] = src[s * 3 + 2];
 }
 
-__global__ void nm_copy_strided_kernel(const float* __restrict__ src, long long R, int n, int src_stride,
-                                       float* __restrict__ dst) {
+// dst[(perm ? perm[r] : r)][0..n) = src[r * src_stride + 0..n): per-ray rows of the workspace (processing order
+// of the rays) out to a caller's [R][n] array (caller's ray order)
+__global__ void nm_rows_out_kernel(const float* __restrict__ src, long long R, int n, int src_stride,
+                                   const int* __restrict__ perm, float* __restrict__ dst) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= R * n) return;
     const long long r = e / n;
-    dst[e] = src[r * src_stride + (e - r * n)];
+    const int j = (int)(e - r * n);
+    const long long ro = perm ? (long long)perm[r] : r;
+    dst[ro * n + j] = src[r * src_stride + j];
 }

@@ -32,15 +32,20 @@
 
 typedef float nm_f32x16 __attribute__((ext_vector_type(16)));
 
-// Debug hook (off unless nm_debug_phase_log() installed a buffer): workgroups 4096..4127 of an MLP
-// launch record the shader clock at their phase boundaries (slot 0 start, 1 after the prologue,
-// then after each layer's MFMA loop and after its epilogue, last = end), 16 stamps per workgroup.
+// Debug hook, compiled in only with -DNM_PHASE_STAMPS (tools/mlp_phases.py builds such a library):
+// workgroups 4096..4127 of an MLP launch record the shader clock at their phase boundaries (slot 0
+// start, 1 after the prologue, then after each layer's MFMA loop and after its epilogue, last = end),
+// 16 stamps per workgroup.  The production build has no trace of it.
+#ifdef NM_PHASE_STAMPS
 __device__ long long* g_nm_phase_log = nullptr;
 __device__ __forceinline__ void nm_phase_stamp(int slot) {
     long long* log = g_nm_phase_log;
     if (log && blockIdx.x >= 4096u && blockIdx.x < 4128u && threadIdx.x == 0 && slot < 16)
         log[(blockIdx.x - 4096u) * 16 + slot] = (long long)clock64();
 }
+#else
+__device__ __forceinline__ void nm_phase_stamp(int) {}
+#endif
 
 struct NmLayer {
     const float* W;  // packed [256][Kpad], zero padded

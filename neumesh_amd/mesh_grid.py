@@ -119,6 +119,11 @@ class MeshGrid(MeshPrimitive):
             if want_grad:
                 raise ValueError("want_grad is only meaningful without autograd")
             return self._compute_distance_autograd(xyz, K, indicator, indicator_weight)
+        if K != 8:  # the fused kernel is built for the reference's K = 8 (mesh_grid.py:77); any other K <= 32: nm_knn + torch ops
+            if want_grad:
+                raise ValueError("want_grad needs K = 8 (fused kernel)")
+            with torch.no_grad():
+                return self._compute_distance_autograd(xyz, K, indicator, indicator_weight)
         lib = _lib.load()
         q = xyz.detach().to(torch.float32).reshape(-1, 3).contiguous()
         Q = q.shape[0]

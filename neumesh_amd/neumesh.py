@@ -107,7 +107,9 @@ class NeuMesh(nn.Module):
         # (fp32-input MFMA).
         self.mlp_precision = os.environ.get("NEUMESH_MLP_PRECISION", "f16x2")
         self._field = None        # nm_field_t
-        self._field_key = None    # parameter versions the packed weights were built from
+        self._field_key = None    # parameter versions / device / precision the packed weights were built from
+        self._field_dev = None
+        self._field_epoch = 0     # bumped by invalidate_field()
         self._keep = None         # tensors whose pointers the last FieldDesc referenced
 
     # ------------------------------------------------------------------ scalars
@@ -140,13 +142,17 @@ class NeuMesh(nn.Module):
         ps = self._mlp_params()
         if self.mlp_precision not in ("fp32", "f16x2"):
             raise ValueError(f"mlp_precision={self.mlp_precision!r}: expected 'fp32' or 'f16x2'")
-        key = tuple((p.data_ptr(), p._version) for p in ps) + (self.mlp_precision,)
+        dev = ps[0].device
+        key = tuple((p.data_ptr(), p._version) for p in ps) + (self.mlp_precision, str(dev), self._field_epoch)
         if self._field is not None and key == self._field_key:
             return self._field
         lib = _lib.load()
-        dev = ps[0].device
         if dev.type != "cuda":
             raise _lib.NeuMeshHipError("NeuMesh parameters must live on a HIP device (model.to('cuda')); no CPU fallback")
+        if self._field is not None and self._field_dev != dev:
+            # the packed weights live on the device they were created on: a moved model gets a new handle
+            lib.nm_field_destroy(self._field)
+            self._field = None
         with torch.no_grad():
             def folded(m):  # W = g * v / ||v||_row  (torch.nn.utils.weight_norm, dim=0)
                 return (m.weight_v * (m.weight_g / m.weight_v.norm(dim=1, keepdim=True))).float().contiguous()
@@ -180,7 +186,14 @@ class NeuMesh(nn.Module):
                 _lib.check(lib.nm_field_update(self._field, C.byref(d), stream), "nm_field_update")
         self._keep = (gw, gb, dw, db, cw, cb, rw, rb)  # the pack call synchronised; kept for clarity
         self._field_key = key
+        self._field_dev = dev
         return self._field
+
+    def invalidate_field(self):
+        """Force a re-pack of the MLP weights at the next use.  Needed only after edits that bypass
+        autograd's version counters (``p.data.copy_()`` / ``p.data.mul_()``); ordinary in-place ops,
+        optimizer steps and load_state_dict are detected automatically."""
+        self._field_epoch += 1
 
     def field_tables(self, color_features=None):
         """nm_field_tables for the current codes / scalars (borrowed pointers; returns the struct

@@ -39,8 +39,19 @@ def alpha_to_w(alpha):
     return alpha * torch.cumprod(torch.cat([ones, 1.0 - alpha + 1e-10], dim=-1), dim=-1)[..., :-1]
 
 
+# Evaluation-strategy switches of nm_render_rays (nm_render_cfg.flags / tuning fields).  The library
+# itself reads no environment; this host layer maps the NEUMESH_* variables onto the struct so that a
+# measurement script can flip them without touching the caller (none of them changes a result bit).
+_ENV_FLAGS = (("NEUMESH_FULL_PROBES", _lib.RENDER_FULL_PROBES), ("NEUMESH_NO_ZERO_SKIP", _lib.RENDER_NO_ZERO_SKIP),
+              ("NEUMESH_NO_RAY_SORT", _lib.RENDER_NO_RAY_SORT), ("NEUMESH_NO_MID_ORDER", _lib.RENDER_NO_MID_ORDER))
+_ENV_TUNING = (("NEUMESH_CHAIN_TILES", "chain_tiles"), ("NEUMESH_FINE_GROUP", "fine_group_rays"), ("NEUMESH_MID_GROUP", "mid_group_rays"))
+
+
 def make_render_cfg(obj_bounding_radius=1.0, N_samples=64, N_importance=64, N_upsample_iters=4, bounded_near_far=True,
-                    calc_normal=False, white_bkgd=False, near_bypass=None, far_bypass=None) -> _lib.RenderCfg:
+                    calc_normal=False, white_bkgd=False, near_bypass=None, far_bypass=None, flags=None,
+                    **tuning) -> _lib.RenderCfg:
+    """nm_render_cfg for volume_render's arguments.  flags: NM_RENDER_* bits (None = take them from the
+    NEUMESH_* environment variables); tuning: chain_tiles / fine_group_rays / mid_group_rays (0 = default)."""
     c = _lib.RenderCfg()
     c.obj_bounding_radius = float(obj_bounding_radius)
     c.N_samples, c.N_importance, c.N_upsample_iters = int(N_samples), int(N_importance), int(N_upsample_iters)
@@ -48,6 +59,20 @@ def make_render_cfg(obj_bounding_radius=1.0, N_samples=64, N_importance=64, N_up
     c.probe_grid, c.probe_thresh = 256, 0.1  # compute_bounded_near_far defaults (renderer.py:72-73)
     c.near_bypass = -1.0 if near_bypass is None else float(near_bypass)
     c.far_bypass = -1.0 if far_bypass is None else float(far_bypass)
+    if flags is None:
+        flags = 0
+        for env, bit in _ENV_FLAGS:
+            if os.environ.get(env):
+                flags |= bit
+    c.flags = int(flags)
+    for env, field in _ENV_TUNING:
+        v = tuning.get(field)
+        if v is None:
+            try:
+                v = int(os.environ.get(env, "0"))
+            except ValueError:
+                v = 0
+        setattr(c, field, max(0, int(v)))
     return c
 
 
@@ -76,13 +101,27 @@ class _Workspace:
 # tails are filled by the other's kernels (800x800 frame on one MI355X: 65536-ray chunks 1029 ->
 # 909 ms, 327680-ray chunks 951 -> 895 ms; the whole frame as ONE chunk, 925 ms, is single-stream).
 # NEUMESH_RENDER_STREAMS=1 restores the single-stream order.
-_LANES = [_Workspace(), _Workspace()]
-_WS = _LANES[0]
+# Workspaces and side streams belong to one (device, caller stream) pair: calls issued on the same
+# stream are ordered by it (fork/join below), calls on different streams or devices never share scratch.
+_POOLS = {}
+
+
+def _lanes_for(device, stream_handle: int):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), int(stream_handle or 0))
+    pool = _POOLS.get(key)
+    if pool is None:
+        pool = _POOLS[key] = [_Workspace(), _Workspace()]
+    return pool
+
+
+def release_workspaces():
+    """Drop every cached render workspace (they are sized for the largest chunk seen: 56 KB per ray)."""
+    _POOLS.clear()
 
 
 def _n_lanes() -> int:
     try:
-        return max(1, min(len(_LANES), int(os.environ.get("NEUMESH_RENDER_STREAMS", "2"))))
+        return max(1, min(2, int(os.environ.get("NEUMESH_RENDER_STREAMS", "2"))))
     except ValueError:
         return 2
 
@@ -113,12 +152,12 @@ def render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg: _lib.RenderCfg, raysc
     if ws_bytes < 0:
         _lib.check(1, "nm_render_workspace_bytes")
     starts = list(range(0, R, chunk))
-    lanes = _LANES[:min(_n_lanes(), len(starts))]
-    wss = [lane.get(ws_bytes, dev) for lane in lanes]
     field, grid = model.field_handle(), model.mesh_grid.grid.handle
     t, keep = tables if tables is not None else model.field_tables()
     with torch.cuda.device(dev):
         main = torch.cuda.current_stream(dev)
+        lanes = _lanes_for(dev, main.cuda_stream)[:min(_n_lanes(), len(starts))]
+        wss = [lane.get(ws_bytes, dev) for lane in lanes]
         if len(lanes) > 1:  # fork: the side streams start after everything already queued on the caller's stream
             side = [lane.side_stream(dev) for lane in lanes]
             for st in side:
