@@ -1,21 +1,31 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the NeuMesh volumetric-render hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a torch.distributed environment re-executes itself under `torch.distributed.run`
+(one rank per GPU, 127.0.0.1 rendezvous); launched by the driver under torch.distributed.run it
+uses the environment it is given.
 
 Workload (BASELINE.json configs[1], shape only -- there is no DTU data / checkpoint in the
 environment, SURVEY.md section 8d scene S-DTU): V = 140 000-vertex prior mesh, 32-d geometry /
-colour codes, W=256 MLPs at default init, s = 200; one STEP = one 800x800 frame = 640 000 rays x
-(64 coarse + 64 importance) samples with bounded near/far (256 probes/ray) and normals, i.e. the
-kwargs get_model() hands render.py for configs/neumesh_dtu_scan63.yaml.  Rays are resident in HBM
-before the timed region.  With N GPUs every rank renders its own frame of the orbit per step
-(weak scaling: per-GPU work is fixed) and the final pixels are all-gathered over RCCL -- the only
-collective of the path.
+colour codes, W=256 MLPs (the default-init weight set of tests/golden/model_seed0.npz, i.e. the scene
+whose reference render is pinned by tests/golden/render_v140k_dtu.npz), s = 200; one STEP = one
+800x800 frame = 640 000 rays x (64 coarse + 64 importance) samples with bounded near/far (256
+probes/ray) and normals, i.e. the kwargs get_model() hands render.py for
+configs/neumesh_dtu_scan63.yaml.  Rays are resident in HBM before the timed region.  With N GPUs
+every rank renders its own frame of the orbit per step (weak scaling: per-GPU work is fixed) and the
+final pixels are all-gathered over RCCL -- the only collective of the path.
 
-Prints ONE JSON line (rank 0): value = rays/s of the whole job; `roofline` = the dominant kernel
-(measured live with HIP events on the launch stream inside the timed region) against the fp32
-MFMA peak; `cpu_baseline` = the CPU oracle (numpy + kd-tree K-NN) on a bounded ray sample of the
-same frame (rank 0, N=1 only).
+Prints ONE JSON line (rank 0):
+  value        rays/s of the whole job
+  roofline     the dominant kernel, measured live with HIP events on the launch stream inside the
+               timed region: achieved = ALGORITHMIC fp32 FLOP / time against the peak of the matrix
+               pipe it runs on (frac); the issued-MFMA utilisation is a separate key
+  cpu_baseline the CPU oracle (numpy + kd-tree K-NN) on a bounded ray sample of the same frame
+  parity_vs_reference   the same frame's 1536 fixture rays against the imported reference's output
+  extra        short runs (2 steps each, N = 1 only) of the variants the headline does not show:
+               data-independent frame, fp32 MLP, calc_normal=False, BASELINE config 3 shape, config 5
 """
 from __future__ import annotations
 
@@ -23,6 +33,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
 import sys
 import time
 
@@ -38,9 +49,11 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 PEAK_HBM_GBS = 8000.0
 KNN_BYTES_PER_QUERY = 76    # 12 in + 8*4 idx + 8*4 w  
+PROFILE_TAG = "r02"         # profiles/<tag>_pmc_*.json: rocprofv3 --pmc passes of this command (tools/pmc_*.py)
 
 MODEL_CFG = dict(D_density=3, D_color=4, W=256, geometry_dim=32, color_dim=32, multires_view=4, multires_d=8,
                  multires_fg=2, multires_ft=2, enable_nablas_input=True, speed_factor=10.0, learn_indicator_weight=False)
+KINDS = {0: ("knn_distance", None), 1: ("geo_mlp", FLOP_GEO), 2: ("geo_mlp_tangent", FLOP_GEO + FLOP_TANGENT), 3: ("color_mlp", FLOP_COL)}
 
 
 class _Mesh:
@@ -52,11 +65,20 @@ class _Mesh:
 
 
 def build_scene(V, device, seed=0, s_value=200.0):
+    """Scene S-DTU.  MLP weights: the set shared by every golden fixture
+    (tests/golden/model_seed0.npz = the reference constructor under torch.manual_seed(0)), so that the
+    benchmark scene is exactly the scene of tests/golden/render_v140k_dtu.npz; torch default init under
+    `seed` if that file is missing."""
     import torch
     from neumesh_amd import MeshGrid, NeuMesh, synthetic
     mesh = synthetic.fibonacci_blob(V)
     torch.manual_seed(seed)
     model = NeuMesh(MeshGrid(_Mesh(mesh), device), **MODEL_CFG)
+    wpath = os.path.join(ROOT, "tests", "golden", "model_seed0.npz")
+    if os.path.exists(wpath):
+        sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in np.load(wpath).items()}
+        res = model.load_state_dict(sd, strict=False)
+        assert not res.unexpected_keys, res.unexpected_keys
     with torch.no_grad():
         model.geometry_features.copy_(torch.from_numpy(synthetic.random_codes(V, 32, 1)))
         model.color_features.copy_(torch.from_numpy(synthetic.random_codes(V, 32, 2)))
@@ -70,15 +92,16 @@ def frame_rays(frame, H, W):
     return synthetic.camera_rays(synthetic.orbit_pose(frame), synthetic.pinhole_intrinsics(H, W), H, W)
 
 
-def cpu_baseline(mesh, model, H, W, n_rays, gpu_rgb_frame0, rays0=None, samples=128, white_bkgd=False, calc_normal=True):
-    """Oracle (CPU restatement of the reference) on a strided sample of frame 0's rays."""
-    from oracle import compare, field as ofield, knn as oknn, render as orender
+def cpu_baseline(mesh, model, H, W, n_rays, rays0, samples=128, white_bkgd=False, calc_normal=True):
+    """Oracle (CPU restatement of the reference, kind "port") on a strided sample of frame 0's rays.
+    Returns (baseline dict, oracle rgb of the sample, ray indices)."""
+    from oracle import field as ofield, knn as oknn, render as orender
     state = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     orc = ofield.OracleField(mesh.vertices, state, ofield.FieldConfig(speed_factor=MODEL_CFG["speed_factor"]))
     from scipy.spatial import cKDTree
     tree = cKDTree(mesh.vertices.astype(np.float64))
     orc.knn_fn = lambda q, v, K: oknn.knn_kdtree(q, v, K, tree=tree)
-    o, d = frame_rays(0, H, W) if rays0 is None else rays0   # the very rays the GPU rendered
+    o, d = rays0
     sel = np.linspace(0, H * W - 1, n_rays).astype(np.int64)
     cfg = orender.RenderConfig(calc_normal=calc_normal, white_bkgd=white_bkgd, N_samples=samples // 2, N_importance=samples // 2)
     orender.render_rays(orc, o[sel[:8]], d[sel[:8]], cfg)  # warm caches / thread pools
@@ -87,25 +110,59 @@ def cpu_baseline(mesh, model, H, W, n_rays, gpu_rgb_frame0, rays0=None, samples=
     dt = time.perf_counter() - t
     res = {"value": n_rays / dt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
            "sample": f"{n_rays} rays strided over frame 0 of the same {H}x{W}x{samples} workload, {dt:.1f} s; numpy fp32 oracle + "
-                     f"scipy cKDTree candidates re-ranked with the declared fp32 arithmetic (BLAS/OpenMP threads = all cores)"}
-    parity = None
-    if gpu_rgb_frame0 is not None:
+                     f"scipy cKDTree candidates re-ranked with the declared fp32 arithmetic (BLAS/OpenMP threads = all cores); "
+                     f"the imported reference itself did 108 rays/s on 8 cores in the build container (oracle/gen_golden.py scale)"}
+    return res, out["rgb"], sel
+
+
+def _psnr(a, b):
+    mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
+    return 200.0 if mse == 0 else -10.0 * np.log10(mse)
+
+
+def parity_blocks(gpu_rgb_frame0, H, W, V, oracle_rgb, sel):
+    """(a) vs the committed REFERENCE output of the very same rays (fixture, 1536 rays of frame 0);
+    (b) vs the oracle sample rendered for the CPU baseline."""
+    out = {}
+    fpath = os.path.join(ROOT, "tests", "golden", "render_v140k_dtu.npz")
+    if gpu_rgb_frame0 is not None and os.path.exists(fpath):
+        f = np.load(fpath)
+        if int(f["V"]) == V and int(f["H"]) == H and int(f["W"]) == W:
+            g = gpu_rgb_frame0[f["sel"]]
+            err = np.abs(g - f["rgb"]).max(-1)
+            se = f["self_err_1ulp"]
+            out["parity_vs_reference"] = {
+                "source": "tests/golden/render_v140k_dtu.npz: the imported reference (CPU torch + declared-arithmetic K-NN) on these rays",
+                "rays": int(len(err)), "psnr_db": _psnr(g, f["rgb"]), "max_abs_rgb": float(err.max()),
+                "median_abs_rgb": float(np.median(err)), "frac_rays_within_1e-4": float((err <= 1e-4).mean()),
+                "reference_self_sensitivity_1ulp": {"max_abs_rgb": float(se.max()), "frac_rays_within_1e-4": float((se <= 1e-4).mean())}}
+    if gpu_rgb_frame0 is not None and oracle_rgb is not None:
         g = gpu_rgb_frame0[sel]
-        err = np.abs(g - out["rgb"]).max(-1)
-        # yardstick: how much the reference algorithm itself moves when its input rays are nudged by
-        # one ulp (the up-sampling cascade + the discontinuous K-NN field amplify rounding for a few
-        # rays; see oracle/compare.py and DESIGN.md "Parity")
-        nudged = orender.render_rays(orc, o[sel], np.nextafter(d[sel], np.float32(10), dtype=np.float32), cfg)
-        self_err = np.abs(nudged["rgb"] - out["rgb"]).max(-1)
-        parity = {"rays": int(n_rays), "psnr_db": compare.psnr(g, out["rgb"]), "max_abs_rgb": float(err.max()),
-                  "median_abs_rgb": float(np.median(err)), "frac_rays_within_1e-4": float((err <= 1e-4).mean()),
-                  "oracle_self_sensitivity_1ulp": {"max_abs_rgb": float(self_err.max()), "median_abs_rgb": float(np.median(self_err)),
-                                                   "frac_rays_within_1e-4": float((self_err <= 1e-4).mean()),
-                                                   "psnr_db": compare.psnr(nudged["rgb"], out["rgb"])}}
-    return res, parity
+        err = np.abs(g - oracle_rgb).max(-1)
+        out["parity_vs_oracle"] = {"rays": int(len(err)), "psnr_db": _psnr(g, oracle_rgb), "max_abs_rgb": float(err.max()),
+                                   "median_abs_rgb": float(np.median(err)), "frac_rays_within_1e-4": float((err <= 1e-4).mean())}
+    return out
 
 
-def stress5(args):
+def _load_profile(name):
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{name}.json")
+    try:
+        return json.load(open(path)), os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
+
+
+def read_prof(lib):
+    from neumesh_amd import _lib
+    prof = {}
+    for k, (name, flop) in KINDS.items():
+        ms, n, u = C.c_double(), C.c_int64(), C.c_int64()
+        _lib.check(lib.nm_profile_read(k, C.byref(ms), C.byref(n), C.byref(u)), "nm_profile_read")
+        prof[name] = {"ms": ms.value, "launches": n.value, "points": u.value, "flop_per_point": flop}
+    return prof
+
+
+def stress5_run(args, dev, world, rank, steps, warmup):
     """BASELINE config 5, the HBM-bound case of the path: V = 1 000 000 vertices, one 256-d
     vertex feature table, kernels = K-NN + gather-interpolate only (nm_distance_interpolate), queries =
     the 4096x4096 rays of a frame, one point per ray where it meets the surface shell.  One step = one
@@ -115,14 +172,6 @@ def stress5(args):
     from neumesh_amd import _lib, synthetic
     from neumesh_amd.mesh_grid import MeshGrid
     from neumesh_amd.rays import make_rays
-    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
     lib = _lib.load()
     V, dim, H, W, slab = 1_000_000, 256, 4096, 4096, 256
     mesh = synthetic.fibonacci_blob(V)
@@ -132,7 +181,7 @@ def stress5(args):
     table = torch.randn((V, dim), generator=gen, device=dev)
     ind = grid.vertex_normals.contiguous()
     K = synthetic.pinhole_intrinsics(H, W)
-    total = args.warmup + args.steps
+    total = warmup + steps
     feat = torch.empty((slab * W, dim), device=dev)
     ds = torch.empty((slab * W,), device=dev)
 
@@ -158,12 +207,12 @@ def stress5(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     fence()
     lib.nm_profile_enable(1)
     t0 = time.perf_counter()
-    for i in range(args.warmup, total):
+    for i in range(warmup, total):
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
@@ -174,31 +223,39 @@ def stress5(args):
     ms, n, u = C.c_double(), C.c_int64(), C.c_int64()
     _lib.check(lib.nm_profile_read(0, C.byref(ms), C.byref(n), C.byref(u)), "nm_profile_read")
     lib.nm_profile_enable(0)
-    if rank == 0:
-        bytes_q = 12 + 8 * dim * 4          # query + 8 gathered rows (the 4*dim-byte output row is extra)
-        per_launch_q = u.value / max(n.value, 1)
-        avg_ms = ms.value / max(n.value, 1)
-        achieved = per_launch_q * bytes_q / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic_stress5.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("knn_distance", {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        print(json.dumps({
-            "metric": "K-NN + gather-interpolate queries/sec, 1M-vertex mesh x 256-d features, 4096x4096 rays (BASELINE config 5)",
-            "value": world * H * W * args.steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"stress5: V={V}, {dim}-d table ({V * dim * 4 / 2**30:.2f} GiB), {H}x{W} queries per step per GPU in slabs of {slab} rows",
-                       "parallelism": f"queries sharded: {world} GPU(s) x 1 frame per step, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "nm_distance_kernel<false> (K-NN + weights + 8-row gather-interpolate)",
-                         "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                         "bytes_per_query": bytes_q, "written_bytes_per_query_not_counted": dim * 4 + 4,
-                         "avg_launch_ms": avg_ms, "launches": n.value, "traffic": traffic}}), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    bytes_q = 12 + 8 * dim * 4          # query + 8 gathered rows (the 4*dim-byte output row is extra)
+    per_launch_q = u.value / max(n.value, 1)
+    avg_ms = ms.value / max(n.value, 1)
+    achieved = per_launch_q * bytes_q / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    traffic, tsrc = _load_profile("pmc_traffic_stress5")
+    hbm_per_launch = (traffic or {}).get("knn_distance", {}).get("hbm_bytes_per_launch")
+    return {
+        "metric": "K-NN + gather-interpolate queries/sec, 1M-vertex mesh x 256-d features, 4096x4096 rays (BASELINE config 5)",
+        "value": world * H * W * steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"stress5: V={V}, {dim}-d table ({V * dim * 4 / 2**30:.2f} GiB), {H}x{W} queries per step per GPU in slabs of {slab} rows",
+                   "parallelism": f"queries sharded: {world} GPU(s) x 1 frame per step, no collective"},
+        "roofline": {"bound": "hbm", "kernel": "nm_distance_kernel<false> (K-NN + weights + 8-row gather-interpolate)",
+                     "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                     "bytes_per_query": bytes_q, "written_bytes_per_query_not_counted": dim * 4 + 4,
+                     "avg_launch_ms": avg_ms, "launches": n.value,
+                     "traffic": hbm_per_launch, "traffic_source": tsrc,
+                     "measured_hbm_GBs": (hbm_per_launch / (avg_ms * 1e-3) / 1e9) if (hbm_per_launch and avg_ms > 0) else None,
+                     "note": "algorithmic bytes assume every gathered row comes from HBM; neighbouring queries share rows, so the "
+                             "measured HBM traffic (`traffic`) is far below it and the kernel is not HBM-bound in practice"}}
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: re-exec under it (one rank per GPU)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execvpe(cmd[0], cmd, env)
 
 
 def main():
@@ -221,9 +278,12 @@ def main():
     ap.add_argument("--white-bkgd", action="store_true", help="white background compositing (NeRF-synthetic scenes, BASELINE configs[2])")
     ap.add_argument("--no-normals", action="store_true",
                     help="calc_normal=False (SURVEY 8d config 2 asks for both): no nablas at the N sample points, no normals_volume")
+    ap.add_argument("--data-independent", action="store_true",
+                    help="evaluate every probe and every mid-point (NM_RENDER_FULL_PROBES | NM_RENDER_NO_ZERO_SKIP): the work the reference always does")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short variant runs reported under `extra`")
     args = ap.parse_args()
-    if args.workload == "stress5":
-        return stress5(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)
 
     import torch
     import torch.distributed as dist
@@ -235,7 +295,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -243,29 +303,21 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     lib = _lib.load()
 
-    mesh, model = build_scene(args.V, dev)
-    model.mlp_precision = args.mlp_precision
+    if args.workload == "stress5":
+        out = stress5_run(args, dev, world, rank, args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     if args.samples < 8 or args.samples % 8:
         raise SystemExit("--samples must be a multiple of 8 (two halves, four up-sampling iterations)")
-    cfg = make_render_cfg(calc_normal=not args.no_normals, N_samples=args.samples // 2, N_importance=args.samples // 2,
-                          white_bkgd=args.white_bkgd)
-    n_rays = args.H * args.W
-    total_steps = args.warmup + args.steps
+    mesh, model = build_scene(args.V, dev)
     from neumesh_amd import synthetic
     from neumesh_amd.rays import make_rays
-    rays = []
-    for s in range(total_steps):  # every rank builds the rays of ITS frame of the orbit on ITS GPU (nm_make_rays): resident before timing
-        rays.append(make_rays(synthetic.orbit_pose(s * world + rank), synthetic.pinhole_intrinsics(args.H, args.W), args.H, args.W, dev))
-    tables = model.field_tables()
-    model.field_handle()
-    gathered = torch.empty((world * n_rays, 8), dtype=torch.float32, device=dev) if world > 1 else None
-
-    def step(i):
-        ret = render_rays_fused(model, rays[i][0], rays[i][1], cfg, args.rayschunk or n_rays, tables=tables)
-        if world > 1:
-            packed, _ = pack_outputs(ret)
-            dist.all_gather_into_tensor(gathered, packed)   # the path's only collective: final pixels
-        return ret
+    n_rays = args.H * args.W
+    intr = synthetic.pinhole_intrinsics(args.H, args.W)
 
     def fence():
         torch.cuda.synchronize()
@@ -273,90 +325,147 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    rgb0 = None
-    for i in range(args.warmup):
-        ret = step(i)
-        if i == 0 and rank == 0:
-            rgb0 = ret["rgb"].cpu().numpy()
-    if args.warmup == 0 and rank == 0 and args.cpu_rays > 0 and world == 1:
+    def run(steps, warmup, precision="f16x2", samples=128, normals=True, white=False, flags=0, keep_frame0=False, gather=True):
+        """warmup + `steps` timed frames of one variant; returns (elapsed s [max over ranks], profile dict, rgb of frame 0 or None)."""
+        model.mlp_precision = precision
+        cfg = make_render_cfg(calc_normal=normals, N_samples=samples // 2, N_importance=samples // 2, white_bkgd=white, flags=flags)
+        total = warmup + steps
+        # every rank builds the rays of ITS frame of the orbit on ITS GPU (nm_make_rays): resident before timing
+        rays = [make_rays(synthetic.orbit_pose(s * world + rank), intr, args.H, args.W, dev) for s in range(total)]
+        tables = model.field_tables()
+        model.field_handle()
+        gathered = torch.empty((world * n_rays, 8 if normals else 5), dtype=torch.float32, device=dev) if (world > 1 and gather) else None
+
+        def step(i):
+            ret = render_rays_fused(model, rays[i][0], rays[i][1], cfg, args.rayschunk or n_rays, tables=tables)
+            if gathered is not None:
+                packed, _ = pack_outputs(ret)
+                dist.all_gather_into_tensor(gathered, packed)   # the path's only collective: final pixels
+            return ret
+
         rgb0 = None
-    fence()
-    lib.nm_profile_enable(1)
-    t0 = time.perf_counter()
-    for i in range(args.warmup, total_steps):
-        ret = step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        for i in range(warmup):
+            ret = step(i)
+            if i == 0 and keep_frame0 and rank == 0:
+                rgb0 = ret["rgb"].cpu().numpy()
+        fence()
+        lib.nm_profile_enable(1)
+        t0 = time.perf_counter()
+        for i in range(warmup, total):
+            step(i)
+        fence()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        prof = read_prof(lib)
+        lib.nm_profile_enable(0)
+        return elapsed, prof, rgb0, (rays[0] if keep_frame0 else None)
 
-    # per-kernel time inside the timed region (HIP events on the launch stream)
-    kinds = {0: ("knn_distance", None), 1: ("geo_mlp", FLOP_GEO), 2: ("geo_mlp_tangent", FLOP_GEO + FLOP_TANGENT), 3: ("color_mlp", FLOP_COL)}
-    prof = {}
-    for k, (name, flop) in kinds.items():
-        ms, n, u = C.c_double(), C.c_int64(), C.c_int64()
-        _lib.check(lib.nm_profile_read(k, C.byref(ms), C.byref(n), C.byref(u)), "nm_profile_read")
-        prof[name] = {"ms": ms.value, "launches": n.value, "points": u.value, "flop_per_point": flop}
-    lib.nm_profile_enable(0)
+    head_flags = (_lib.RENDER_FULL_PROBES | _lib.RENDER_NO_ZERO_SKIP) if args.data_independent else 0
+    elapsed, prof, rgb0, rays0 = run(args.steps, args.warmup, precision=args.mlp_precision, samples=args.samples,
+                                     normals=not args.no_normals, white=args.white_bkgd, flags=head_flags, keep_frame0=True)
 
-    if rank == 0:
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath))
-            except Exception:
-                traffic = None
-        rays_total = world * n_rays * args.steps
-        value = rays_total / elapsed
-        split = args.mlp_precision == "f16x2"
+    def mlp_summary(prof, precision):
+        split = precision == "f16x2"
         dom = max(("geo_mlp", "geo_mlp_tangent", "color_mlp"), key=lambda k: prof[k]["ms"])
         p = prof[dom]
-        achieved = p["points"] * p["flop_per_point"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
+        alg = p["points"] * p["flop_per_point"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
+        peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+        return dom, p, alg, peak, split
+
+    if rank == 0:
+        value = world * n_rays * args.steps / elapsed
+        dom, p, alg, peak, split = mlp_summary(prof, args.mlp_precision)
         mlp_flop = sum(prof[k]["points"] * prof[k]["flop_per_point"] for k in ("geo_mlp", "geo_mlp_tangent", "color_mlp"))
         mlp_ms = sum(prof[k]["ms"] for k in ("geo_mlp", "geo_mlp_tangent", "color_mlp"))
         kd = prof["knn_distance"]
+        traffic, tsrc = _load_profile("pmc_traffic")
+        mfma_pmc, msrc = _load_profile("pmc_mfma")
+        knn_pmc, ksrc = _load_profile("pmc_knn")
+        kname = ({"geo_mlp": "nm_geo_mlp_h_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_h_kernel<true>", "color_mlp": "nm_col_mlp_h_kernel"} if split else
+                 {"geo_mlp": "nm_geo_mlp_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_kernel<true>", "color_mlp": "nm_col_mlp_kernel"})[dom]
+        searched_per_s = kd["points"] / (kd["ms"] * 1e-3) if kd["ms"] > 0 else 0.0
+        strategy = ("every probe and every mid-point evaluated (data-independent work, as the reference)" if args.data_independent else
+                    "probes between the first and last hit and mid-points of weight 0 are not evaluated (bit-identical results, scene-dependent work)")
         out = {
             "metric": f"rays/sec at {args.H}x{args.W}x{args.samples} samples (DTU scan63 shape, synthetic scene S-DTU)",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_frame": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16x2-split (22-bit operands, fp32 accumulate; K-NN and per-ray stages fp32)" if split else "f32", "data": "synthetic",
-            "config": {"workload": f"S-DTU V={args.V} {args.H}x{args.W} rays/frame/GPU, {args.samples // 2}+{args.samples // 2} samples{', white background' if args.white_bkgd else ''}, bounded_near_far (256 probes), "
-                                   + (f"calc_normal, per ray {256 + 3 * args.samples - 1} K-NN points ({256 + 2 * args.samples - 1} searched at most, {args.samples} reused), {2 * args.samples - 1} geometry-MLP evaluations with nablas (the reference's {args.samples} forward-only ones at the same points are the value rows of these) + {args.samples - 1} colour-MLP; probes between the first and last hit and mid-points of weight 0 are not evaluated"
-                                    if not args.no_normals else f"calc_normal=False, per ray {256 + 3 * args.samples - 1} K-NN points ({256 + 2 * args.samples - 1} searched at most, {args.samples} reused), {args.samples} forward-only + {args.samples - 1} nabla geometry-MLP evaluations + {args.samples - 1} colour-MLP; probes between the first and last hit and mid-points of weight 0 are not evaluated"),
+            "config": {"workload": f"S-DTU V={args.V} {args.H}x{args.W} rays/frame/GPU, {args.samples // 2}+{args.samples // 2} samples"
+                                   f"{', white background' if args.white_bkgd else ''}, bounded_near_far (256 probes), calc_normal={not args.no_normals}; "
+                                   f"per ray {256 + 3 * args.samples - 1} K-NN points in the reference ({args.samples} of them re-addressed, not searched again), "
+                                   f"{2 * args.samples - 1} geometry-MLP evaluations + {args.samples - 1} colour-MLP; {strategy}",
                        "rayschunk": args.rayschunk or n_rays, "parallelism": f"rays sharded: {world} GPU(s) x 1 frame per step, 1 all-gather of pixels"},
-            "roofline": {"bound": "mfma", "kernel": ({"geo_mlp": "nm_geo_mlp_h_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_h_kernel<true>",
-                                                      "color_mlp": "nm_col_mlp_h_kernel"} if split else
-                                                     {"geo_mlp": "nm_geo_mlp_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_kernel<true>",
-                                                      "color_mlp": "nm_col_mlp_kernel"})[dom],
-                         # split-half mode executes 3 f16 MFMA products per algorithmic fp32 product
-                         "achieved": achieved * (3.0 if split else 1.0), "peak": PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved * (3.0 if split else 1.0) / (PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS),
-                         "algorithmic_tflops": achieved, "algorithmic_vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "mfma_dtype": "f16 (x3 products per fp32 product, fp32 accumulate)" if split else "f32",
-                         "traffic": (traffic or {}).get({"geo_mlp": "geo_mlp", "geo_mlp_tangent": "geo_mlp_tangent", "color_mlp": "color_mlp"}[dom], {}).get("hbm_bytes_per_launch") if traffic else None,
-                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)" if traffic else None,
+            "roofline": {"bound": "mfma", "kernel": kname,
+                         # achieved = ALGORITHMIC fp32 flops of the layer products / measured kernel time
+                         "achieved": alg, "peak": peak, "unit": "TFLOP/s", "frac": alg / peak,
+                         "mfma_dtype": "f16 (3 MFMA products per fp32 product: split-half operands, fp32 accumulate)" if split else "f32",
+                         # what the matrix pipe actually executes (3x the algorithmic flops in split-half mode)
+                         "issued_tflops": alg * (3.0 if split else 1.0), "issued_frac_of_pipe_peak": alg * (3.0 if split else 1.0) / peak,
+                         "algorithmic_vs_fp32_mfma_peak": alg / PEAK_FP32_MFMA_TFLOPS,
+                         "mfma_busy_pmc": (mfma_pmc or {}).get(dom), "mfma_busy_source": msrc,
+                         "traffic": (traffic or {}).get(dom, {}).get("hbm_bytes_per_launch"), "traffic_source": tsrc,
+                         "algorithmic_bytes_per_launch": (p["points"] / max(p["launches"], 1)) * (160 if dom != "color_mlp" else 156),
                          "avg_launch_ms": p["ms"] / max(p["launches"], 1), "launches": p["launches"],
+                         "points_per_launch": p["points"] / max(p["launches"], 1),
                          "all_mlp_kernels_tflops": mlp_flop / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0,
-                         "share_of_step_time": {k: prof[k]["ms"] / (elapsed * 1e3) for k in prof},
-                         "knn_kernel": {"queries_per_s": kd["points"] / (kd["ms"] * 1e-3) if kd["ms"] > 0 else 0.0,
-                                        "algorithmic_GBs": kd["points"] * KNN_BYTES_PER_QUERY / (kd["ms"] * 1e-3) / 1e9 if kd["ms"] > 0 else 0.0,
-                                        "hbm_frac": (kd["points"] * KNN_BYTES_PER_QUERY / (kd["ms"] * 1e-3) / 1e9) / PEAK_HBM_GBS if kd["ms"] > 0 else 0.0}},
+                         "share_of_step_time": {k: prof[k]["ms"] / (elapsed * 1e3) for k in prof}},
+            "knn_kernel": {"kernels": "nm_distance_kernel<chain> + nm_probe_bounds_kernel",
+                           "bound": "instruction issue + scalar-load latency (index is L2/scalar-cache resident; not HBM)",
+                           "searched_points_per_s": searched_per_s, "searched_points_per_frame": kd["points"] / max(args.steps * 1, 1),
+                           "ms_per_frame": kd["ms"] / max(args.steps, 1),
+                           "algorithmic_GBs_at_76B_per_query": searched_per_s * KNN_BYTES_PER_QUERY / 1e9,
+                           "hbm_frac_at_76B_per_query": searched_per_s * KNN_BYTES_PER_QUERY / 1e9 / PEAK_HBM_GBS,
+                           "issue_pmc": knn_pmc, "issue_pmc_source": ksrc,
+                           "traffic": (traffic or {}).get("knn_distance", {}).get("hbm_bytes_per_launch")},
         }
+        extra = {}
+        if world == 1 and not args.no_extras and not args.data_independent and args.samples == 128 and not args.no_normals and not args.white_bkgd:
+            def short(name, **kw):
+                try:
+                    e, pr, _, _ = run(2, 1, **kw)
+                    d, pp, a, pk, sp = mlp_summary(pr, kw.get("precision", "f16x2"))
+                    extra[name] = {"value": n_rays * 2 / e, "unit": "rays/s", "ms_per_frame": e / 2 * 1e3, "steps": 2,
+                                   "dominant_kernel": d, "achieved_tflops_algorithmic": a, "frac_of_pipe_peak": a / pk,
+                                   "knn_ms_per_frame": pr["knn_distance"]["ms"] / 2, "knn_searched_per_frame": pr["knn_distance"]["points"] / 2,
+                                   "mlp_points_per_frame": {k: pr[k]["points"] / 2 for k in ("geo_mlp", "geo_mlp_tangent", "color_mlp")}}
+                except Exception as ex:  # a variant must never sink the headline
+                    extra[name] = {"error": str(ex)}
+            short("data_independent_frame (every probe + every mid-point evaluated: the reference's work)",
+                  flags=_lib.RENDER_FULL_PROBES | _lib.RENDER_NO_ZERO_SKIP)
+            short("mlp_precision_fp32 (fp32-input MFMA)", precision="fp32")
+            short("calc_normal_false", normals=False)
+            short("config3_shape (64 samples/ray, white background)", samples=64, white=True)
+            model.mlp_precision = args.mlp_precision
         if world == 1 and args.cpu_rays > 0:
             try:
-                rays0 = (rays[0][0].cpu().numpy(), rays[0][1].cpu().numpy())
-                base, parity = cpu_baseline(mesh, model, args.H, args.W, args.cpu_rays, rgb0, rays0, samples=args.samples,
-                                            white_bkgd=args.white_bkgd, calc_normal=not args.no_normals)
+                r0 = (rays0[0].cpu().numpy(), rays0[1].cpu().numpy())
+                base, orgb, sel = cpu_baseline(mesh, model, args.H, args.W, args.cpu_rays, r0, samples=args.samples,
+                                               white_bkgd=args.white_bkgd, calc_normal=not args.no_normals)
                 out["cpu_baseline"] = base
-                if parity:
-                    out["parity_vs_oracle"] = parity
                 out["speedup_vs_cpu_baseline"] = value / base["value"]
+                out.update(parity_blocks(rgb0, args.H, args.W, args.V, orgb, sel))
             except Exception as e:  # the baseline must never sink the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        elif world == 1:
+            out.update(parity_blocks(rgb0, args.H, args.W, args.V, None, None))
+        if world == 1 and not args.no_extras and extra:
+            try:   # BASELINE config 5 (HBM-stress of the K-NN + gather kernel), 2 steps
+                del model
+                from neumesh_amd.renderer import release_workspaces
+                release_workspaces()
+                torch.cuda.empty_cache()
+                s5 = stress5_run(args, dev, 1, 0, 2, 1)
+                extra["config5_stress (V=1M, 256-d table, 4096x4096 queries/step)"] = {
+                    "value": s5["value"], "unit": s5["unit"], "ms_per_step": s5["ms_per_step"], "steps": 2, "roofline": s5["roofline"]}
+            except Exception as ex:
+                extra["config5_stress (V=1M, 256-d table, 4096x4096 queries/step)"] = {"error": str(ex)}
+        if extra:
+            out["extra"] = extra
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -215,7 +215,7 @@ class _RestoreGradMode:
 
 
 def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int, netchunk: int, detailed: bool = False,
-                       progress=None, differentiable: bool = False, perturb: bool = False):
+                       progress=None, differentiable: bool = False, perturb: bool = False, trace=None):
     """render_rayschunk (models/renderer.py:162-350) for ANY object that offers the field methods the
     reference's renderer calls -- compute_distance / forward_density_only / forward_with_nablas /
     forward / forward_s -- e.g. the editing tools' TextureEditableNeuMesh wrapper
@@ -227,7 +227,11 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
     above under torch.no_grad() (as in the reference, renderer.py:200-259), then the field is queried at
     the final points WITH autograd and alpha / weights / compositing are torch ops (renderer.py:264-333),
     so gradients reach every model parameter.  perturb=True draws the importance samples with
-    sample_pdf(det=False) (torch.rand handed to nm_rays_upsample)."""
+    sample_pdf(det=False) (torch.rand handed to nm_rays_upsample).
+
+    trace (diagnostics): a dict that receives, per ray chunk, the stage outputs a diverging ray can be
+    followed through -- "near_far" [R,2], "sdf_coarse" [R,Ns], "d_iter" (list: sorted depths after each
+    up-sampling iteration, renderer.py:255)."""
     lib = _lib.load()
     dev = rays_o.device
     rays_o = rays_o.detach().float().reshape(-1, 3).contiguous()
@@ -276,6 +280,10 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
             pts = torch.empty((R, Ns, 3), **f32)
             _lib.check(lib.nm_rays_points(_lib.ptr(ro), _lib.ptr(dirn), R, Ns, 2, _lib.ptr(nf), None, N, 0, _lib.ptr(d), _lib.ptr(pts), st), "nm_rays_points")
             sdf[:, :Ns] = query(model.forward_density_only, pts)[0].reshape(R, Ns)
+            if trace is not None:
+                trace.setdefault("near_far", []).append(nf.clone())
+                trace.setdefault("sdf_coarse", []).append(sdf[:, :Ns].clone())
+                trace.setdefault("d_iter", []).append([])
             n, pending = Ns, 0
             if Ni > 0:
                 n_new = Ni // iters
@@ -286,6 +294,8 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
                     _lib.check(lib.nm_rays_points(_lib.ptr(ro), _lib.ptr(dirn), R, n_new, 1, None, _lib.ptr(d), N, n, None, _lib.ptr(pts), st), "nm_rays_points")
                     sdf[:, n:n + n_new] = query(model.forward_density_only, pts)[0].reshape(R, n_new)
                     n, pending = n + n_new, n_new
+                    if trace is not None:   # (the merge of these n_new samples happens inside the next stage call)
+                        trace["d_iter"][-1].append(torch.sort(d[:, :n], dim=-1)[0])
             dmid = torch.zeros((R, N), **f32)
             _lib.check(lib.nm_rays_finalize(_lib.ptr(d), _lib.ptr(sdf), R, N, n, pending, _lib.ptr(dmid), st), "nm_rays_finalize")
             pts = torch.empty((R, N, 3), **f32)

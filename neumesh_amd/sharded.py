@@ -42,6 +42,20 @@ def unpack_outputs(packed: torch.Tensor, keys: Tuple[str, ...]) -> Dict[str, tor
     return out
 
 
+def _all_gather_rows(buf: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """[per, C] per rank -> [world*per, C] on every rank: ONE collective.  RCCL ("nccl") gathers device
+    tensors directly over xGMI; under a host backend (gloo: CPU-only test runs, or two ranks sharing one
+    GPU in the single-GPU parity test) the rows are staged through host memory."""
+    full = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype, device=buf.device)
+    if buf.is_cuda and dist.get_backend(group) != "nccl":
+        host = torch.empty(full.shape, dtype=buf.dtype)
+        dist.all_gather_into_tensor(host, buf.cpu(), group=group)
+        full.copy_(host)
+    else:
+        dist.all_gather_into_tensor(full, buf, group=group)
+    return full
+
+
 def render_sharded(render_fn: Callable[[torch.Tensor, torch.Tensor], Dict[str, torch.Tensor]], rays_o: torch.Tensor,
                    rays_d: torch.Tensor, group=None) -> Dict[str, torch.Tensor]:
     """Every rank passes the SAME full [N,3] rays (or its rank could build them on device, rays
@@ -57,8 +71,7 @@ def render_sharded(render_fn: Callable[[torch.Tensor, torch.Tensor], Dict[str, t
     per = -(-n // world)  # padded shard size so that the collective is a plain all_gather
     buf = torch.zeros((per, width), dtype=torch.float32, device=packed.device)
     buf[: hi - lo] = packed
-    full = torch.empty((world * per, width), dtype=torch.float32, device=packed.device)
-    dist.all_gather_into_tensor(full, buf, group=group)
+    full = _all_gather_rows(buf, world, group)
     pieces = []
     for r in range(world):
         a, b = shard_range(n, r, world)
@@ -82,7 +95,6 @@ def render_frame_sharded(render_fn, c2w, intrinsics, H: int, W: int, device, gro
     per = -(-n // world)
     buf = torch.zeros((per, packed.shape[1]), dtype=torch.float32, device=packed.device)
     buf[: hi - lo] = packed
-    full = torch.empty((world * per, packed.shape[1]), dtype=torch.float32, device=packed.device)
-    dist.all_gather_into_tensor(full, buf, group=group)
+    full = _all_gather_rows(buf, world, group)
     pieces = [full[r * per: r * per + (shard_range(n, r, world)[1] - shard_range(n, r, world)[0])] for r in range(world)]
     return unpack_outputs(torch.cat(pieces, dim=0), keys)

@@ -97,3 +97,25 @@ def psnr(a, b):
     """utils/metric_util.py:6-16 of the reference: -10 log10(mean((a-b)^2))."""
     mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
     return float("inf") if mse == 0 else -10.0 * np.log10(mse)
+
+
+def first_divergent_stage(got: dict, want: dict, ray: int):
+    """Diagnostics for a ray whose pixel differs: the first stage of render_rayschunk
+    (models/renderer.py:162-259) whose output differs from the reference's by more than the last bit.
+    got / want: {"near_far": [R,2], "sdf_coarse": [R,Ns], "d_iter1".."d_iterK": [R,n_k] sorted depths}.
+    Returns (stage name, max difference in units of the last place, number of differing entries)."""
+    stages = ["near_far", "sdf_coarse"] + sorted(k for k in want if k.startswith("d_iter"))
+    for name in stages:
+        if name not in got or name not in want:
+            continue
+        a = np.asarray(got[name][ray], np.float32).reshape(-1)
+        b = np.asarray(want[name][ray], np.float32).reshape(-1)
+        ulp = np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)).astype(np.float64)
+        diff = np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.maximum(ulp, 1e-45)
+        # sdf values are outputs of a 3-layer MLP: "the last bit" of the field is its 3e-6 parity bound
+        if name == "sdf_coarse":
+            diff = np.abs(a.astype(np.float64) - b.astype(np.float64)) / 3e-6
+        bad = diff > 1.0
+        if bad.any():
+            return name, float(diff.max()), int(bad.sum())
+    return None, 0.0, 0

@@ -227,6 +227,129 @@ def gen_grad_fixture(tag, render_tag, V, mlp_state):
                         rgb=rgb[0].detach().numpy(), **grads)
 
 
+def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=800, mlp_state=None):
+    """Headline-scale pin (BASELINE configs[1] shape, SURVEY 8d scene S-DTU): `n_rays` strided rays of
+    frame 0 of the 800x800 orbit rendered by the IMPORTED REFERENCE at V = 140 000, with the stages a
+    diverging ray can be traced through (near/far, coarse SDF, sorted depths after every up-sampling
+    iteration, final SDF) and the reference's own sensitivity to a 1-ulp nudge of the ray directions.
+
+    K-NN stand-in for FRNN: kd-tree candidates re-ranked under the declared fp32 arithmetic
+    (oracle/knn.py:knn_kdtree), checked here against the brute-force declaration on a sample of
+    the very query points the render issued."""
+    import time
+    import torch
+    from scipy.spatial import cKDTree
+    from oracle import knn as oknn
+    print(f"[{tag}] V={V} rays={n_rays} of {H}x{W}")
+    mesh = synthetic.fibonacci_blob(V)
+    model, kw, renderer, _ = harness.build_reference(mesh, seed=0, mlp_state=mlp_state)
+    import frnn as frnn_stub                 # oracle/refimport/stubs/frnn.py
+    import models.renderer as ref_renderer   # reference
+    tree = cKDTree(mesh.vertices.astype(np.float64))
+    queries = []
+
+    def knn_fn(q, v, K):
+        queries.append(q)
+        return oknn.knn_kdtree(q, v, K, tree=tree)
+
+    old_knn = frnn_stub.KNN_FN[0]
+    frnn_stub.KNN_FN[0] = knn_fn
+    o_all, d_all_ = synthetic.camera_rays(synthetic.orbit_pose(0), synthetic.pinhole_intrinsics(H, W), H, W)
+    sel = np.linspace(0, H * W - 1, n_rays).astype(np.int64)
+    rays_o, rays_d = o_all[sel], d_all_[sel]
+    kw = dict(kw)
+    kw.update(rayschunk=n_rays, calc_normal=True, N_samples=64, N_importance=64, perturb=False, white_bkgd=False)
+
+    def run(rd, trace):
+        """one reference render; trace (dict or None) receives the per-stage arrays"""
+        rec = {"sdf_calls": [], "sorted": []}
+        orig_bnf, orig_fdo, orig_fwn, orig_sort = (ref_renderer.compute_bounded_near_far, model.forward_density_only,
+                                                   model.forward_with_nablas, torch.sort)
+
+        def spy_bnf(*a, **k):
+            near, far = orig_bnf(*a, **k)
+            rec["near"], rec["far"] = near.detach().clone(), far.detach().clone()
+            return near, far
+
+        def spy_fdo(xyz):
+            out = orig_fdo(xyz)
+            rec["sdf_calls"].append(out.detach().clone())
+            return out
+
+        def spy_fwn(xyz):
+            rec["pts"] = xyz.detach().clone()
+            return orig_fwn(xyz)
+
+        def spy_sort(x, *a, **k):
+            out = orig_sort(x, *a, **k)
+            rec["sorted"].append(out[0].detach().clone())
+            return out
+
+        ref_renderer.compute_bounded_near_far, model.forward_density_only, model.forward_with_nablas = spy_bnf, spy_fdo, spy_fwn
+        torch.sort = spy_sort
+        try:
+            with torch.no_grad():
+                rgb, depth, ex = renderer(torch.from_numpy(rays_o)[None], torch.from_numpy(rd)[None], detailed_output=True, **kw)
+        finally:
+            ref_renderer.compute_bounded_near_far, model.forward_density_only, model.forward_with_nablas = orig_bnf, orig_fdo, orig_fwn
+            torch.sort = orig_sort
+        out = {k: v[0].detach().numpy() for k, v in ex.items()}
+        if trace is not None:
+            assert len(rec["sdf_calls"]) == 5 and len(rec["sorted"]) == 4, (len(rec["sdf_calls"]), len(rec["sorted"]))
+            trace["near_far"] = np.concatenate([rec["near"][0].numpy(), rec["far"][0].numpy()], axis=-1).astype(np.float32)
+            trace["sdf_coarse"] = rec["sdf_calls"][0][0, ..., 0].numpy().reshape(n_rays, -1).astype(np.float32)
+            for i, d in enumerate(rec["sorted"]):
+                trace[f"d_iter{i + 1}"] = d[0].numpy().astype(np.float32)
+            trace["pts"] = rec["pts"].numpy().reshape(n_rays, -1, 3)
+        return out
+
+    trace = {}
+    t0 = time.perf_counter()
+    ref = run(rays_d, trace)
+    t_ref = time.perf_counter() - t0
+    print(f"    reference render: {t_ref:.1f} s ({n_rays / t_ref:.0f} rays/s on {os.cpu_count()} cores, torch threads {torch.get_num_threads()})")
+    d_all = trace["d_iter4"]
+    assert d_all.shape == (n_rays, 128)
+    # the kd-tree stand-in == the brute-force declaration on (a sample of) the queries this render issued
+    qs = np.concatenate([q.reshape(-1, 3) for q in queries])
+    pick = np.random.default_rng(5).choice(qs.shape[0], 40000, replace=False)
+    bi, bd = oknn.knn_bruteforce(qs[pick], mesh.vertices, 8)
+    ki, kd = oknn.knn_kdtree(qs[pick], mesh.vertices, 8, tree=tree)
+    assert np.array_equal(bi, ki) and np.array_equal(bd, kd), "kd-tree + re-rank differs from the declared brute force"
+    print(f"    K-NN stand-in == brute-force declaration on 40000 of the {qs.shape[0]} query points of this render")
+    # the reference's own conditioning: the same render with every ray direction moved by 1 ulp
+    queries.clear()
+    ref2 = run(np.nextafter(rays_d, np.float32(10), dtype=np.float32), None)
+    frnn_stub.KNN_FN[0] = old_knn
+    self_err = np.abs(ref2["rgb"] - ref["rgb"]).max(-1).astype(np.float32)
+    print(f"    reference vs itself (directions + 1 ulp): {int((self_err > 1e-4).sum())}/{n_rays} rays > 1e-4, "
+          f"max {self_err.max():.2e}, median {np.median(self_err):.1e}, PSNR {compare.psnr(ref2['rgb'], ref['rgb']):.1f} dB")
+    # oracle restatement on the same rays (report; the V=3000 fixtures gate it tightly)
+    orc = oracle_from_reference(model, mesh)
+    orc.knn_fn = lambda q, v, K: oknn.knn_kdtree(q, v, K, tree=tree)
+    out = orender.render_rays(orc, rays_o, rays_d, orender.RenderConfig(calc_normal=True), detailed=True)
+    e = np.abs(out["rgb"] - ref["rgb"]).max(-1)
+    same = np.all(out["d_all"] == d_all, axis=1)
+    print(f"    oracle vs reference: {int((e > 1e-4).sum())}/{n_rays} rays > 1e-4, median {np.median(e):.1e}, PSNR {compare.psnr(out['rgb'], ref['rgb']):.1f} dB; "
+          f"rays with bit-identical sample sets {int(same.sum())}, max err among them {float(e[same].max()) if same.any() else float('nan'):.2e}")
+    REPORT[f"{tag}.oracle_vs_reference"] = {"rays_gt_1e-4": int((e > 1e-4).sum()), "median": float(np.median(e)),
+                                            "psnr_db": float(compare.psnr(out["rgb"], ref["rgb"])),
+                                            "identical_sample_sets": int(same.sum()),
+                                            "max_err_identical": float(e[same].max()) if same.any() else None}
+    REPORT[f"{tag}.reference_self_sensitivity_1ulp"] = {"rays_gt_1e-4": int((self_err > 1e-4).sum()), "max": float(self_err.max()),
+                                                       "psnr_db": float(compare.psnr(ref2["rgb"], ref["rgb"]))}
+    assert same.any() and float(e[same].max()) <= 1e-5 and (e > 1e-4).mean() <= (self_err > 1e-4).mean() + 0.01
+    np.savez_compressed(
+        os.path.join(GOLDEN, f"{tag}.npz"),
+        V=np.int64(V), H=np.int64(H), W=np.int64(W), frame=np.int64(0), sel=sel,
+        rays_o=rays_o, rays_d=rays_d, near_far=trace["near_far"], sdf_coarse=trace["sdf_coarse"],
+        d_iter1=trace["d_iter1"], d_iter2=trace["d_iter2"], d_iter3=trace["d_iter3"], d_all=d_all,
+        sdf_all=ref["implicit_surface"].astype(np.float32),
+        rgb=ref["rgb"], depth_volume=ref["depth_volume"], mask_volume=ref["mask_volume"], normals_volume=ref["normals_volume"],
+        self_err_1ulp=self_err,
+    )
+
+
 def gen_rays_fixture():
     """rend_util.get_rays of the reference (utils/rend_util.py:123-176) for a skewed pin-hole camera."""
     import torch
@@ -248,6 +371,15 @@ def gen_rays_fixture():
 
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "scale":   # only the V = 140 000 fixture (the others are unchanged)
+        sd = dict(np.load(os.path.join(GOLDEN, "model_seed0.npz")))
+        gen_scale_fixture("render_v140k_dtu", mlp_state=sd)
+        rp = os.path.join(GOLDEN, "REPORT.json")
+        old = json.load(open(rp)) if os.path.exists(rp) else {}
+        old.update(REPORT)
+        with open(rp, "w") as f:
+            json.dump(old, f, indent=1, sort_keys=True)
+        return
     gen_rays_fixture()
     model = gen_field_fixture("field_v3000", V=3000, Q=2048, seed=11)
     # one weights file shared by every fixture (reference ctor, torch.manual_seed(0))
@@ -258,6 +390,7 @@ def main():
     gen_render_fixture("render_v3000_dtu", V=3000, H=6, W=12, frame=3, mlp_state=sd)
     gen_render_fixture("render_v3000_lego", V=3000, H=4, W=12, frame=17, white_bkgd=True, n_samples=32, mlp_state=sd)
     gen_grad_fixture("grad_v3000_dtu", "render_v3000_dtu", V=3000, mlp_state=sd)
+    gen_scale_fixture("render_v140k_dtu", mlp_state=sd)
     with open(os.path.join(GOLDEN, "REPORT.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
     print("all oracle-vs-reference checks passed; fixtures written to", GOLDEN)
