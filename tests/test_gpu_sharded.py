@@ -25,6 +25,7 @@ import numpy as np, torch, torch.distributed as dist
 import common
 from neumesh_amd import synthetic
 from neumesh_amd.renderer import volume_render
+from neumesh_amd.rays import make_rays
 from neumesh_amd.sharded import render_frame_sharded
 ndev = torch.cuda.device_count()
 dev = torch.device("cuda", rank % ndev)
@@ -43,8 +44,8 @@ def render(ro, rd):
     with torch.no_grad():
         return volume_render(ro, rd, model, **rkw)[2]
 full = render_frame_sharded(render, c2w, K, H, W, dev)
-o, d = synthetic.camera_rays(c2w, K, H, W)
-want = render(torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev))
+o, d = make_rays(c2w, K, H, W, dev)      # the same device-side ray set-up the shards use (nm_make_rays), whole frame
+want = render(o, d)
 ok = all(torch.equal(full[k], want[k]) for k in ("rgb", "depth_volume", "mask_volume", "normals_volume"))
 ok = ok and tuple(full["rgb"].shape) == (H * W, 3) and bool(torch.isfinite(full["rgb"]).all())
 print("RANK", rank, "of", world, backend, "OK" if ok else "MISMATCH", flush=True)
