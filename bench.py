@@ -271,7 +271,7 @@ def main():
     ap.add_argument("--V", type=int, default=140_000)
     ap.add_argument("--rayschunk", type=int, default=0,
                     help="rays per nm_render_rays call; 0 = the whole frame in one call (56 KB of workspace per ray: 36 GB for 800x800)")
-    ap.add_argument("--mlp-precision", choices=["f16x2", "fp32"], default="f16x2",
+    ap.add_argument("--mlp-precision", choices=["f16x2", "f16x2_v1", "fp32"], default="f16x2",
                     help="MLP arithmetic: split-half f16 MFMA (default; 22-bit operands, fp32 accumulation) or fp32 MFMA")
     ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU-baseline sample (0 disables)")
     ap.add_argument("--samples", type=int, default=128, help="samples per ray, half coarse / half importance (BASELINE configs[2], lego: 64)")
@@ -368,7 +368,7 @@ def main():
                                      normals=not args.no_normals, white=args.white_bkgd, flags=head_flags, keep_frame0=True)
 
     def mlp_summary(prof, precision):
-        split = precision == "f16x2"
+        split = precision != "fp32"
         dom = max(("geo_mlp", "geo_mlp_tangent", "color_mlp"), key=lambda k: prof[k]["ms"])
         p = prof[dom]
         alg = p["points"] * p["flop_per_point"] / (p["ms"] * 1e-3) / 1e12 if p["ms"] > 0 else 0.0
@@ -384,7 +384,8 @@ def main():
         traffic, tsrc = _load_profile("pmc_traffic")
         mfma_pmc, msrc = _load_profile("pmc_mfma")
         knn_pmc, ksrc = _load_profile("pmc_knn")
-        kname = ({"geo_mlp": "nm_geo_mlp_h_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_h_kernel<true>", "color_mlp": "nm_col_mlp_h_kernel"} if split else
+        kname = ({"geo_mlp": "nm_geo_mlp_h2_kernel<false,true>", "geo_mlp_tangent": "nm_geo_mlp_h2_kernel<true,true>", "color_mlp": "nm_col_mlp_h2_kernel<true>"} if args.mlp_precision == "f16x2" else
+                 {"geo_mlp": "nm_geo_mlp_h_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_h_kernel<true>", "color_mlp": "nm_col_mlp_h_kernel"} if split else
                  {"geo_mlp": "nm_geo_mlp_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_kernel<true>", "color_mlp": "nm_col_mlp_kernel"})[dom]
         searched_per_s = kd["points"] / (kd["ms"] * 1e-3) if kd["ms"] > 0 else 0.0
         strategy = ("every probe and every mid-point evaluated (data-independent work, as the reference)" if args.data_independent else

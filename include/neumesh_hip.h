@@ -108,9 +108,10 @@ typedef struct nm_field_desc {
     int32_t multires_d, multires_fg, multires_ft, multires_view; /* embedder bands, >= 0 */
     int32_t enable_nablas_input;
     int32_t use_view_dirs;     /* must be 1 */
-    int32_t mlp_precision;     /* 0: fp32 MFMA (reference numerics); 1: split-half f16 MFMA -- every
+    int32_t mlp_precision;     /* 0: fp32 MFMA (reference numerics); 2: split-half f16 MFMA -- every
                                   value carried as two fp16 halves (22 bits), 3 f16 MFMAs per product,
-                                  fp32 accumulation; |activations| must stay < 65504 */
+                                  fp32 accumulation; |activations| must stay < 65504 (nm_field_overflow
+                                  reports a violation); 1: the first split-half kernels (A/B only) */
     const float* geo_weight[8];   /* device; layer 0: [W, in_geo], others [W,W] */
     const float* geo_bias[8];     /* device [W] */
     const float* density_weight;  /* device [1,W] */
@@ -124,6 +125,10 @@ typedef struct nm_field_desc {
 int nm_field_create(const nm_field_desc* desc, nm_stream_t stream, nm_field_t* out);
 int nm_field_update(nm_field_t f, const nm_field_desc* desc, nm_stream_t stream); /* re-pack */
 int nm_field_destroy(nm_field_t f);
+/* Split-half modes: *flag = 1 if any kernel launched on this handle since the last call saw a value
+ * outside the fp16 range (|v| >= 65504: the outputs of those launches are unusable, re-run with
+ * mlp_precision 0), else 0.  Synchronises `stream`; resets the flag. */
+int nm_field_overflow(nm_field_t f, int* flag, nm_stream_t stream);
 
 /* Tables + scalars that change without re-packing (borrowed device pointers, [V,dim]). */
 typedef struct nm_field_tables {

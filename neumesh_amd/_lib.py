@@ -75,6 +75,7 @@ SIGNATURES = {
     "nm_field_create": (C.c_int, [C.POINTER(FieldDesc), _P, C.POINTER(_P)]),
     "nm_field_update": (C.c_int, [_P, C.POINTER(FieldDesc), _P]),
     "nm_field_destroy": (C.c_int, [_P]),
+    "nm_field_overflow": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
     "nm_field_scratch_bytes": (C.c_int64, [C.c_int64]),
     "nm_field_density": (C.c_int, [_P, _P, C.POINTER(FieldTables), _P, C.c_int64, _P, _P, _P, _P]),
     "nm_field_forward": (C.c_int, [_P, _P, C.POINTER(FieldTables), _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -19,6 +19,7 @@
 #include "nm_kernels.h"
 #include "nm_mlp.h"
 #include "nm_mlp_f16.h"
+#include "nm_mlp_h2.h"
 
 // ------------------------------------------------------------------------------ error state
 static thread_local std::string g_err;
@@ -106,11 +107,15 @@ struct nm_field_s {
     NmColParams col;
     float* blob = nullptr;  // packed weights
     size_t blob_floats = 0;
-    int precision = 0;       // 0 fp32, 1 split-half f16
+    int precision = 0;       // 0 fp32, 1 split-half f16 (first layout), 2 split-half f16 (nm_mlp_h2.h, default)
     NmGeoParamsH geo_h;
     NmColParamsH col_h;
-    _Float16* blob_h = nullptr;  // split-half weights in fragment order
+    NmGeoParamsH2 geo_h2;
+    NmColParamsH2 col_h2;
+    bool geo_fixed = false, col_fixed = false;  // reference configuration: kernels with constant embedding trip counts
+    _Float16* blob_h = nullptr;  // split-half weights in fragment order (layout of the active mode)
     size_t blob_h_halves = 0;
+    int* overflow = nullptr;     // device flag raised by the split-half kernels when a value leaves the fp16 range
 };
 
 extern "C" {
@@ -265,7 +270,7 @@ static int nm_field_validate(const nm_field_desc* d) {
     if (d->multires_d < 0 || d->multires_fg < 0 || d->multires_ft < 0 || d->multires_view < 0) return nm_fail("nm_field: negative multires (identity embedders) unsupported");
     if (d->multires_d > 16 || d->multires_view > 16) return nm_fail("nm_field: multires too large");
     if (!d->use_view_dirs) return nm_fail("nm_field: use_view_dirs=0 unsupported");
-    if (d->mlp_precision != 0 && d->mlp_precision != 1) return nm_fail("nm_field: mlp_precision=%d (0 = fp32, 1 = split-half f16)", d->mlp_precision);
+    if (d->mlp_precision < 0 || d->mlp_precision > 2) return nm_fail("nm_field: mlp_precision=%d (0 = fp32, 1 = split-half f16 first layout, 2 = split-half f16)", d->mlp_precision);
     const int in_geo = 1 + 2 * d->multires_d + d->geometry_dim * (1 + 2 * d->multires_fg);
     const int in_col = (d->enable_nablas_input ? 3 : 0) + 1 + 2 * d->multires_d + 3 * (1 + 2 * d->multires_view) + d->color_dim * (1 + 2 * d->multires_ft);
     if (in_geo > 256 || in_col > 256) return nm_fail("nm_field: MLP input width %d/%d exceeds the 256-column LDS tile", in_geo, in_col);
@@ -335,7 +340,7 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
     f->col.in_dim = in_col;
     f->desc = *d;
     f->precision = d->mlp_precision;
-    if (d->mlp_precision == 1) {
+    if (d->mlp_precision >= 1) {
         size_t need_h = 0;
         for (int l = 0; l < d->D_density; ++l) need_h += (size_t)NM_W * nm_round16(l == 0 ? in_geo : NM_W) * 2;
         for (int l = 0; l < d->D_color; ++l) need_h += (size_t)NM_W * nm_round16(l == 0 ? in_col : NM_W) * 2;
@@ -346,6 +351,12 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
             NM_HIP(hipMalloc((void**)&f->blob_h, need_h * sizeof(_Float16)));
             f->blob_h_halves = need_h;
         }
+        if (!f->overflow) {
+            NM_HIP(hipMalloc((void**)&f->overflow, sizeof(int)));
+            NM_HIP(hipMemsetAsync(f->overflow, 0, sizeof(int), stream));
+        }
+    }
+    if (d->mlp_precision == 1) {
         _Float16* ph = f->blob_h;
         memset(&f->geo_h, 0, sizeof(f->geo_h));
         memset(&f->col_h, 0, sizeof(f->col_h));
@@ -367,6 +378,57 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
         f->col_h.brgb[0] = f->col.brgb[0]; f->col_h.brgb[1] = f->col.brgb[1]; f->col_h.brgb[2] = f->col.brgb[2];
         f->col_h.multires_d = f->col.multires_d; f->col_h.multires_ft = f->col.multires_ft; f->col_h.multires_view = f->col.multires_view;
         f->col_h.cdim = f->col.cdim; f->col_h.use_nabla = f->col.use_nabla; f->col_h.d_emb = f->col.d_emb; f->col_h.in_dim = f->col.in_dim;
+    }
+    if (d->mlp_precision == 2) {
+        _Float16* ph = f->blob_h;
+        memset(&f->geo_h2, 0, sizeof(f->geo_h2));
+        memset(&f->col_h2, 0, sizeof(f->col_h2));
+        auto pack_h2 = [&](const float* src, int in_dim, const NmColSeg& seg, NmLayerH& L, const float* packed_bias) {
+            L.Kpad = nm_round16(in_dim);
+            L.W = ph;
+            L.b = packed_bias;
+            hipLaunchKernelGGL(nm_pack_weight_h2_kernel, dim3(nm_blocks((long long)NM_W * L.Kpad, 256)), dim3(256), 0, stream, src, in_dim, L.Kpad, seg, ph);
+            ph += (size_t)NM_W * L.Kpad * 2;
+        };
+        NmColSeg ident;
+        memset(&ident, 0, sizeof(ident));
+        ident.n = 1; ident.len[0] = NM_W; ident.src[0] = 0;
+        // layer-0 column orders (nm_mlp_h2.h): logical = the reference's torch.cat order
+        //   geometry  logical [ds | (sin,cos) x md | code embedding]         -> physical [code embedding | (sin,cos) x md | ds]
+        //   colour    logical [nabla | ds | (sin,cos) x md | view | view bands | code embedding]
+        //                                                                      -> physical [code embedding | (sin,cos) x md | view bands | view | nabla | ds]
+        const int md2 = 2 * d->multires_d, d_emb = 1 + md2;
+        const int FG = d->geometry_dim * (1 + 2 * d->multires_fg), FT = d->color_dim * (1 + 2 * d->multires_ft);
+        NmColSeg sg;
+        memset(&sg, 0, sizeof(sg));
+        sg.n = 3;
+        sg.len[0] = FG;  sg.src[0] = d_emb;
+        sg.len[1] = md2; sg.src[1] = 1;
+        sg.len[2] = 1;   sg.src[2] = 0;
+        const int nb = d->enable_nablas_input ? 3 : 0, vb = 6 * d->multires_view;
+        const int lo_d = nb, lo_v = nb + d_emb, lo_f = lo_v + 3 + vb;
+        NmColSeg sc;
+        memset(&sc, 0, sizeof(sc));
+        sc.n = 6;
+        sc.len[0] = FT;  sc.src[0] = lo_f;
+        sc.len[1] = md2; sc.src[1] = lo_d + 1;
+        sc.len[2] = vb;  sc.src[2] = lo_v + 3;
+        sc.len[3] = 3;   sc.src[3] = lo_v;
+        sc.len[4] = nb;  sc.src[4] = 0;
+        sc.len[5] = 1;   sc.src[5] = lo_d;
+        for (int l = 0; l < d->D_density; ++l) pack_h2(d->geo_weight[l], l == 0 ? in_geo : NM_W, l == 0 ? sg : ident, f->geo_h2.layer[l], f->geo.layer[l].b);
+        for (int l = 0; l < d->D_color; ++l) pack_h2(d->col_weight[l], l == 0 ? in_col : NM_W, l == 0 ? sc : ident, f->col_h2.layer[l], f->col.layer[l].b);
+        NM_LAUNCH_CHECK();
+        NM_HIP(hipStreamSynchronize(stream));
+        f->geo_h2.D = f->geo.D; f->geo_h2.wd = f->geo.wd; f->geo_h2.bd = f->geo.bd;
+        f->geo_h2.multires_d = f->geo.multires_d; f->geo_h2.multires_fg = f->geo.multires_fg; f->geo_h2.gdim = f->geo.gdim;
+        f->geo_h2.fg_w = FG; f->geo_h2.in_dim = f->geo.in_dim;
+        f->col_h2.D = f->col.D; f->col_h2.wrgb = f->col.wrgb;
+        f->col_h2.brgb[0] = f->col.brgb[0]; f->col_h2.brgb[1] = f->col.brgb[1]; f->col_h2.brgb[2] = f->col.brgb[2];
+        f->col_h2.multires_d = f->col.multires_d; f->col_h2.multires_ft = f->col.multires_ft; f->col_h2.multires_view = f->col.multires_view;
+        f->col_h2.cdim = f->col.cdim; f->col_h2.use_nabla = f->col.use_nabla; f->col_h2.ft_w = FT; f->col_h2.in_dim = f->col.in_dim;
+        f->geo_fixed = d->geometry_dim == 32 && d->multires_fg == 2 && d->multires_d == 8;
+        f->col_fixed = d->color_dim == 32 && d->multires_ft == 2 && d->multires_d == 8 && d->multires_view == 4 && d->enable_nablas_input;
     }
     return 0;
 }
@@ -393,7 +455,19 @@ int nm_field_destroy(nm_field_t f) {
     if (!f) return 0;
     if (f->blob) hipFree(f->blob);
     if (f->blob_h) hipFree(f->blob_h);
+    if (f->overflow) hipFree(f->overflow);
     delete f;
+    return 0;
+}
+
+int nm_field_overflow(nm_field_t f, int* flag, nm_stream_t stream_) {
+    if (!f || !flag) return nm_fail("nm_field_overflow: NULL argument");
+    *flag = 0;
+    if (!f->overflow) return 0;
+    hipStream_t stream = (hipStream_t)stream_;
+    NM_HIP(hipMemcpyAsync(flag, f->overflow, sizeof(int), hipMemcpyDeviceToHost, stream));
+    NM_HIP(hipStreamSynchronize(stream));
+    if (*flag) NM_HIP(hipMemsetAsync(f->overflow, 0, sizeof(int), stream));
     return 0;
 }
 
@@ -438,6 +512,15 @@ static int nm_launch_geo(nm_field_t f, const float* fg, const float* ds, const f
                          NmRecMap rmap = NM_COMPACT, int nabla_slotted = 0, NmSlotMap smap = NM_NO_SLOTS, bool counted = false) {
     if (P <= 0) return 0;
     NmProfScope prof(nabla ? NM_K_GEO_NABLA : NM_K_GEO, counted ? 0 : P, stream, counted ? NM_CNT_MID : NM_CNT_NONE);
+    if (f->precision == 2) {
+        const dim3 gr(nm_blocks(P, nabla ? 32 : 64)), bl(NM_H_THREADS);
+        if (nabla && f->geo_fixed) hipLaunchKernelGGL((nm_geo_mlp_h2_kernel<true, true>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow);
+        else if (nabla) hipLaunchKernelGGL((nm_geo_mlp_h2_kernel<true, false>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow);
+        else if (f->geo_fixed) hipLaunchKernelGGL((nm_geo_mlp_h2_kernel<false, true>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow);
+        else hipLaunchKernelGGL((nm_geo_mlp_h2_kernel<false, false>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow);
+        NM_LAUNCH_CHECK();
+        return 0;
+    }
     if (f->precision == 1) {
         if (nabla) hipLaunchKernelGGL((nm_geo_mlp_h_kernel<true>), dim3(nm_blocks(P, 32)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap);
         else hipLaunchKernelGGL((nm_geo_mlp_h_kernel<false>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap);
@@ -459,6 +542,12 @@ static int nm_launch_col(nm_field_t f, const float* ft, const float* ds, const f
                          long long P, float* rgb, hipStream_t stream, NmSlotMap smap = NM_NO_SLOTS, bool counted = false) {
     if (P <= 0) return 0;
     NmProfScope prof(NM_K_COLOR, counted ? 0 : P, stream, counted ? NM_CNT_MID : NM_CNT_NONE);
+    if (f->precision == 2) {
+        if (f->col_fixed) hipLaunchKernelGGL((nm_col_mlp_h2_kernel<true>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h2, ft, ds, nabla, dirs, dir_div, P, rgb, smap, f->overflow);
+        else hipLaunchKernelGGL((nm_col_mlp_h2_kernel<false>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h2, ft, ds, nabla, dirs, dir_div, P, rgb, smap, f->overflow);
+        NM_LAUNCH_CHECK();
+        return 0;
+    }
     if (f->precision == 1) {
         hipLaunchKernelGGL(nm_col_mlp_h_kernel, dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h, ft, ds, nabla, dirs, dir_div, P, rgb, smap);
         NM_LAUNCH_CHECK();

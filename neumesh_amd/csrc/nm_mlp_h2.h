@@ -1,0 +1,626 @@
+// nm_mlp_h2.h -- fused embed + MLP kernels on the f16 matrix pipe with split-half operands
+// (precision mode 2, the default).  Same arithmetic model as nm_mlp_f16.h (every fp32 value carried
+// as h1 + h2 * 2^-11, three f16 MFMAs per fp32 product, fp32 accumulation) with the data flow
+// re-cut around what the phase stamps of that kernel showed (matrix pipe 46 % busy,
+// the rest spent in 2-byte LDS stores, a 14 k-cycle input phase and a separate output projection):
+//
+//  * The MFMA operands are swapped: D = W_tile (32 output columns x 16 k) * A^T (16 k x 32 points).
+//    The 32x32 result layout then gives a lane ONE point and 16 output columns, and the weight rows
+//    of a column tile are packed in the order that makes those 16 columns CONSECUTIVE
+//    (MFMA row i = 4h + 8g + e  <->  column 16h + 4g + e of the tile).  The epilogue therefore
+//    writes its activations with 16-byte LDS stores (4 per tile and plane-pair instead of 64
+//    2-byte stores) and converts them in pairs.
+//  * Layer-0 input columns are PERMUTED (the permutation is folded into the packed weights):
+//    [code embedding | sin/cos pairs of ds | (view bands, view, nabla) | ds].  Every lane of the
+//    input phase then owns 4 consecutive columns per embedding band (8-byte stores), the tangent
+//    rows of the geometry MLP are non-zero only in the last k-steps of layer 0 (the others are
+//    skipped for that row tile), and no column needs an odd-address store except the last few.
+//  * The output projection (256 -> 1 / 3) is fused into the last hidden layer's epilogue: each
+//    lane multiplies its 32 fp32 activations by the head weights straight from the accumulators,
+//    a half-wave exchange + a 4-wave LDS reduction finish it.  The last layer's activations are
+//    never split or stored, and the head sees full fp32 activations.
+//  * Biases and head weights sit in LDS (one coalesced copy per workgroup).
+//  * The input phase of the reference configuration (32-d codes, 2 / 8 / 4 embedding bands) is
+//    compiled with constant trip counts (FIXED); other configurations take the same code with the
+//    counts as run-time values.
+//  * Every value that is split is also tracked for fp16 range: a lane that sees |v| >= 65504 raises
+//    a flag in the field handle (nm_field_overflow), so a checkpoint that does not fit the
+//    split-half format is detected instead of rendering garbage.
+//
+// Reference semantics: models/frameworks/neumesh/neumesh.py:204-260, models/base.py:52-70 (see nm_mlp.h).
+#pragma once
+
+#include "nm_mlp_f16.h"
+
+typedef _Float16 nm_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 nm_h2 __attribute__((ext_vector_type(2)));
+
+#define NM_H2_BIAS_LAYERS 4  // biases of the first 4 layers live in LDS (deeper layers read them from L2)
+#define NM_H2_FP16_MAX 65504.0f
+
+// physical input column k of layer 0 -> logical column of the reference's concatenation:
+// consecutive segments, segment s = physical [sum len[<s], +len[s]) = logical [src[s], +len[s])
+struct NmColSeg {
+    int n;
+    int len[6], src[6];
+};
+
+// weights: fp32 [256][in_dim] (PyTorch layout, logical columns) -> split halves in MFMA A-operand
+// fragment order [column tile 8][k-step Kpad/16][plane 2][lane 64][8 halves]; lane = (row i of the
+// tile) | (k-half << 5) with row i = 4h + 8g + e holding output column 16h + 4g + e (header comment).
+__global__ void nm_pack_weight_h2_kernel(const float* __restrict__ src, int in_dim, int Kpad, NmColSeg seg, _Float16* __restrict__ dst) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (n, k)
+    if (e >= NM_W * Kpad) return;
+    const int n = e / Kpad, k = e - n * Kpad;
+    int kl = -1, base = 0;
+    for (int s = 0; s < seg.n; ++s) {
+        if (kl < 0 && k >= base && k < base + seg.len[s]) kl = seg.src[s] + (k - base);
+        base += seg.len[s];
+    }
+    const float w = (kl >= 0 && kl < in_dim) ? src[(size_t)n * in_dim + kl] : 0.f;
+    _Float16 h1, h2;
+    nm_split_half(w, &h1, &h2);
+    const int ct = n >> 5, c = n & 31;
+    const int i = 4 * (c >> 4) + 8 * ((c >> 2) & 3) + (c & 3);
+    const int lane = i | (((k >> 3) & 1) << 5), ks = k >> 4, el = k & 7;
+    const int KS = Kpad >> 4;
+    const size_t o = ((size_t)(ct * KS + ks) * 2) * 64 * 8;
+    dst[o + (size_t)lane * 8 + el] = h1;
+    dst[o + 64 * 8 + (size_t)lane * 8 + el] = h2;
+}
+
+struct NmGeoParamsH2 {
+    NmLayerH layer[NM_MAX_LAYERS];
+    int D;
+    const float* wd;  // [256]
+    float bd;
+    int multires_d, multires_fg, gdim;
+    int fg_w, in_dim;  // fg_w = gdim*(1+2*multires_fg): width of the code-embedding block = first column of the ds block
+};
+
+struct NmColParamsH2 {
+    NmLayerH layer[NM_MAX_LAYERS];
+    int D;
+    const float* wrgb;  // [3][256]
+    float brgb[3];
+    int multires_d, multires_ft, multires_view, cdim, use_nabla;
+    int ft_w, in_dim;   // ft_w = cdim*(1+2*multires_ft)
+};
+
+// ------------------------------------------------------------------------- split + store helpers
+// (mx: running max of |value| for the fp16-range check)
+__device__ __forceinline__ void nm_h2_store1(_Float16* p, float a, float& mx) {
+    _Float16 h1, h2;
+    nm_split_half(a, &h1, &h2);
+    p[0] = h1;
+    p[NM_H_PLANE] = h2;
+    mx = fmaxf(mx, fabsf(a));
+}
+__device__ __forceinline__ void nm_h2_store2(_Float16* p, float a, float b, float& mx) {  // p 4-byte aligned
+    _Float16 a1, a2, b1, b2;
+    nm_split_half(a, &a1, &a2);
+    nm_split_half(b, &b1, &b2);
+    *reinterpret_cast<nm_h2*>(p) = nm_h2{a1, b1};
+    *reinterpret_cast<nm_h2*>(p + NM_H_PLANE) = nm_h2{a2, b2};
+    mx = fmaxf(mx, fmaxf(fabsf(a), fabsf(b)));
+}
+__device__ __forceinline__ void nm_h2_store4(_Float16* p, const float (&v)[4], float& mx) {  // p 8-byte aligned
+    nm_h4 a, b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        _Float16 h1, h2;
+        nm_split_half(v[e], &h1, &h2);
+        a[e] = h1;
+        b[e] = h2;
+        mx = fmaxf(mx, fabsf(v[e]));
+    }
+    *reinterpret_cast<nm_h4*>(p) = a;
+    *reinterpret_cast<nm_h4*>(p + NM_H_PLANE) = b;
+}
+__device__ __forceinline__ void nm_h2_store8(_Float16* p, const float (&v)[8], float& mx) {  // p 16-byte aligned
+    nm_h8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        _Float16 h1, h2;
+        nm_split_half(v[e], &h1, &h2);
+        a[e] = h1;
+        b[e] = h2;
+        mx = fmaxf(mx, fabsf(v[e]));
+    }
+    *reinterpret_cast<nm_h8*>(p) = a;
+    *reinterpret_cast<nm_h8*>(p + NM_H_PLANE) = b;
+}
+// zero columns [c0, c1) of a tile row, both planes (c0 a multiple of 8: 16-byte stores, then singles)
+__device__ __forceinline__ void nm_h2_zero_cols(_Float16* row, int c0, int c1, int j) {
+    const nm_h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int full = (c1 - c0) >> 3;
+    for (int b = j; b < full; b += 8) {
+        *reinterpret_cast<nm_h8*>(row + c0 + 8 * b) = z;
+        *reinterpret_cast<nm_h8*>(row + NM_H_PLANE + c0 + 8 * b) = z;
+    }
+    for (int c = c0 + 8 * full + j; c < c1; c += 8) {
+        row[c] = (_Float16)0.0f;
+        row[NM_H_PLANE + c] = (_Float16)0.0f;
+    }
+}
+
+// x and its sin/cos bands for 4 consecutive dims of a `dim`-wide code vector, into an embedding block
+// that starts at blk[0]: 8-byte stores (dim is a multiple of 4).  Odd bands from the even band below
+// by the double-angle identities, as nm_embed4_h.
+__device__ __forceinline__ void nm_h2_embed_chunk(_Float16* blk, int dim, int bands, int chunk, float4 x, float& mx) {
+    const float xs[4] = {x.x, x.y, x.z, x.w};
+    nm_h2_store4(blk + 4 * chunk, xs, mx);
+    float f = 1.0f;
+    for (int b = 0; b < bands; b += 2) {
+        float s[4], c[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) nm_sincos(xs[e] * f, &s[e], &c[e]);
+        nm_h2_store4(blk + dim * (1 + 2 * b) + 4 * chunk, s, mx);
+        nm_h2_store4(blk + dim * (2 + 2 * b) + 4 * chunk, c, mx);
+        if (b + 1 < bands) {
+            float s2[4], c2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s2[e] = 2.0f * s[e] * c[e];
+                c2[e] = (c[e] - s[e]) * (c[e] + s[e]);
+            }
+            nm_h2_store4(blk + dim * (3 + 2 * b) + 4 * chunk, s2, mx);
+            nm_h2_store4(blk + dim * (4 + 2 * b) + 4 * chunk, c2, mx);
+        }
+        f *= 4.0f;
+    }
+}
+
+// --------------------------------------------------------------------------------- K loop
+// As nm_kloop_h (B fragments two k-steps ahead in three rotating register sets, A fragments one step
+// ahead, fully unrolled, sched_barriers pinning the issue points) with the operands swapped -- the
+// weight fragment is the MFMA's A operand, the activation fragment its B operand -- and KT0: the first
+// k-step in which row tile 1 takes part (layer 0 of the tangent kernel: its tangent rows are zero before).
+#define NM_H2_MFMAS(A, F, R1)                                                                             \
+    _Pragma("unroll") for (int rt_ = 0; rt_ < (R1); ++rt_) _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_)  \
+        c.hi[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[c_], A[rt_][0], c.hi[rt_][c_], 0, 0, 0);   \
+    _Pragma("unroll") for (int rt_ = 0; rt_ < (R1); ++rt_) _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_)  \
+        c.lo[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.b[c_], A[rt_][0], c.lo[rt_][c_], 0, 0, 0);   \
+    _Pragma("unroll") for (int rt_ = 0; rt_ < (R1); ++rt_) _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_)  \
+        c.lo[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[c_], A[rt_][1], c.lo[rt_][c_], 0, 0, 0);
+
+template <int KS, int CT, int KT0>
+__device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16* a1p, const nm_h8* const (&bp)[CT],
+                                            const NmBFrag<CT>& pre0, const NmBFrag<CT>& pre1, NmAccH<CT>& c) {
+    NmBFrag<CT> f[3];
+    f[0] = pre0;
+    f[1] = pre1;
+    nm_h8 a[2][2][2];  // [buffer][row tile][plane]
+    a[0][0][0] = *reinterpret_cast<const nm_h8*>(a0p);
+    a[0][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
+    if (KT0 == 0) {
+        a[0][1][0] = *reinterpret_cast<const nm_h8*>(a1p);
+        a[0][1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 2 < KS) f[(ks + 2) % 3] = nm_ld_b<CT>(bp, ks + 2);
+        if (ks + 1 < KS) {
+            const int oa = (ks + 1) * 16;
+            a[(ks + 1) & 1][0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
+            a[(ks + 1) & 1][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
+            if (ks + 1 >= KT0) {
+                a[(ks + 1) & 1][1][0] = *reinterpret_cast<const nm_h8*>(a1p + oa);
+                a[(ks + 1) & 1][1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE + oa);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks >= KT0) {
+            NM_H2_MFMAS(a[ks & 1], f[ks % 3], 2)
+        } else {
+            NM_H2_MFMAS(a[ks & 1], f[ks % 3], 1)
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// any other layer-0 width (run-time k-step counts): rolled loops, fragments one step ahead; k-steps
+// [0, kt0) without row tile 1, then [kt0, KS) with it
+template <int CT>
+__device__ __forceinline__ void nm_kloop_h2_generic(int KS, int kt0, const _Float16* a0p, const _Float16* a1p,
+                                                    const nm_h8* const (&bp)[CT], const NmBFrag<CT>& pre0, NmAccH<CT>& c) {
+    NmBFrag<CT> nf = pre0;
+    nm_h8 na[2][2];
+    na[0][0] = *reinterpret_cast<const nm_h8*>(a0p);
+    na[0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
+    na[1][0] = *reinterpret_cast<const nm_h8*>(a1p);
+    na[1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE);
+    int ks = 0;
+    for (; ks < kt0; ++ks) {
+        const NmBFrag<CT> F = nf;
+        nm_h8 A[2][2];
+        A[0][0] = na[0][0]; A[0][1] = na[0][1]; A[1][0] = na[1][0]; A[1][1] = na[1][1];
+        if (ks + 1 < KS) {
+            nf = nm_ld_b<CT>(bp, ks + 1);
+            const int oa = (ks + 1) * 16;
+            na[0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
+            na[0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
+            na[1][0] = *reinterpret_cast<const nm_h8*>(a1p + oa);
+            na[1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE + oa);
+        }
+        NM_H2_MFMAS(A, F, 1)
+    }
+    for (; ks < KS; ++ks) {
+        const NmBFrag<CT> F = nf;
+        nm_h8 A[2][2];
+        A[0][0] = na[0][0]; A[0][1] = na[0][1]; A[1][0] = na[1][0]; A[1][1] = na[1][1];
+        if (ks + 1 < KS) {
+            nf = nm_ld_b<CT>(bp, ks + 1);
+            const int oa = (ks + 1) * 16;
+            na[0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
+            na[0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
+            na[1][0] = *reinterpret_cast<const nm_h8*>(a1p + oa);
+            na[1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE + oa);
+        }
+        NM_H2_MFMAS(A, F, 2)
+    }
+}
+#undef NM_H2_MFMAS
+
+// One dense layer on the split-half LDS tile.  Not the last hidden layer: activations go back into the
+// tile (in place).  LAST: the NOUT-wide head (density / rgb) is applied to the fp32 activations in
+// registers and the per-row sums land in red[wave][row][NOUT]; the tile is not written.
+//   cst_b: this layer's bias in LDS ([256], or nullptr -> bias_g from global); head_w: LDS [NOUT][256].
+//   KSF / KT0F: compile-time k-step count of the layer and first k-step with non-zero row-tile-1 operands
+//   (non-zero only in layer 0 of the tangent kernel); KSF = 0: run-time counts (L.Kpad, kt0), rolled loops.
+template <int ACT, bool TANGENT, bool LAST, int NOUT, int CT, int KSF, int KT0F>
+__device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L, const int kt0, const bool has_next, const NmLayerH next,
+                                                NmBFrag<CT>& pre0, NmBFrag<CT>& pre1, const float* cst_b, const float* head_w,
+                                                float* red, float& mx, int stamp_slot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int n0 = wave * 32 * CT;
+    const _Float16* a0p = tile + li * NM_H_STRIDE + 8 * h;
+    const _Float16* a1p = tile + (32 + li) * NM_H_STRIDE + 8 * h;
+    const nm_h8* bp[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bp[c] = nm_b_base(L.W, L.Kpad, wave * CT + c);
+    NmAccH<CT> c;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) c.hi[rt][ct] = c.lo[rt][ct] = nm_f32x16{0};
+    if (KSF > 0) nm_kloop_h2<(KSF > 0 ? KSF : 1), CT, KT0F>(a0p, a1p, bp, pre0, pre1, c);  // one straight-line loop, no run-time dispatch
+    else nm_kloop_h2_generic<CT>(L.Kpad >> 4, kt0, a0p, a1p, bp, pre0, c);
+    if (has_next) nm_prefetch_b<CT>(next, pre0, pre1);
+    if (!LAST) __syncthreads();  // every wave has finished reading the input tile
+    nm_phase_stamp(stamp_slot);
+    const float sc = 1.0f / 2048.0f;
+    float so[2][NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) so[0][o] = so[1][o] = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {  // 8 columns at a time: one 16-byte store per row and plane, short live ranges
+            const int col0 = n0 + 32 * ct + 16 * h + 8 * hf;  // this lane's columns: register 8*hf + r <-> column col0 + r
+            const float* bsrc = (cst_b ? cst_b : L.b) + col0;
+            const float4 b0 = *reinterpret_cast<const float4*>(bsrc), b1 = *reinterpret_cast<const float4*>(bsrc + 4);
+            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float y0[8], y1[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float z0 = fmaf(c.lo[0][ct][8 * hf + r], sc, c.hi[0][ct][8 * hf + r]) + bv[r];
+                const float t1 = fmaf(c.lo[1][ct][8 * hf + r], sc, c.hi[1][ct][8 * hf + r]);
+                if (TANGENT) {
+                    float g0;
+                    if (ACT == 0) {
+                        y0[r] = nm_softplus100(z0, &g0);
+                    } else {
+                        y0[r] = fmaxf(z0, 0.f);
+                        g0 = z0 > 0.f ? 1.f : 0.f;
+                    }
+                    y1[r] = t1 * g0;
+                } else {
+                    const float z1 = t1 + bv[r];
+                    if (ACT == 0) {
+                        y0[r] = nm_softplus100(z0, nullptr);
+                        y1[r] = nm_softplus100(z1, nullptr);
+                    } else {
+                        y0[r] = fmaxf(z0, 0.f);
+                        y1[r] = fmaxf(z1, 0.f);
+                    }
+                }
+            }
+            if (!LAST) {
+                nm_h2_store8(tile + li * NM_H_STRIDE + col0, y0, mx);
+                nm_h2_store8(tile + (32 + li) * NM_H_STRIDE + col0, y1, mx);
+            } else {
+#pragma unroll
+                for (int o = 0; o < NOUT; ++o) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(head_w + o * NM_W + col0);
+                    const float4 w1 = *reinterpret_cast<const float4*>(head_w + o * NM_W + col0 + 4);
+                    const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        so[0][o] = fmaf(y0[r], wv[r], so[0][o]);
+                        so[1][o] = fmaf(y1[r], wv[r], so[1][o]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (!LAST) {
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {  // the two half-waves hold the same points, different columns
+            so[0][o] += __shfl_xor(so[0][o], 32);
+            so[1][o] += __shfl_xor(so[1][o], 32);
+        }
+        if (h == 0) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                red[(wave * NM_ROWS + li) * NOUT + o] = so[0][o];
+                red[(wave * NM_ROWS + 32 + li) * NOUT + o] = so[1][o];
+            }
+        }
+        __syncthreads();
+    }
+    nm_phase_stamp(stamp_slot + 1);
+}
+
+__device__ __forceinline__ void nm_h2_raise(int* overflow, float mx) {
+    if (overflow && !(mx < NM_H2_FP16_MAX)) *overflow = 1;  // (benign race: every writer stores 1)
+}
+
+// ------------------------------------------------------------------ geometry MLP (split-half, v2)
+// Same contract as nm_geo_mlp_h_kernel.  FIXED: gdim = 32, multires_fg = 2, multires_d = 8 (Kpad0 = 192).
+template <bool NABLA, bool FIXED>
+__global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_h2_kernel(
+    NmGeoParamsH2 prm, const float* __restrict__ fg_rec, const float* __restrict__ ds, const float* __restrict__ grad, NmRecMap rmap,
+    long long npts, float* __restrict__ sdf_out, int P, int stride, int off, float* __restrict__ nabla_out, int nabla_slotted,
+    NmSlotMap smap, int* __restrict__ overflow) {
+    __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE + NM_EXP_LDS_PAD];
+    __shared__ __attribute__((aligned(16))) float cst[(NM_H2_BIAS_LAYERS + 1) * NM_W];  // biases of layers 0..3 | density weights
+    __shared__ float red[4 * NM_ROWS];
+    constexpr int PTS = NABLA ? 32 : 64;
+    const long long base = (long long)blockIdx.x * PTS;
+    if (smap.order && smap.order[base] == 0xffffu) return;  // no point in this tile (valid entries lead each group)
+    const NmDivBase rdiv = nm_div_base(base, rmap.stride ? rmap.P : 1), odiv = nm_div_base(base, P);
+    nm_phase_stamp(0);
+    NmBFrag<NM_H_CT> pre0, pre1;
+    nm_prefetch_b<NM_H_CT>(prm.layer[0], pre0, pre1);  // in flight during the input phase
+    const int gdim = FIXED ? 32 : prm.gdim, mfg = FIXED ? 2 : prm.multires_fg, md = FIXED ? 8 : prm.multires_d;
+    const int FG = FIXED ? 160 : prm.fg_w, in_dim = FG + 2 * md + 1;
+    const int Kpad0 = FIXED ? 192 : prm.layer[0].Kpad;
+    const int kt0 = NABLA ? (FG >> 4) : 0;  // tangent rows are zero before the ds block
+    const int nchunk = gdim >> 2;           // <= 16: at most two 4-dim chunks per lane
+    constexpr int ROUNDS = PTS * 8 / NM_H_THREADS;
+    float in_ds[ROUNDS];
+    float4 in_fg[ROUNDS][2];
+    // all global loads of the input phase first (both task rounds), then the constants, then the embedding work
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int task = threadIdx.x + rd * NM_H_THREADS;
+        const int p = task >> 3, j = task & 7;
+        in_ds[rd] = 0.f;
+        in_fg[rd][0] = in_fg[rd][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (base + p < npts && nm_slot_valid(smap, base + p)) {
+            const long long rq = nm_rec_index_local(rmap, rdiv, base, p);
+            in_ds[rd] = ds[rq];
+            if (j < nchunk) in_fg[rd][0] = *reinterpret_cast<const float4*>(fg_rec + rq * gdim + 4 * j);
+            if (j + 8 < nchunk) in_fg[rd][1] = *reinterpret_cast<const float4*>(fg_rec + rq * gdim + 4 * (j + 8));
+        }
+    }
+    {
+        const int nb = prm.D < NM_H2_BIAS_LAYERS ? prm.D : NM_H2_BIAS_LAYERS;
+        for (int l = 0; l < nb; ++l) cst[l * NM_W + threadIdx.x] = prm.layer[l].b[threadIdx.x];
+        cst[NM_H2_BIAS_LAYERS * NM_W + threadIdx.x] = prm.wd[threadIdx.x];
+    }
+    float mx = 0.f;
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int task = threadIdx.x + rd * NM_H_THREADS;
+        const int p = task >> 3, j = task & 7;
+        const long long q = base + p;
+        _Float16* vrow = tile + p * NM_H_STRIDE;
+        _Float16* trow = tile + (32 + p) * NM_H_STRIDE;  // (NABLA only)
+        if (q >= npts || !nm_slot_valid(smap, q)) {
+            nm_h2_zero_cols(vrow, 0, Kpad0, j);
+            if (NABLA) nm_h2_zero_cols(trow, 16 * kt0, Kpad0, j);
+            continue;
+        }
+        const float dsv = in_ds[rd];
+        if (j < nchunk) nm_h2_embed_chunk(vrow, gdim, mfg, j, in_fg[rd][0], mx);
+        if (j + 8 < nchunk) nm_h2_embed_chunk(vrow, gdim, mfg, j + 8, in_fg[rd][1], mx);
+        for (int b = j; b < md; b += 8) {  // ds block: (sin, cos) pairs, then ds itself
+            const float f = (float)(1 << b);
+            float s, co;
+            nm_sincos(dsv * f, &s, &co);
+            nm_h2_store2(vrow + FG + 2 * b, s, co, mx);
+            if (NABLA) nm_h2_store2(trow + FG + 2 * b, (NM_TANGENT_SCALE * f) * co, -(NM_TANGENT_SCALE * f) * s, mx);
+        }
+        if (j == 0) {
+            nm_h2_store1(vrow + FG + 2 * md, dsv, mx);
+            if (NABLA) nm_h2_store1(trow + FG + 2 * md, NM_TANGENT_SCALE, mx);
+        }
+        for (int c = in_dim + j; c < Kpad0; c += 8) {  // padding columns
+            vrow[c] = (_Float16)0.0f;
+            vrow[NM_H_PLANE + c] = (_Float16)0.0f;
+            if (NABLA) {
+                trow[c] = (_Float16)0.0f;
+                trow[NM_H_PLANE + c] = (_Float16)0.0f;
+            }
+        }
+        if (NABLA)
+            for (int c = 16 * kt0 + j; c < FG; c += 8) {  // tangent columns of the first live k-step below the ds block
+                trow[c] = (_Float16)0.0f;
+                trow[NM_H_PLANE + c] = (_Float16)0.0f;
+            }
+    }
+    __syncthreads();
+    nm_phase_stamp(1);
+    // layer 0: straight-line K loop for the reference widths (FIXED), rolled loops otherwise; hidden layers are
+    // always 256 wide (16 k-steps).  (kernel-argument loads with a uniform index: scalar)
+    constexpr int KS0 = FIXED ? 12 : 0, KT0 = (FIXED && NABLA) ? 10 : 0;
+    const float* head = cst + NM_H2_BIAS_LAYERS * NM_W;
+    if (prm.D == 1) {
+        nm_mlp_layer_h2<0, NABLA, true, 1, NM_H_CT, KS0, KT0>(tile, prm.layer[0], kt0, false, prm.layer[0], pre0, pre1, cst, head, red, mx, 2);
+    } else {
+        nm_mlp_layer_h2<0, NABLA, false, 1, NM_H_CT, KS0, KT0>(tile, prm.layer[0], kt0, true, prm.layer[1], pre0, pre1, cst, nullptr, red, mx, 2);
+        for (int l = 1; l + 1 < prm.D; ++l)
+            nm_mlp_layer_h2<0, NABLA, false, 1, NM_H_CT, 16, 0>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre0, pre1,
+                                                                 l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, nullptr, red, mx, 2 + 2 * l);
+        const int l = prm.D - 1;
+        nm_mlp_layer_h2<0, NABLA, true, 1, NM_H_CT, 16, 0>(tile, prm.layer[l], 0, false, prm.layer[l], pre0, pre1,
+                                                            l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, head, red, mx, 2 + 2 * l);
+    }
+    if (threadIdx.x < PTS) {
+        const int t = threadIdx.x;
+        const long long q = base + t;
+        if (q < npts && nm_slot_valid(smap, q)) {
+            const float sdf = ((red[t] + red[NM_ROWS + t]) + (red[2 * NM_ROWS + t] + red[3 * NM_ROWS + t])) + prm.bd;
+            long long orow;
+            int op;
+            nm_div_local(odiv, t, orow, op);
+            const long long oidx = orow * stride + off + op;  // (ray, sample) addressed output position
+            if (sdf_out) sdf_out[oidx] = sdf;
+            if (NABLA && nabla_out) {
+                const float dsdf = ((red[32 + t] + red[NM_ROWS + 32 + t]) + (red[2 * NM_ROWS + 32 + t] + red[3 * NM_ROWS + 32 + t])) * (1.0f / NM_TANGENT_SCALE);
+                const long long rq = nm_rec_index_local(rmap, rdiv, base, t);
+                const long long no = nabla_slotted ? oidx : q;
+                nabla_out[no * 3 + 0] = dsdf * grad[rq * 3 + 0];
+                nabla_out[no * 3 + 1] = dsdf * grad[rq * 3 + 1];
+                nabla_out[no * 3 + 2] = dsdf * grad[rq * 3 + 2];
+            }
+        }
+    }
+    nm_h2_raise(overflow, mx);
+    nm_phase_stamp(15);
+}
+
+// ------------------------------------------------------------------ colour MLP (split-half, v2)
+// Physical input columns: [ft embedding | (sin, cos) pairs of ds | view bands | view | nabla | ds].
+// FIXED: cdim = 32, multires_ft = 2, multires_d = 8, multires_view = 4, nabla input (207 -> Kpad0 = 208).
+template <bool FIXED>
+__global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_h2_kernel(
+    NmColParamsH2 prm, const float* __restrict__ ft_rec, const float* __restrict__ ds, const float* __restrict__ nabla,
+    const float* __restrict__ dirs, int dir_div, long long npts, float* __restrict__ rgb_out, NmSlotMap smap, int* __restrict__ overflow) {
+    __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE + NM_EXP_LDS_PAD];
+    __shared__ __attribute__((aligned(16))) float cst[(NM_H2_BIAS_LAYERS + 3) * NM_W];  // biases of layers 0..3 | rgb weights [3][256]
+    __shared__ float red[4 * NM_ROWS * 3];
+    const long long base = (long long)blockIdx.x * NM_ROWS;
+    if (smap.order && smap.order[base] == 0xffffu) return;  // no point in this tile
+    const NmDivBase ddiv = nm_div_base(base, dir_div);
+    const long long ray0 = smap.order ? (base / smap.E) * smap.G : 0;  // uniform: one division per workgroup
+    nm_phase_stamp(0);
+    NmBFrag<NM_H_CT> pre0, pre1;
+    nm_prefetch_b<NM_H_CT>(prm.layer[0], pre0, pre1);  // in flight during the input phase
+    const int cdim = FIXED ? 32 : prm.cdim, mft = FIXED ? 2 : prm.multires_ft, md = FIXED ? 8 : prm.multires_d;
+    const int mv = FIXED ? 4 : prm.multires_view, use_nabla = FIXED ? 1 : prm.use_nabla;
+    const int FT = FIXED ? 160 : prm.ft_w;
+    const int o_d = FT, o_vb = o_d + 2 * md, o_v = o_vb + 6 * mv, o_n = o_v + 3, o_ds = o_n + (use_nabla ? 3 : 0);
+    const int in_dim = o_ds + 1;
+    const int Kpad0 = FIXED ? 208 : prm.layer[0].Kpad;
+    const int nchunk = cdim >> 2;
+    constexpr int ROUNDS = NM_ROWS * 8 / NM_H_THREADS;  // global loads of both task rounds first
+    float in_ds[ROUNDS], in_x[ROUNDS];  // in_x: lane j < 3: view component j, 3 <= j < 6: nabla component j - 3
+    float in_dv[ROUNDS][3];
+    float4 in_ft[ROUNDS][2];
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int task = threadIdx.x + rd * NM_H_THREADS;
+        const int p = task >> 3, j = task & 7;
+        const long long q = base + p;
+        in_ds[rd] = in_x[rd] = 0.f;
+        in_dv[rd][0] = in_dv[rd][1] = in_dv[rd][2] = 0.f;
+        in_ft[rd][0] = in_ft[rd][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < npts && nm_slot_valid(smap, q)) {
+            in_ds[rd] = ds[q];
+            long long ray;
+            int unused_p;
+            if (smap.order) nm_slot_ray(smap, q, ray0, ray, unused_p);
+            else nm_div_local(ddiv, p, ray, unused_p);
+            in_dv[rd][0] = dirs[ray * 3 + 0];
+            in_dv[rd][1] = dirs[ray * 3 + 1];
+            in_dv[rd][2] = dirs[ray * 3 + 2];
+            if (use_nabla && j >= 3 && j < 6) in_x[rd] = nabla[q * 3 + (j - 3)];
+            if (j < nchunk) in_ft[rd][0] = *reinterpret_cast<const float4*>(ft_rec + q * cdim + 4 * j);
+            if (j + 8 < nchunk) in_ft[rd][1] = *reinterpret_cast<const float4*>(ft_rec + q * cdim + 4 * (j + 8));
+        }
+    }
+    {
+        const int nb = prm.D < NM_H2_BIAS_LAYERS ? prm.D : NM_H2_BIAS_LAYERS;
+        for (int l = 0; l < nb; ++l) cst[l * NM_W + threadIdx.x] = prm.layer[l].b[threadIdx.x];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) cst[(NM_H2_BIAS_LAYERS + o) * NM_W + threadIdx.x] = prm.wrgb[o * NM_W + threadIdx.x];
+    }
+    float mx = 0.f;
+#pragma unroll
+    for (int rd = 0; rd < ROUNDS; ++rd) {
+        const int task = threadIdx.x + rd * NM_H_THREADS;
+        const int p = task >> 3, j = task & 7;
+        const long long q = base + p;
+        _Float16* vrow = tile + p * NM_H_STRIDE;
+        if (q >= npts || !nm_slot_valid(smap, q)) {
+            nm_h2_zero_cols(vrow, 0, Kpad0, j);
+            continue;
+        }
+        const float dsv = in_ds[rd];
+        const float dv[3] = {in_dv[rd][0], in_dv[rd][1], in_dv[rd][2]};
+        if (j < nchunk) nm_h2_embed_chunk(vrow, cdim, mft, j, in_ft[rd][0], mx);
+        if (j + 8 < nchunk) nm_h2_embed_chunk(vrow, cdim, mft, j + 8, in_ft[rd][1], mx);
+        for (int b = j; b < md; b += 8) {
+            float s, co;
+            nm_sincos(dsv * (float)(1 << b), &s, &co);
+            nm_h2_store2(vrow + o_d + 2 * b, s, co, mx);
+        }
+        for (int e = j; e < 3 * mv; e += 8) {  // view bands: [sin(v f_b) (3) | cos(v f_b) (3)] per band
+            const int b = e / 3, dim = e - 3 * b;
+            float s, co;
+            nm_sincos((dim == 0 ? dv[0] : dim == 1 ? dv[1] : dv[2]) * (float)(1 << b), &s, &co);
+            nm_h2_store1(vrow + o_vb + 6 * b + dim, s, mx);
+            nm_h2_store1(vrow + o_vb + 6 * b + 3 + dim, co, mx);
+        }
+        if (j < 3) nm_h2_store1(vrow + o_v + j, j == 0 ? dv[0] : j == 1 ? dv[1] : dv[2], mx);
+        else if (j < 6 && use_nabla) nm_h2_store1(vrow + o_n + (j - 3), in_x[rd], mx);
+        else if (j == 6) nm_h2_store1(vrow + o_ds, dsv, mx);
+        for (int c = in_dim + j; c < Kpad0; c += 8) {
+            vrow[c] = (_Float16)0.0f;
+            vrow[NM_H_PLANE + c] = (_Float16)0.0f;
+        }
+    }
+    __syncthreads();
+    nm_phase_stamp(1);
+    constexpr int KS0 = FIXED ? 13 : 0;
+    const float* head = cst + NM_H2_BIAS_LAYERS * NM_W;
+    if (prm.D == 1) {
+        nm_mlp_layer_h2<1, false, true, 3, NM_H_CT, KS0, 0>(tile, prm.layer[0], 0, false, prm.layer[0], pre0, pre1, cst, head, red, mx, 2);
+    } else {
+        nm_mlp_layer_h2<1, false, false, 3, NM_H_CT, KS0, 0>(tile, prm.layer[0], 0, true, prm.layer[1], pre0, pre1, cst, nullptr, red, mx, 2);
+        for (int l = 1; l + 1 < prm.D; ++l)
+            nm_mlp_layer_h2<1, false, false, 3, NM_H_CT, 16, 0>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre0, pre1,
+                                                                 l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, nullptr, red, mx, 2 + 2 * l);
+        const int l = prm.D - 1;
+        nm_mlp_layer_h2<1, false, true, 3, NM_H_CT, 16, 0>(tile, prm.layer[l], 0, false, prm.layer[l], pre0, pre1,
+                                                            l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, head, red, mx, 2 + 2 * l);
+    }
+    if (threadIdx.x < NM_ROWS) {  // one thread per point: its three channels are one 12-byte store
+        const int p = threadIdx.x;
+        const long long q = base + p;
+        if (q < npts && nm_slot_valid(smap, q)) {
+            long long oq = q;  // ordered lists: the colour goes back to its (ray, sample) position
+            if (smap.order) {
+                long long ray;
+                int sp;
+                nm_slot_ray(smap, q, ray0, ray, sp);
+                oq = ray * smap.P + sp;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float z = ((red[p * 3 + c] + red[(NM_ROWS + p) * 3 + c]) + (red[(2 * NM_ROWS + p) * 3 + c] + red[(3 * NM_ROWS + p) * 3 + c])) + prm.brgb[c];
+                rgb_out[oq * 3 + c] = __fdiv_rn(1.0f, 1.0f + expf(-z));
+            }
+        }
+    }
+    nm_h2_raise(overflow, mx);
+    nm_phase_stamp(15);
+}

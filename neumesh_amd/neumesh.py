@@ -52,6 +52,10 @@ def get_embedder(multires: int, input_dim: int = 3):
     return e, e.out_dim
 
 
+# mlp_precision -> nm_field_desc.mlp_precision ("f16x2_v1": the first split-half kernels, kept for A/B runs)
+_PRECISION_CODES = {"fp32": 0, "f16x2_v1": 1, "f16x2": 2}
+
+
 def interpolation(features, indices, weights):
     """neumesh.py:11-13."""
     return torch.sum(features[indices] * weights.unsqueeze(-1), dim=-2)
@@ -110,6 +114,7 @@ class NeuMesh(nn.Module):
         self._field_key = None    # parameter versions / device / precision the packed weights were built from
         self._field_dev = None
         self._field_epoch = 0     # bumped by invalidate_field()
+        self._range_checked = False
         self._keep = None         # tensors whose pointers the last FieldDesc referenced
 
     # ------------------------------------------------------------------ scalars
@@ -140,8 +145,8 @@ class NeuMesh(nn.Module):
     def field_handle(self):
         """nm_field_t with the current MLP weights (weight-norm folded), re-packed when they change."""
         ps = self._mlp_params()
-        if self.mlp_precision not in ("fp32", "f16x2"):
-            raise ValueError(f"mlp_precision={self.mlp_precision!r}: expected 'fp32' or 'f16x2'")
+        if self.mlp_precision not in _PRECISION_CODES:
+            raise ValueError(f"mlp_precision={self.mlp_precision!r}: expected one of {sorted(_PRECISION_CODES)}")
         dev = ps[0].device
         key = tuple((p.data_ptr(), p._version) for p in ps) + (self.mlp_precision, str(dev), self._field_epoch)
         if self._field is not None and key == self._field_key:
@@ -169,7 +174,7 @@ class NeuMesh(nn.Module):
         d.geometry_dim, d.color_dim = c["geometry_dim"], c["color_dim"]
         d.multires_d, d.multires_fg, d.multires_ft, d.multires_view = c["multires_d"], c["multires_fg"], c["multires_ft"], c["multires_view"]
         d.enable_nablas_input, d.use_view_dirs = int(self.enable_nablas_input), 1
-        d.mlp_precision = 1 if self.mlp_precision == "f16x2" else 0
+        d.mlp_precision = _PRECISION_CODES[self.mlp_precision]
         for i, (w_, b_) in enumerate(zip(gw, gb)):
             d.geo_weight[i], d.geo_bias[i] = w_.data_ptr(), b_.data_ptr()
         for i, (w_, b_) in enumerate(zip(cw, cb)):
@@ -187,7 +192,29 @@ class NeuMesh(nn.Module):
         self._keep = (gw, gb, dw, db, cw, cb, rw, rb)  # the pack call synchronised; kept for clarity
         self._field_key = key
         self._field_dev = dev
+        self._range_checked = False   # new weights: the next fused call verifies the fp16 range once
         return self._field
+
+    def check_fp16_range(self, force: bool = False) -> bool:
+        """Split-half modes only: ask the library whether any launch since the last check saw a value
+        outside the fp16 range (nm_field_overflow; synchronises the stream).  Called once after the
+        first fused call on a new weight set; returns True if the results of those launches are valid.
+        On overflow the model switches itself to mlp_precision='fp32' (with a warning) and returns False:
+        the caller re-runs the call."""
+        if self.mlp_precision == "fp32" or self._field is None or (self._range_checked and not force):
+            return True
+        lib = _lib.load()
+        flag = C.c_int(0)
+        with torch.cuda.device(self._field_dev):
+            _lib.check(lib.nm_field_overflow(self._field, C.byref(flag), _lib.current_stream(self._field_dev)), "nm_field_overflow")
+        self._range_checked = True
+        if not flag.value:
+            return True
+        import warnings
+        warnings.warn("NeuMesh: an MLP activation or input left the fp16 range (|v| >= 65504) in the split-half f16 mode; "
+                      "switching this model to mlp_precision='fp32' and re-running", RuntimeWarning)
+        self.mlp_precision = "fp32"
+        return False
 
     def invalidate_field(self):
         """Force a re-pack of the MLP weights at the next use.  Needed only after edits that bypass
@@ -225,9 +252,12 @@ class NeuMesh(nn.Module):
         scratch = torch.empty((int(lib.nm_field_scratch_bytes(P)),), dtype=torch.uint8, device=q.device)
         t, keep = self.field_tables()
         with torch.cuda.device(q.device):
-            _lib.check(lib.nm_field_density(self.field_handle(), self.mesh_grid.grid.handle, C.byref(t), _lib.ptr(q), P,
-                                            _lib.ptr(sdf), _lib.ptr(nab), _lib.ptr(scratch), _lib.current_stream(q.device)),
-                       "nm_field_density")
+            for _attempt in range(2):
+                _lib.check(lib.nm_field_density(self.field_handle(), self.mesh_grid.grid.handle, C.byref(t), _lib.ptr(q), P,
+                                                _lib.ptr(sdf), _lib.ptr(nab), _lib.ptr(scratch), _lib.current_stream(q.device)),
+                           "nm_field_density")
+                if self.check_fp16_range():
+                    break
         del keep
         return sdf.reshape(*xyz.shape[:-1], 1), (None if nab is None else nab.reshape(xyz.shape))
 
@@ -245,9 +275,12 @@ class NeuMesh(nn.Module):
         scratch = torch.empty((int(lib.nm_field_scratch_bytes(P)),), dtype=torch.uint8, device=dev)
         t, keep = self.field_tables()
         with torch.cuda.device(dev):
-            _lib.check(lib.nm_field_forward(self.field_handle(), self.mesh_grid.grid.handle, C.byref(t), _lib.ptr(q), _lib.ptr(v), P,
-                                            _lib.ptr(sdf), _lib.ptr(rgb), _lib.ptr(nab), _lib.ptr(ds), _lib.ptr(idx), _lib.ptr(w),
-                                            _lib.ptr(scratch), _lib.current_stream(dev)), "nm_field_forward")
+            for _attempt in range(2):
+                _lib.check(lib.nm_field_forward(self.field_handle(), self.mesh_grid.grid.handle, C.byref(t), _lib.ptr(q), _lib.ptr(v), P,
+                                                _lib.ptr(sdf), _lib.ptr(rgb), _lib.ptr(nab), _lib.ptr(ds), _lib.ptr(idx), _lib.ptr(w),
+                                                _lib.ptr(scratch), _lib.current_stream(dev)), "nm_field_forward")
+                if self.check_fp16_range():
+                    break
         del keep
         lead = xyz.shape[:-1]
         out = (sdf.reshape(*lead, 1), rgb.reshape(*lead, 3), nab.reshape(*lead, 3))
@@ -312,9 +345,12 @@ class NeuMesh(nn.Module):
             rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
             scratch = torch.empty((int(lib.nm_field_scratch_bytes(P)),), dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
-                _lib.check(lib.nm_field_color(self.field_handle(), _lib.ptr(cf), _lib.ptr(dd), _lib.ptr(v), _lib.ptr(ii), _lib.ptr(ww),
-                                              _lib.ptr(nn_), P, _lib.ptr(rgb), _lib.ptr(scratch), _lib.current_stream(dev)),
-                           "nm_field_color")
+                for _attempt in range(2):
+                    _lib.check(lib.nm_field_color(self.field_handle(), _lib.ptr(cf), _lib.ptr(dd), _lib.ptr(v), _lib.ptr(ii), _lib.ptr(ww),
+                                                  _lib.ptr(nn_), P, _lib.ptr(rgb), _lib.ptr(scratch), _lib.current_stream(dev)),
+                               "nm_field_color")
+                    if self.check_fp16_range():
+                        break
             return rgb.reshape(*lead, 3)
         return self._forward_color(self.embed_fn_d(d), view_dirs, color_features, indices, weights, nabla)
 

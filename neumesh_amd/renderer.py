@@ -129,6 +129,13 @@ def _n_lanes() -> int:
 def render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int, detailed: bool = False,
                       tables=None, progress=None):
     """rays_o / rays_d: [R,3] device tensors.  Returns dict of [R,...] tensors."""
+    out = _render_rays_fused(model, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress)
+    if not model.check_fp16_range():   # first call on a new weight set only: out of fp16 range -> fp32 kernels, once more
+        out = _render_rays_fused(model, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress)
+    return out
+
+
+def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress):
     lib = _lib.load()
     dev = rays_o.device
     if dev.type != "cuda":

@@ -164,7 +164,7 @@ def test_compute_distance_matches_reference(small, cuda_device, torch_mod):
     assert torch_mod.equal(ds, ds2)
 
 
-@pytest.mark.parametrize("precision", ["f16x2", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x2", "f16x2_v1", "fp32"])
 def test_field_methods_match_reference(small, cuda_device, torch_mod, precision):
     torch = torch_mod
     _, _, model = small
@@ -257,7 +257,7 @@ def test_get_rays_kernel_matches_reference(cuda_device, torch_mod):
 
 
 # ----------------------------------------------------------------------------- renderer
-@pytest.mark.parametrize("precision", ["f16x2", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x2", "f16x2_v1", "fp32"])
 @pytest.mark.parametrize("tag", ["render_v3000_dtu", "render_v3000_lego"])
 def test_render_matches_reference_fixture(small, cuda_device, torch_mod, tag, precision):
     torch = torch_mod
