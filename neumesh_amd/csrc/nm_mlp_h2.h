@@ -35,6 +35,12 @@
 typedef _Float16 nm_h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 nm_h2 __attribute__((ext_vector_type(2)));
 
+#ifndef NM_H2_DEPTH0
+#define NM_H2_DEPTH0 2   // layer-0 B-fragment prefetch distance of the tangent kernel (measured: 4 is slower, spills)
+#endif
+#ifndef NM_H2_EARLY_LOADS
+#define NM_H2_EARLY_LOADS 0  // record loads issued without waiting for the list entry (measured: no gain)
+#endif
 #define NM_H2_BIAS_LAYERS 4  // biases of the first 4 layers live in LDS (deeper layers read them from L2)
 #define NM_H2_FP16_MAX 65504.0f
 
@@ -184,12 +190,22 @@ __device__ __forceinline__ void nm_h2_embed_chunk(_Float16* blk, int dim, int ba
     _Pragma("unroll") for (int rt_ = 0; rt_ < (R1); ++rt_) _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_)  \
         c.lo[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[c_], A[rt_][1], c.lo[rt_][c_], 0, 0, 0);
 
-template <int KS, int CT, int KT0>
+#define NM_H2_PRE 4  // B-fragment sets a layer can receive pre-loaded (layer 0: all four, hidden layers: two)
+template <int CT>
+struct NmBPre {
+    NmBFrag<CT> s[NM_H2_PRE];
+};
+// DEPTH: how many k-steps ahead the B fragments are requested (DEPTH + 1 rotating register sets, the first
+// DEPTH arrive pre-loaded in `pre`).  Hidden layers: 2 (the accumulators leave no room for more).  Layer 0
+// of the tangent kernel: 4 -- its row-tile-1 accumulators are only initialised at k-step KT0, so until
+// then their 64 registers carry the deeper prefetch that the short (6-MFMA) k-steps need to cover the
+// L2 latency.
+template <int KS, int CT, int KT0, int DEPTH>
 __device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16* a1p, const nm_h8* const (&bp)[CT],
-                                            const NmBFrag<CT>& pre0, const NmBFrag<CT>& pre1, NmAccH<CT>& c) {
-    NmBFrag<CT> f[3];
-    f[0] = pre0;
-    f[1] = pre1;
+                                            const NmBPre<CT>& pre, NmAccH<CT>& c) {
+    NmBFrag<CT> f[DEPTH + 1];
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) f[i] = pre.s[i];
     nm_h8 a[2][2][2];  // [buffer][row tile][plane]
     a[0][0][0] = *reinterpret_cast<const nm_h8*>(a0p);
     a[0][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
@@ -200,7 +216,11 @@ __device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16*
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         __builtin_amdgcn_sched_barrier(0);
-        if (ks + 2 < KS) f[(ks + 2) % 3] = nm_ld_b<CT>(bp, ks + 2);
+        if (KT0 > 0 && ks == KT0) {  // row tile 1 joins here: its accumulators start their life now
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) c.hi[1][ct] = c.lo[1][ct] = nm_f32x16{0};
+        }
+        if (ks + DEPTH < KS) f[(ks + DEPTH) % (DEPTH + 1)] = nm_ld_b<CT>(bp, ks + DEPTH);
         if (ks + 1 < KS) {
             const int oa = (ks + 1) * 16;
             a[(ks + 1) & 1][0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
@@ -212,20 +232,30 @@ __device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16*
         }
         __builtin_amdgcn_sched_barrier(0);
         if (ks >= KT0) {
-            NM_H2_MFMAS(a[ks & 1], f[ks % 3], 2)
+            NM_H2_MFMAS(a[ks & 1], f[ks % (DEPTH + 1)], 2)
         } else {
-            NM_H2_MFMAS(a[ks & 1], f[ks % 3], 1)
+            NM_H2_MFMAS(a[ks & 1], f[ks % (DEPTH + 1)], 1)
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+}
+template <int CT>
+__device__ __forceinline__ void nm_prefetch_bn(const NmLayerH L, NmBPre<CT>& pre, int n) {
+    const int wave = threadIdx.x >> 6;
+    const nm_h8* bp[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) bp[c] = nm_b_base(L.W, L.Kpad, wave * CT + c);
+#pragma unroll
+    for (int i = 0; i < NM_H2_PRE; ++i)
+        if (i < n) pre.s[i] = nm_ld_b<CT>(bp, i);  // (every layer has >= 2 k-steps; layer 0 of any supported configuration >= 4)
 }
 
 // any other layer-0 width (run-time k-step counts): rolled loops, fragments one step ahead; k-steps
 // [0, kt0) without row tile 1, then [kt0, KS) with it
 template <int CT>
 __device__ __forceinline__ void nm_kloop_h2_generic(int KS, int kt0, const _Float16* a0p, const _Float16* a1p,
-                                                    const nm_h8* const (&bp)[CT], const NmBFrag<CT>& pre0, NmAccH<CT>& c) {
-    NmBFrag<CT> nf = pre0;
+                                                    const nm_h8* const (&bp)[CT], const NmBPre<CT>& pre, NmAccH<CT>& c) {
+    NmBFrag<CT> nf = pre.s[0];
     nm_h8 na[2][2];
     na[0][0] = *reinterpret_cast<const nm_h8*>(a0p);
     na[0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
@@ -269,9 +299,11 @@ __device__ __forceinline__ void nm_kloop_h2_generic(int KS, int kt0, const _Floa
 //   cst_b: this layer's bias in LDS ([256], or nullptr -> bias_g from global); head_w: LDS [NOUT][256].
 //   KSF / KT0F: compile-time k-step count of the layer and first k-step with non-zero row-tile-1 operands
 //   (non-zero only in layer 0 of the tangent kernel); KSF = 0: run-time counts (L.Kpad, kt0), rolled loops.
-template <int ACT, bool TANGENT, bool LAST, int NOUT, int CT, int KSF, int KT0F>
+//   DEPTH: B-fragment prefetch distance of this layer's K loop = number of sets `pre` holds on entry; on exit
+//   `pre` holds the first two sets of `next` (requested before the epilogue so that they arrive while it runs).
+template <int ACT, bool TANGENT, bool LAST, int NOUT, int CT, int KSF, int KT0F, int DEPTH>
 __device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L, const int kt0, const bool has_next, const NmLayerH next,
-                                                NmBFrag<CT>& pre0, NmBFrag<CT>& pre1, const float* cst_b, const float* head_w,
+                                                NmBPre<CT>& pre, const float* cst_b, const float* head_w,
                                                 float* red, float& mx, int stamp_slot) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, h = lane >> 5;
@@ -285,10 +317,11 @@ __device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) c.hi[rt][ct] = c.lo[rt][ct] = nm_f32x16{0};
-    if (KSF > 0) nm_kloop_h2<(KSF > 0 ? KSF : 1), CT, KT0F>(a0p, a1p, bp, pre0, pre1, c);  // one straight-line loop, no run-time dispatch
-    else nm_kloop_h2_generic<CT>(L.Kpad >> 4, kt0, a0p, a1p, bp, pre0, c);
-    if (has_next) nm_prefetch_b<CT>(next, pre0, pre1);
+        for (int ct = 0; ct < CT; ++ct)
+            if (rt == 0 || !(KSF > 0 && KT0F > 0)) c.hi[rt][ct] = c.lo[rt][ct] = nm_f32x16{0};  // (else: initialised at k-step KT0F)
+    if (KSF > 0) nm_kloop_h2<(KSF > 0 ? KSF : 1), CT, KT0F, DEPTH>(a0p, a1p, bp, pre, c);  // one straight-line loop, no run-time dispatch
+    else nm_kloop_h2_generic<CT>(L.Kpad >> 4, kt0, a0p, a1p, bp, pre, c);
+    if (has_next) nm_prefetch_bn<CT>(next, pre, 2);
     if (!LAST) __syncthreads();  // every wave has finished reading the input tile
     nm_phase_stamp(stamp_slot);
     const float sc = 1.0f / 2048.0f;
@@ -386,8 +419,9 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
     if (smap.order && smap.order[base] == 0xffffu) return;  // no point in this tile (valid entries lead each group)
     const NmDivBase rdiv = nm_div_base(base, rmap.stride ? rmap.P : 1), odiv = nm_div_base(base, P);
     nm_phase_stamp(0);
-    NmBFrag<NM_H_CT> pre0, pre1;
-    nm_prefetch_b<NM_H_CT>(prm.layer[0], pre0, pre1);  // in flight during the input phase
+    constexpr int DEPTH0 = (FIXED && NABLA) ? NM_H2_DEPTH0 : 2;  // layer-0 prefetch distance (nm_kloop_h2); the rolled loops use one set
+    NmBPre<NM_H_CT> pre;
+    nm_prefetch_bn<NM_H_CT>(prm.layer[0], pre, DEPTH0);  // in flight during the input phase
     const int gdim = FIXED ? 32 : prm.gdim, mfg = FIXED ? 2 : prm.multires_fg, md = FIXED ? 8 : prm.multires_d;
     const int FG = FIXED ? 160 : prm.fg_w, in_dim = FG + 2 * md + 1;
     const int Kpad0 = FIXED ? 192 : prm.layer[0].Kpad;
@@ -396,14 +430,18 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
     constexpr int ROUNDS = PTS * 8 / NM_H_THREADS;
     float in_ds[ROUNDS];
     float4 in_fg[ROUNDS][2];
-    // all global loads of the input phase first (both task rounds), then the constants, then the embedding work
+    bool in_ok[ROUNDS];
+    // all global loads of the input phase first (both task rounds), then the constants, then the embedding work.
+    // The record loads do not wait for the list entry that says whether the position holds a point (padding
+    // positions have allocated, unused records): one memory round trip instead of two dependent ones.
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
         const int task = threadIdx.x + rd * NM_H_THREADS;
         const int p = task >> 3, j = task & 7;
         in_ds[rd] = 0.f;
         in_fg[rd][0] = in_fg[rd][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (base + p < npts && nm_slot_valid(smap, base + p)) {
+        in_ok[rd] = base + p < npts && nm_slot_valid(smap, base + p);
+        if (NM_H2_EARLY_LOADS ? (base + p < npts) : in_ok[rd]) {
             const long long rq = nm_rec_index_local(rmap, rdiv, base, p);
             in_ds[rd] = ds[rq];
             if (j < nchunk) in_fg[rd][0] = *reinterpret_cast<const float4*>(fg_rec + rq * gdim + 4 * j);
@@ -423,7 +461,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
         const long long q = base + p;
         _Float16* vrow = tile + p * NM_H_STRIDE;
         _Float16* trow = tile + (32 + p) * NM_H_STRIDE;  // (NABLA only)
-        if (q >= npts || !nm_slot_valid(smap, q)) {
+        if (!in_ok[rd]) {
             nm_h2_zero_cols(vrow, 0, Kpad0, j);
             if (NABLA) nm_h2_zero_cols(trow, 16 * kt0, Kpad0, j);
             continue;
@@ -463,15 +501,15 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
     constexpr int KS0 = FIXED ? 12 : 0, KT0 = (FIXED && NABLA) ? 10 : 0;
     const float* head = cst + NM_H2_BIAS_LAYERS * NM_W;
     if (prm.D == 1) {
-        nm_mlp_layer_h2<0, NABLA, true, 1, NM_H_CT, KS0, KT0>(tile, prm.layer[0], kt0, false, prm.layer[0], pre0, pre1, cst, head, red, mx, 2);
+        nm_mlp_layer_h2<0, NABLA, true, 1, NM_H_CT, KS0, KT0, DEPTH0>(tile, prm.layer[0], kt0, false, prm.layer[0], pre, cst, head, red, mx, 2);
     } else {
-        nm_mlp_layer_h2<0, NABLA, false, 1, NM_H_CT, KS0, KT0>(tile, prm.layer[0], kt0, true, prm.layer[1], pre0, pre1, cst, nullptr, red, mx, 2);
+        nm_mlp_layer_h2<0, NABLA, false, 1, NM_H_CT, KS0, KT0, DEPTH0>(tile, prm.layer[0], kt0, true, prm.layer[1], pre, cst, nullptr, red, mx, 2);
         for (int l = 1; l + 1 < prm.D; ++l)
-            nm_mlp_layer_h2<0, NABLA, false, 1, NM_H_CT, 16, 0>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre0, pre1,
-                                                                 l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, nullptr, red, mx, 2 + 2 * l);
+            nm_mlp_layer_h2<0, NABLA, false, 1, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre,
+                                                                    l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, nullptr, red, mx, 2 + 2 * l);
         const int l = prm.D - 1;
-        nm_mlp_layer_h2<0, NABLA, true, 1, NM_H_CT, 16, 0>(tile, prm.layer[l], 0, false, prm.layer[l], pre0, pre1,
-                                                            l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, head, red, mx, 2 + 2 * l);
+        nm_mlp_layer_h2<0, NABLA, true, 1, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, false, prm.layer[l], pre,
+                                                               l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, head, red, mx, 2 + 2 * l);
     }
     if (threadIdx.x < PTS) {
         const int t = threadIdx.x;
@@ -512,8 +550,9 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
     const NmDivBase ddiv = nm_div_base(base, dir_div);
     const long long ray0 = smap.order ? (base / smap.E) * smap.G : 0;  // uniform: one division per workgroup
     nm_phase_stamp(0);
-    NmBFrag<NM_H_CT> pre0, pre1;
-    nm_prefetch_b<NM_H_CT>(prm.layer[0], pre0, pre1);  // in flight during the input phase
+    constexpr int DEPTH0 = 2;
+    NmBPre<NM_H_CT> pre;
+    nm_prefetch_bn<NM_H_CT>(prm.layer[0], pre, DEPTH0);  // in flight during the input phase
     const int cdim = FIXED ? 32 : prm.cdim, mft = FIXED ? 2 : prm.multires_ft, md = FIXED ? 8 : prm.multires_d;
     const int mv = FIXED ? 4 : prm.multires_view, use_nabla = FIXED ? 1 : prm.use_nabla;
     const int FT = FIXED ? 160 : prm.ft_w;
@@ -525,6 +564,8 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
     float in_ds[ROUNDS], in_x[ROUNDS];  // in_x: lane j < 3: view component j, 3 <= j < 6: nabla component j - 3
     float in_dv[ROUNDS][3];
     float4 in_ft[ROUNDS][2];
+    bool in_ok[ROUNDS];
+    // (record loads independent of the list entry, as in the geometry kernel; only the ray's direction needs it)
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
         const int task = threadIdx.x + rd * NM_H_THREADS;
@@ -533,8 +574,14 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
         in_ds[rd] = in_x[rd] = 0.f;
         in_dv[rd][0] = in_dv[rd][1] = in_dv[rd][2] = 0.f;
         in_ft[rd][0] = in_ft[rd][1] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < npts && nm_slot_valid(smap, q)) {
+        in_ok[rd] = q < npts && nm_slot_valid(smap, q);
+        if (NM_H2_EARLY_LOADS ? (q < npts) : in_ok[rd]) {
             in_ds[rd] = ds[q];
+            if (use_nabla && j >= 3 && j < 6) in_x[rd] = nabla[q * 3 + (j - 3)];
+            if (j < nchunk) in_ft[rd][0] = *reinterpret_cast<const float4*>(ft_rec + q * cdim + 4 * j);
+            if (j + 8 < nchunk) in_ft[rd][1] = *reinterpret_cast<const float4*>(ft_rec + q * cdim + 4 * (j + 8));
+        }
+        if (in_ok[rd]) {
             long long ray;
             int unused_p;
             if (smap.order) nm_slot_ray(smap, q, ray0, ray, unused_p);
@@ -542,9 +589,6 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
             in_dv[rd][0] = dirs[ray * 3 + 0];
             in_dv[rd][1] = dirs[ray * 3 + 1];
             in_dv[rd][2] = dirs[ray * 3 + 2];
-            if (use_nabla && j >= 3 && j < 6) in_x[rd] = nabla[q * 3 + (j - 3)];
-            if (j < nchunk) in_ft[rd][0] = *reinterpret_cast<const float4*>(ft_rec + q * cdim + 4 * j);
-            if (j + 8 < nchunk) in_ft[rd][1] = *reinterpret_cast<const float4*>(ft_rec + q * cdim + 4 * (j + 8));
         }
     }
     {
@@ -560,7 +604,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
         const int p = task >> 3, j = task & 7;
         const long long q = base + p;
         _Float16* vrow = tile + p * NM_H_STRIDE;
-        if (q >= npts || !nm_slot_valid(smap, q)) {
+        if (!in_ok[rd]) {
             nm_h2_zero_cols(vrow, 0, Kpad0, j);
             continue;
         }
@@ -593,15 +637,15 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
     constexpr int KS0 = FIXED ? 13 : 0;
     const float* head = cst + NM_H2_BIAS_LAYERS * NM_W;
     if (prm.D == 1) {
-        nm_mlp_layer_h2<1, false, true, 3, NM_H_CT, KS0, 0>(tile, prm.layer[0], 0, false, prm.layer[0], pre0, pre1, cst, head, red, mx, 2);
+        nm_mlp_layer_h2<1, false, true, 3, NM_H_CT, KS0, 0, 2>(tile, prm.layer[0], 0, false, prm.layer[0], pre, cst, head, red, mx, 2);
     } else {
-        nm_mlp_layer_h2<1, false, false, 3, NM_H_CT, KS0, 0>(tile, prm.layer[0], 0, true, prm.layer[1], pre0, pre1, cst, nullptr, red, mx, 2);
+        nm_mlp_layer_h2<1, false, false, 3, NM_H_CT, KS0, 0, 2>(tile, prm.layer[0], 0, true, prm.layer[1], pre, cst, nullptr, red, mx, 2);
         for (int l = 1; l + 1 < prm.D; ++l)
-            nm_mlp_layer_h2<1, false, false, 3, NM_H_CT, 16, 0>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre0, pre1,
-                                                                 l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, nullptr, red, mx, 2 + 2 * l);
+            nm_mlp_layer_h2<1, false, false, 3, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre,
+                                                                    l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, nullptr, red, mx, 2 + 2 * l);
         const int l = prm.D - 1;
-        nm_mlp_layer_h2<1, false, true, 3, NM_H_CT, 16, 0>(tile, prm.layer[l], 0, false, prm.layer[l], pre0, pre1,
-                                                            l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, head, red, mx, 2 + 2 * l);
+        nm_mlp_layer_h2<1, false, true, 3, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, false, prm.layer[l], pre,
+                                                               l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, head, red, mx, 2 + 2 * l);
     }
     if (threadIdx.x < NM_ROWS) {  // one thread per point: its three channels are one 12-byte store
         const int p = threadIdx.x;

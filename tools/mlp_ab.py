@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 stamps = "--stamps" in sys.argv
-if stamps:
+if stamps and "NEUMESH_HIP_LIB" not in os.environ:   # (a pre-built variant may be given through NEUMESH_HIP_LIB)
     from neumesh_amd import build as nb
     out = os.path.join(ROOT, "tools", "_build", "libneumesh_hip_stamps.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
