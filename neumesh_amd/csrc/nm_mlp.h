@@ -140,14 +140,16 @@ struct NmColParams {
 // evaluates this 16 K times per workgroup, so its cost is what decides whether the kernel is
 // MFMA-bound.
 __device__ __forceinline__ float nm_softplus100(float x, float* grad) {
-    // branch-free: z = e^min(100x, 21), y = log(1 + z) / 100.  For small z the rounding of 1 + z costs
-    // <= 6e-8 ABSOLUTE in log(1 + z), i.e. <= 6e-10 in y -- below the fp32 spacing of the O(0.01..1)
-    // values the next layer sums (tests/test_hostlogic.py::test_fast_softplus_formula).
+    // branch- and select-free: z = e^min(100x, 21), y = max(x, log(1 + z) / 100), g = z / (1 + z).
+    // Above torch's threshold (100x > 20, where it returns x and 1) the clamp makes log(1 + z)/100 <= 0.21 and
+    // y = x from x = 0.21 on; in (0.2, 0.21] log(1 + z)/100 = x + e^-100x/100 = x to 2e-11, and g = 1 - 2e-9 (1.0f
+    // or its fp32 neighbour).  For small z the rounding of 1 + z costs <= 6e-8 ABSOLUTE in log(1 + z), i.e.
+    // <= 6e-10 in y -- below the fp32 spacing of the O(0.01..1) values the next layer sums
+    // (tests/test_hostlogic.py::test_fast_softplus_formula).
     const float z = __builtin_amdgcn_exp2f(fminf(x * 144.269504f, 30.2965958f));
     const float u = 1.0f + z;
-    const bool lin = x > 0.2f;  // torch: x*beta > threshold returns x (there log(1+z)/100 == x to 1 ulp)
-    if (grad) *grad = lin ? 1.0f : z * __builtin_amdgcn_rcpf(u);
-    return lin ? x : __builtin_amdgcn_logf(u) * 0.0069314718f;
+    if (grad) *grad = z * __builtin_amdgcn_rcpf(u);
+    return fmaxf(x, __builtin_amdgcn_logf(u) * 0.0069314718f);
 }
 
 // One dense layer on the LDS tile: act[64][K] -> act[64][256] (in place).

@@ -36,7 +36,7 @@ typedef _Float16 nm_h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 nm_h2 __attribute__((ext_vector_type(2)));
 
 #ifndef NM_H2_DEPTH0
-#define NM_H2_DEPTH0 2   // layer-0 B-fragment prefetch distance of the tangent kernel (measured: 4 is slower, spills)
+#define NM_H2_DEPTH0 2   // layer-0 B-fragment prefetch distance of the tangent kernel (<= NM_H2_PRE)
 #endif
 #ifndef NM_H2_EARLY_LOADS
 #define NM_H2_EARLY_LOADS 0  // record loads issued without waiting for the list entry (measured: no gain)
@@ -94,18 +94,24 @@ struct NmColParamsH2 {
 };
 
 // ------------------------------------------------------------------------- split + store helpers
-// (mx: running max of |value| for the fp16-range check)
+// a -> (h1, h2), a ~= h1 + h2 / 2048 as nm_split_half, with the residual formed by ONE mixed-precision fma
+// on the f16 value: (a - h1) * 2048 == fma(h1, -2048, a * 2048) exactly (every term is exact in fp32).
+__device__ __forceinline__ void nm_h2_split(float a, _Float16& h1, _Float16& h2) {
+    h1 = (_Float16)a;
+    h2 = (_Float16)fmaf((float)h1, -2048.0f, a * 2048.0f);
+}
+// (mx: running max of |value| for the fp16-range check; pairs go through one max3)
 __device__ __forceinline__ void nm_h2_store1(_Float16* p, float a, float& mx) {
     _Float16 h1, h2;
-    nm_split_half(a, &h1, &h2);
+    nm_h2_split(a, h1, h2);
     p[0] = h1;
     p[NM_H_PLANE] = h2;
     mx = fmaxf(mx, fabsf(a));
 }
 __device__ __forceinline__ void nm_h2_store2(_Float16* p, float a, float b, float& mx) {  // p 4-byte aligned
     _Float16 a1, a2, b1, b2;
-    nm_split_half(a, &a1, &a2);
-    nm_split_half(b, &b1, &b2);
+    nm_h2_split(a, a1, a2);
+    nm_h2_split(b, b1, b2);
     *reinterpret_cast<nm_h2*>(p) = nm_h2{a1, b1};
     *reinterpret_cast<nm_h2*>(p + NM_H_PLANE) = nm_h2{a2, b2};
     mx = fmaxf(mx, fmaxf(fabsf(a), fabsf(b)));
@@ -115,11 +121,12 @@ __device__ __forceinline__ void nm_h2_store4(_Float16* p, const float (&v)[4], f
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         _Float16 h1, h2;
-        nm_split_half(v[e], &h1, &h2);
+        nm_h2_split(v[e], h1, h2);
         a[e] = h1;
         b[e] = h2;
-        mx = fmaxf(mx, fabsf(v[e]));
     }
+    mx = fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1])));
+    mx = fmaxf(mx, fmaxf(fabsf(v[2]), fabsf(v[3])));
     *reinterpret_cast<nm_h4*>(p) = a;
     *reinterpret_cast<nm_h4*>(p + NM_H_PLANE) = b;
 }
@@ -128,11 +135,12 @@ __device__ __forceinline__ void nm_h2_store8(_Float16* p, const float (&v)[8], f
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         _Float16 h1, h2;
-        nm_split_half(v[e], &h1, &h2);
+        nm_h2_split(v[e], h1, h2);
         a[e] = h1;
         b[e] = h2;
-        mx = fmaxf(mx, fabsf(v[e]));
     }
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) mx = fmaxf(fmaxf(mx, fabsf(v[e])), fabsf(v[e + 1]));
     *reinterpret_cast<nm_h8*>(p) = a;
     *reinterpret_cast<nm_h8*>(p + NM_H_PLANE) = b;
 }
@@ -190,18 +198,36 @@ __device__ __forceinline__ void nm_h2_embed_chunk(_Float16* blk, int dim, int ba
     _Pragma("unroll") for (int rt_ = 0; rt_ < (R1); ++rt_) _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_)  \
         c.lo[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[c_], A[rt_][1], c.lo[rt_][c_], 0, 0, 0);
 
-#define NM_H2_PRE 4  // B-fragment sets a layer can receive pre-loaded (layer 0: all four, hidden layers: two)
+// B (weight) fragments are fetched with raw buffer loads: the (layer, column tile) block is a buffer
+// resource in 4 SGPRs, the lane contributes a constant 32-bit byte offset (lane * 16) and the k-step /
+// plane an immediate or scalar offset.  No per-k-step 64-bit VGPR addresses exist, so the unrolled K
+// loops cannot spill them (global_load forms did: scratch stores between the loads of layer 0, which the
+// in-order vmcnt waits of the loop then had to sit out).
+typedef __amdgpu_buffer_rsrc_t nm_rsrc;
+__device__ __forceinline__ nm_rsrc nm_b_rsrc(const _Float16* W, int Kpad, int ctile_uniform) {
+    const _Float16* p = W + (size_t)ctile_uniform * (Kpad >> 4) * 2 * 64 * 8;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (Kpad >> 4) * 2048, 0x00020000);
+}
+template <int CT>
+__device__ __forceinline__ NmBFrag<CT> nm_ld_bu(const nm_rsrc (&ub)[CT], int lane, int ks) {
+    NmBFrag<CT> f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        f.a[c] = __builtin_bit_cast(nm_h8, __builtin_amdgcn_raw_buffer_load_b128(ub[c], lane * 16, ks * 2048, 0));
+        f.b[c] = __builtin_bit_cast(nm_h8, __builtin_amdgcn_raw_buffer_load_b128(ub[c], lane * 16, ks * 2048 + 1024, 0));
+    }
+    return f;
+}
+#define NM_H2_PRE 2  // B-fragment sets a layer receives pre-loaded (= the prefetch distance of the K loops)
 template <int CT>
 struct NmBPre {
     NmBFrag<CT> s[NM_H2_PRE];
 };
 // DEPTH: how many k-steps ahead the B fragments are requested (DEPTH + 1 rotating register sets, the first
-// DEPTH arrive pre-loaded in `pre`).  Hidden layers: 2 (the accumulators leave no room for more).  Layer 0
-// of the tangent kernel: 4 -- its row-tile-1 accumulators are only initialised at k-step KT0, so until
-// then their 64 registers carry the deeper prefetch that the short (6-MFMA) k-steps need to cover the
-// L2 latency.
+// DEPTH arrive pre-loaded in `pre`): 2 everywhere.  (A distance of 4 in layer 0 of the tangent kernel, whose
+// row-tile-1 accumulators only start their life at k-step KT0, was measured slower.)
 template <int KS, int CT, int KT0, int DEPTH>
-__device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16* a1p, const nm_h8* const (&bp)[CT],
+__device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16* a1p, const nm_rsrc (&bp)[CT], const int lane,
                                             const NmBPre<CT>& pre, NmAccH<CT>& c) {
     NmBFrag<CT> f[DEPTH + 1];
 #pragma unroll
@@ -220,7 +246,7 @@ __device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16*
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) c.hi[1][ct] = c.lo[1][ct] = nm_f32x16{0};
         }
-        if (ks + DEPTH < KS) f[(ks + DEPTH) % (DEPTH + 1)] = nm_ld_b<CT>(bp, ks + DEPTH);
+        if (ks + DEPTH < KS) f[(ks + DEPTH) % (DEPTH + 1)] = nm_ld_bu<CT>(bp, lane, ks + DEPTH);
         if (ks + 1 < KS) {
             const int oa = (ks + 1) * 16;
             a[(ks + 1) & 1][0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
@@ -241,20 +267,20 @@ __device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16*
 }
 template <int CT>
 __device__ __forceinline__ void nm_prefetch_bn(const NmLayerH L, NmBPre<CT>& pre, int n) {
-    const int wave = threadIdx.x >> 6;
-    const nm_h8* bp[CT];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    nm_rsrc bp[CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) bp[c] = nm_b_base(L.W, L.Kpad, wave * CT + c);
+    for (int c = 0; c < CT; ++c) bp[c] = nm_b_rsrc(L.W, L.Kpad, wave * CT + c);
 #pragma unroll
     for (int i = 0; i < NM_H2_PRE; ++i)
-        if (i < n) pre.s[i] = nm_ld_b<CT>(bp, i);  // (every layer has >= 2 k-steps; layer 0 of any supported configuration >= 4)
+        if (i < n) pre.s[i] = nm_ld_bu<CT>(bp, lane, i);  // (every layer has >= 2 k-steps; layer 0 of any supported configuration >= 4)
 }
 
 // any other layer-0 width (run-time k-step counts): rolled loops, fragments one step ahead; k-steps
 // [0, kt0) without row tile 1, then [kt0, KS) with it
 template <int CT>
 __device__ __forceinline__ void nm_kloop_h2_generic(int KS, int kt0, const _Float16* a0p, const _Float16* a1p,
-                                                    const nm_h8* const (&bp)[CT], const NmBPre<CT>& pre, NmAccH<CT>& c) {
+                                                    const nm_rsrc (&bp)[CT], const int lane, const NmBPre<CT>& pre, NmAccH<CT>& c) {
     NmBFrag<CT> nf = pre.s[0];
     nm_h8 na[2][2];
     na[0][0] = *reinterpret_cast<const nm_h8*>(a0p);
@@ -267,7 +293,7 @@ __device__ __forceinline__ void nm_kloop_h2_generic(int KS, int kt0, const _Floa
         nm_h8 A[2][2];
         A[0][0] = na[0][0]; A[0][1] = na[0][1]; A[1][0] = na[1][0]; A[1][1] = na[1][1];
         if (ks + 1 < KS) {
-            nf = nm_ld_b<CT>(bp, ks + 1);
+            nf = nm_ld_bu<CT>(bp, lane, ks + 1);
             const int oa = (ks + 1) * 16;
             na[0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
             na[0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
@@ -281,7 +307,7 @@ __device__ __forceinline__ void nm_kloop_h2_generic(int KS, int kt0, const _Floa
         nm_h8 A[2][2];
         A[0][0] = na[0][0]; A[0][1] = na[0][1]; A[1][0] = na[1][0]; A[1][1] = na[1][1];
         if (ks + 1 < KS) {
-            nf = nm_ld_b<CT>(bp, ks + 1);
+            nf = nm_ld_bu<CT>(bp, lane, ks + 1);
             const int oa = (ks + 1) * 16;
             na[0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
             na[0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
@@ -296,31 +322,32 @@ __device__ __forceinline__ void nm_kloop_h2_generic(int KS, int kt0, const _Floa
 // One dense layer on the split-half LDS tile.  Not the last hidden layer: activations go back into the
 // tile (in place).  LAST: the NOUT-wide head (density / rgb) is applied to the fp32 activations in
 // registers and the per-row sums land in red[wave][row][NOUT]; the tile is not written.
-//   cst_b: this layer's bias in LDS ([256], or nullptr -> bias_g from global); head_w: LDS [NOUT][256].
+//   cst / bias_row: this layer's bias = LDS row cst[bias_row][256], or bias_row < 0 -> L.b from global;
+//   head_w: LDS [NOUT][256].
 //   KSF / KT0F: compile-time k-step count of the layer and first k-step with non-zero row-tile-1 operands
 //   (non-zero only in layer 0 of the tangent kernel); KSF = 0: run-time counts (L.Kpad, kt0), rolled loops.
 //   DEPTH: B-fragment prefetch distance of this layer's K loop = number of sets `pre` holds on entry; on exit
 //   `pre` holds the first two sets of `next` (requested before the epilogue so that they arrive while it runs).
 template <int ACT, bool TANGENT, bool LAST, int NOUT, int CT, int KSF, int KT0F, int DEPTH>
 __device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L, const int kt0, const bool has_next, const NmLayerH next,
-                                                NmBPre<CT>& pre, const float* cst_b, const float* head_w,
+                                                NmBPre<CT>& pre, const float* cst, const int bias_row, const float* head_w,
                                                 float* red, float& mx, int stamp_slot) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, h = lane >> 5;
     const int n0 = wave * 32 * CT;
     const _Float16* a0p = tile + li * NM_H_STRIDE + 8 * h;
     const _Float16* a1p = tile + (32 + li) * NM_H_STRIDE + 8 * h;
-    const nm_h8* bp[CT];
+    nm_rsrc bp[CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) bp[c] = nm_b_base(L.W, L.Kpad, wave * CT + c);
+    for (int c = 0; c < CT; ++c) bp[c] = nm_b_rsrc(L.W, L.Kpad, wave * CT + c);
     NmAccH<CT> c;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
             if (rt == 0 || !(KSF > 0 && KT0F > 0)) c.hi[rt][ct] = c.lo[rt][ct] = nm_f32x16{0};  // (else: initialised at k-step KT0F)
-    if (KSF > 0) nm_kloop_h2<(KSF > 0 ? KSF : 1), CT, KT0F, DEPTH>(a0p, a1p, bp, pre, c);  // one straight-line loop, no run-time dispatch
-    else nm_kloop_h2_generic<CT>(L.Kpad >> 4, kt0, a0p, a1p, bp, pre, c);
+    if (KSF > 0) nm_kloop_h2<(KSF > 0 ? KSF : 1), CT, KT0F, DEPTH>(a0p, a1p, bp, lane, pre, c);  // one straight-line loop, no run-time dispatch
+    else nm_kloop_h2_generic<CT>(L.Kpad >> 4, kt0, a0p, a1p, bp, lane, pre, c);
     if (has_next) nm_prefetch_bn<CT>(next, pre, 2);
     if (!LAST) __syncthreads();  // every wave has finished reading the input tile
     nm_phase_stamp(stamp_slot);
@@ -333,8 +360,15 @@ __device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {  // 8 columns at a time: one 16-byte store per row and plane, short live ranges
             const int col0 = n0 + 32 * ct + 16 * h + 8 * hf;  // this lane's columns: register 8*hf + r <-> column col0 + r
-            const float* bsrc = (cst_b ? cst_b : L.b) + col0;
-            const float4 b0 = *reinterpret_cast<const float4*>(bsrc), b1 = *reinterpret_cast<const float4*>(bsrc + 4);
+            float4 b0, b1;  // (two address spaces: LDS for the first layers, global beyond -- never a generic pointer)
+            if (bias_row >= 0) {
+                b0 = *reinterpret_cast<const float4*>(cst + bias_row * NM_W + col0);
+                b1 = *reinterpret_cast<const float4*>(cst + bias_row * NM_W + col0 + 4);
+            } else {  // (buffer loads: a different instruction class, so the two paths are never merged into flat loads)
+                const nm_rsrc rb = __builtin_amdgcn_make_buffer_rsrc((void*)L.b, 0, NM_W * 4, 0x00020000);
+                b0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, col0 * 4, 0, 0));
+                b1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, col0 * 4 + 16, 0, 0));
+            }
             const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             float y0[8], y1[8];
 #pragma unroll
@@ -501,15 +535,15 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
     constexpr int KS0 = FIXED ? 12 : 0, KT0 = (FIXED && NABLA) ? 10 : 0;
     const float* head = cst + NM_H2_BIAS_LAYERS * NM_W;
     if (prm.D == 1) {
-        nm_mlp_layer_h2<0, NABLA, true, 1, NM_H_CT, KS0, KT0, DEPTH0>(tile, prm.layer[0], kt0, false, prm.layer[0], pre, cst, head, red, mx, 2);
+        nm_mlp_layer_h2<0, NABLA, true, 1, NM_H_CT, KS0, KT0, DEPTH0>(tile, prm.layer[0], kt0, false, prm.layer[0], pre, cst, 0, head, red, mx, 2);
     } else {
-        nm_mlp_layer_h2<0, NABLA, false, 1, NM_H_CT, KS0, KT0, DEPTH0>(tile, prm.layer[0], kt0, true, prm.layer[1], pre, cst, nullptr, red, mx, 2);
+        nm_mlp_layer_h2<0, NABLA, false, 1, NM_H_CT, KS0, KT0, DEPTH0>(tile, prm.layer[0], kt0, true, prm.layer[1], pre, cst, 0, nullptr, red, mx, 2);
         for (int l = 1; l + 1 < prm.D; ++l)
             nm_mlp_layer_h2<0, NABLA, false, 1, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre,
-                                                                    l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, nullptr, red, mx, 2 + 2 * l);
+                                                                    cst, l < NM_H2_BIAS_LAYERS ? l : -1, nullptr, red, mx, 2 + 2 * l);
         const int l = prm.D - 1;
         nm_mlp_layer_h2<0, NABLA, true, 1, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, false, prm.layer[l], pre,
-                                                               l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, head, red, mx, 2 + 2 * l);
+                                                               cst, l < NM_H2_BIAS_LAYERS ? l : -1, head, red, mx, 2 + 2 * l);
     }
     if (threadIdx.x < PTS) {
         const int t = threadIdx.x;
@@ -637,15 +671,15 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
     constexpr int KS0 = FIXED ? 13 : 0;
     const float* head = cst + NM_H2_BIAS_LAYERS * NM_W;
     if (prm.D == 1) {
-        nm_mlp_layer_h2<1, false, true, 3, NM_H_CT, KS0, 0, 2>(tile, prm.layer[0], 0, false, prm.layer[0], pre, cst, head, red, mx, 2);
+        nm_mlp_layer_h2<1, false, true, 3, NM_H_CT, KS0, 0, 2>(tile, prm.layer[0], 0, false, prm.layer[0], pre, cst, 0, head, red, mx, 2);
     } else {
-        nm_mlp_layer_h2<1, false, false, 3, NM_H_CT, KS0, 0, 2>(tile, prm.layer[0], 0, true, prm.layer[1], pre, cst, nullptr, red, mx, 2);
+        nm_mlp_layer_h2<1, false, false, 3, NM_H_CT, KS0, 0, 2>(tile, prm.layer[0], 0, true, prm.layer[1], pre, cst, 0, nullptr, red, mx, 2);
         for (int l = 1; l + 1 < prm.D; ++l)
             nm_mlp_layer_h2<1, false, false, 3, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre,
-                                                                    l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, nullptr, red, mx, 2 + 2 * l);
+                                                                    cst, l < NM_H2_BIAS_LAYERS ? l : -1, nullptr, red, mx, 2 + 2 * l);
         const int l = prm.D - 1;
         nm_mlp_layer_h2<1, false, true, 3, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, false, prm.layer[l], pre,
-                                                               l < NM_H2_BIAS_LAYERS ? cst + l * NM_W : nullptr, head, red, mx, 2 + 2 * l);
+                                                               cst, l < NM_H2_BIAS_LAYERS ? l : -1, head, red, mx, 2 + 2 * l);
     }
     if (threadIdx.x < NM_ROWS) {  // one thread per point: its three channels are one 12-byte store
         const int p = threadIdx.x;

@@ -158,9 +158,8 @@ def test_fast_softplus_formula():
     f = np.float32
     z = np.exp2(np.minimum(x * f(144.269504), f(30.2965958))).astype(np.float32)
     u = f(1) + z
-    lin = x > f(0.2)
-    y = np.where(lin, x, np.log2(u).astype(np.float32) * f(0.0069314718)).astype(np.float32)
-    g = np.where(lin, f(1), z / u).astype(np.float32)
+    y = np.maximum(x, np.log2(u).astype(np.float32) * f(0.0069314718)).astype(np.float32)
+    g = (z / u).astype(np.float32)
     xd = x.astype(np.float64)
     with np.errstate(over="ignore"):
         yt = np.where(xd * 100 > 20, xd, np.log1p(np.exp(xd * 100)) / 100)
