@@ -5,8 +5,11 @@
 ``get_model(args)`` reads the same config keys, injects the same defaults with ``setdefault`` and
 returns the same 5-tuple ``(model, trainer, render_kwargs_train, render_kwargs_test, renderer)``
 so render.py's ``model, trainer, render_kwargs_train, render_kwargs_test, render_fn =
-build_framework(args, args.model.framework)`` (render.py:272-278) works unchanged.  ``trainer`` is
-None: the training loop (models/trainer.py) is outside the hot path.
+build_framework(args, args.model.framework)`` (render.py:272-278) and train.py's
+``trainer.forward(args, indices, model_input, ground_truth, render_kwargs_train, it)`` (train.py:176)
+work unchanged.  ``trainer`` is ``neumesh_amd.trainer.Trainer`` (same interface as models/trainer.py).
+A NeuS teacher for the distillation losses (training.teacher_ckpt / teacher_config) is a different
+framework of the reference and is built by the reference's own factory when that tree is importable.
 """
 from __future__ import annotations
 
@@ -16,6 +19,7 @@ from .mesh_grid import MeshGrid
 from .neumesh import NeuMesh
 from .ply import read_ply
 from .renderer import SingleRenderer
+from .trainer import Trainer
 
 
 def _read_mesh(path_or_mesh):
@@ -67,7 +71,32 @@ def get_model(args):
     render_kwargs_test["perturb"] = False
     model = NeuMesh(mesh_grid, **model_config)
     renderer = SingleRenderer(model)
-    return model, None, render_kwargs_train, render_kwargs_test, renderer
+    teacher_model = _load_teacher(training, model)
+    trainer = Trainer(model, loss_weights=lw, teacher_model=teacher_model, device_ids=args["device_ids"])
+    return model, trainer, render_kwargs_train, render_kwargs_test, renderer
+
+
+def _load_teacher(training, model):
+    """neumesh/__init__.py:73-89: the distillation teacher (a NeuS model of the reference) is built by the
+    reference's own ``build_framework`` and its s-parameter shared with the student.  Only possible where the
+    reference tree is importable (a drop-in deployment inside it); elsewhere a configured teacher is an error."""
+    ckpt, cfg = training.get("teacher_ckpt"), training.get("teacher_config")
+    if ckpt is None or cfg is None:
+        return None
+    try:
+        import torch
+        from models.frameworks import build_framework as ref_build   # reference tree
+        from utils.io_util import load_yaml                           # reference tree
+    except ImportError as e:
+        raise NotImplementedError(
+            "training.teacher_ckpt / teacher_config name a NeuS teacher: that framework lives in the reference tree "
+            "(models/frameworks/neus), which is not importable here") from e
+    teacher_config = load_yaml(cfg)
+    teacher_model = ref_build(teacher_config, teacher_config.model.framework)[0]
+    teacher_model.load_state_dict(torch.load(ckpt)["model"])
+    model.ln_s = teacher_model.ln_s
+    model.speed_factor = teacher_model.speed_factor
+    return teacher_model
 
 
 def build_framework(args, framework):

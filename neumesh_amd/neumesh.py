@@ -73,6 +73,49 @@ def _mlp(in_dim: int, width: int, depth: int, act, wn: bool) -> nn.Sequential:
     return nn.Sequential(*mods)
 
 
+class _FusedField(autograd.Function):
+    """Training-side form of the field queries: the FORWARD values come from the fused HIP
+    kernels -- sdf, and nabla = d sdf / d xyz through the kernel's closed-form forward-mode tangent instead of
+    an autograd.grad pass (neumesh.py:225-232 in the reference) -- and no graph of the ~60 torch ops per query
+    is kept.  BACKWARD re-evaluates the same query with the torch-op restatement (`NeuMesh._forward_density` /
+    `_forward_color`, K-NN again from the HIP kernel) under autograd and differentiates that: first derivatives
+    of sdf / rgb and, for a cotangent on nabla (the eikonal loss), the second derivative of the nabla graph.
+    Costs one extra forward per backward (as activation checkpointing does); saves the activation memory."""
+
+    @staticmethod
+    def forward(ctx, model, mode, xyz, view_dirs, *params):
+        with torch.no_grad():
+            if mode == "density":
+                out = (model._fused_density(xyz, False)[0],)
+            elif mode == "density_nabla":
+                out = model._fused_density(xyz, True)
+            else:   # "forward": sdf, rgb
+                out = model._fused_forward(xyz, view_dirs, False)[:2]
+        ctx.model, ctx.mode = model, mode
+        ctx.save_for_backward(xyz, view_dirs if view_dirs is not None else xyz.new_zeros(0))
+        ctx.n_params = len(params)
+        return out if len(out) > 1 else out[0]
+
+    @staticmethod
+    def backward(ctx, *cotangents):
+        model, mode = ctx.model, ctx.mode
+        xyz, view_dirs = ctx.saved_tensors
+        params = model._trainable()
+        with torch.enable_grad():
+            x = xyz.detach().requires_grad_(True)
+            if mode == "density":
+                outs = (model._density_autograd(x, False)[0],)
+            elif mode == "density_nabla":
+                outs = model._density_autograd(x, True)[:2]
+            else:
+                outs = model._forward_autograd(x, view_dirs.detach(), True, False, False)[:2]
+            pairs = [(o, g) for o, g in zip(outs, cotangents) if g is not None and o.requires_grad]
+            grads = autograd.grad([o for o, _ in pairs], [x] + params, [g for _, g in pairs], allow_unused=True) if pairs else \
+                [None] * (1 + len(params))
+        gx = grads[0] if ctx.needs_input_grad[2] else None
+        return (None, None, gx, None, *grads[1:])
+
+
 class NeuMesh(nn.Module):
     def __init__(self, mesh_grid, D_density: int, D_color: int, W: int, geometry_dim: int, color_dim: int,
                  multires_view: int, multires_d: int, multires_fg: int, multires_ft: int,
@@ -115,6 +158,9 @@ class NeuMesh(nn.Module):
         self._field_dev = None
         self._field_epoch = 0     # bumped by invalidate_field()
         self._range_checked = False
+        # With autograd enabled: False (default) = the torch-op restatement end to end; True = fused HIP forward
+        # + recomputing backward (_FusedField): same gradients, no activation graph kept.
+        self.fused_autograd = os.environ.get("NEUMESH_FUSED_AUTOGRAD", "0") == "1"
         self._keep = None         # tensors whose pointers the last FieldDesc referenced
 
     # ------------------------------------------------------------------ scalars
@@ -300,18 +346,17 @@ class NeuMesh(nn.Module):
         """neumesh.py:140-145."""
         if not torch.is_grad_enabled():
             return self._fused_density(xyz, False)[0]
-        ds, indices, weights = self.compute_distance(xyz)
-        return self._forward_density(xyz, ds, self.geometry_features, indices, weights, need_nablas=False)[0]
+        if self.fused_autograd:
+            return _FusedField.apply(self, "density", xyz, None, *self._trainable())
+        return self._density_autograd(xyz, False)[0]
 
     def forward_with_nablas(self, xyz):
         """neumesh.py:147-154."""
         if not torch.is_grad_enabled():
             return self._fused_density(xyz, True)
-        xyz.requires_grad_(True)
-        with torch.enable_grad():
-            ds, indices, weights = self.compute_distance(xyz)
-        density, nablas, _ = self._forward_density(xyz, ds, self.geometry_features, indices, weights, need_nablas=True)
-        return density, nablas
+        if self.fused_autograd:
+            return _FusedField.apply(self, "density_nabla", xyz, None, *self._trainable())
+        return self._density_autograd(xyz, True)[:2]
 
     def forward(self, xyz, view_dirs, need_nablas=True, nablas_only=False, return_ds=False):
         """neumesh.py:113-138."""
@@ -319,6 +364,24 @@ class NeuMesh(nn.Module):
             sdf, rgb, nab, *rest = self._fused_forward(xyz, view_dirs, return_ds)
             out = (sdf, nab) if nablas_only else (sdf, rgb)
             return out + tuple(rest)
+        if self.fused_autograd and torch.is_grad_enabled() and need_nablas and not nablas_only and not return_ds:
+            return _FusedField.apply(self, "forward", xyz, view_dirs.expand_as(xyz), *self._trainable())
+        return self._forward_autograd(xyz, view_dirs, need_nablas, nablas_only, return_ds)
+
+    # ------------------------------------------------------------------ torch-op (autograd) forms of the queries
+    def _trainable(self):
+        return [p for p in self.parameters() if p.requires_grad]
+
+    def _density_autograd(self, xyz, need_nablas):
+        """forward_density_only / forward_with_nablas with autograd (neumesh.py:140-154)."""
+        if need_nablas:
+            xyz.requires_grad_(True)
+        with (torch.enable_grad() if need_nablas else contextlib.nullcontext()):
+            ds, indices, weights = self.compute_distance(xyz)
+        return self._forward_density(xyz, ds, self.geometry_features, indices, weights, need_nablas=need_nablas)
+
+    def _forward_autograd(self, xyz, view_dirs, need_nablas, nablas_only, return_ds):
+        """NeuMesh.forward with autograd (neumesh.py:113-138, 176-202)."""
         if need_nablas:
             xyz.requires_grad_(True)
         with (torch.enable_grad() if need_nablas else contextlib.nullcontext()):

@@ -222,7 +222,8 @@ class _RestoreGradMode:
 
 
 def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int, netchunk: int, detailed: bool = False,
-                       progress=None, differentiable: bool = False, perturb: bool = False, trace=None):
+                       progress=None, differentiable: bool = False, perturb: bool = False, trace=None,
+                       samples_output: bool = False, random_color_direction: bool = False):
     """render_rayschunk (models/renderer.py:162-350) for ANY object that offers the field methods the
     reference's renderer calls -- compute_distance / forward_density_only / forward_with_nablas /
     forward / forward_s -- e.g. the editing tools' TextureEditableNeuMesh wrapper
@@ -235,6 +236,11 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
     the final points WITH autograd and alpha / weights / compositing are torch ops (renderer.py:264-333),
     so gradients reach every model parameter.  perturb=True draws the importance samples with
     sample_pdf(det=False) (torch.rand handed to nm_rays_upsample).
+
+    samples_output (renderer.py:198,291-293,343-347): with `detailed`, the mid-points, their view directions, SDF
+    and radiance are returned as "xyz" / "dirs" / "density" / "colors" (the distillation losses of
+    models/trainer.py:211-221 read them).  random_color_direction (renderer.py:279-289): the colour branch is
+    queried with random unit directions (torch.rand_like, normalised) instead of the rays' own.
 
     trace (diagnostics): a dict that receives, per ray chunk, the stage outputs a diverging ray can be
     followed through -- "near_far" [R,2], "sdf_coarse" [R,Ns], "d_iter" (list: sorted depths after each
@@ -309,7 +315,7 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
             _lib.check(lib.nm_rays_points(_lib.ptr(ro), _lib.ptr(dirn), R, N, 1, None, _lib.ptr(d), N, 0, None, _lib.ptr(pts), st), "nm_rays_points")
             torch.set_grad_enabled(grad_was)
             if differentiable:
-                chunks.append(_composite_autograd(model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf))
+                chunks.append(_composite_autograd(model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf, samples_output, random_color_direction))
                 continue
             nablas = None
             if cfg.calc_normal:
@@ -320,8 +326,8 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
             sdf = s_all.reshape(R, N).float().contiguous()
             pm = torch.empty((R, N - 1, 3), **f32)
             _lib.check(lib.nm_rays_points(_lib.ptr(ro), _lib.ptr(dirn), R, N - 1, 1, None, _lib.ptr(dmid), N, 0, None, _lib.ptr(pm), st), "nm_rays_points")
-            view = dirn[:, None, :].expand(R, N - 1, 3).contiguous()
-            _, radiance = query(lambda x, v: model.forward(x, v)[:2], pm, view)
+            view = _mid_directions(dirn, pm, random_color_direction)
+            sdf_mid, radiance = query(lambda x, v: model.forward(x, v)[:2], pm, view)
             radiance = radiance.float().contiguous()
             rgb, depth, acc = torch.empty((R, 3), **f32), torch.empty((R,), **f32), torch.empty((R,), **f32)
             normals = torch.empty((R, 3), **f32) if cfg.calc_normal else None
@@ -337,11 +343,23 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
                     ret["implicit_nablas"] = nablas
                 ret.update(implicit_surface=sdf, radiance=radiance, alpha=alpha, cdf=cdf, visibility_weights=alpha_to_w(alpha),
                            d_final=0.5 * (d[:, 1:] + d[:, :-1]), d_all=d, near_far=nf)
+                if samples_output:
+                    ret.update(xyz=pm, dirs=dirn[:, None, :].expand(R, N - 1, 3), density=sdf_mid, colors=radiance)
             chunks.append(ret)
     return OrderedDict((k, torch.cat([c[k] for c in chunks], 0)) for k in chunks[0])
 
 
-def _composite_autograd(model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf):
+def _mid_directions(dirn, pts_mid, random_color_direction: bool):
+    """View directions handed to the colour branch at the mid-points: the ray's own direction, or
+    (renderer.py:279-289) random ones -- torch.rand_like in [0,1)^3, normalised, exactly as the reference draws them."""
+    R, M = pts_mid.shape[0], pts_mid.shape[1]
+    if not random_color_direction:
+        return dirn[:, None, :].expand(R, M, 3).contiguous()
+    rnd = torch.rand_like(pts_mid)
+    return rnd / torch.linalg.norm(rnd, axis=-1, keepdims=True)
+
+
+def _composite_autograd(model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf, samples_output=False, random_color_direction=False):
     """renderer.py:264-348 as differentiable torch ops on the (detached) sample depths d [R,N]."""
     R, N = d.shape
     nablas = None
@@ -352,8 +370,8 @@ def _composite_autograd(model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf)
     sdf = sdf.reshape(R, N)
     cdf, alpha = sdf_to_alpha(sdf, model.forward_s())
     pm = ro[:, None, :] + dmid[:, :N - 1, None] * dirn[:, None, :]
-    view = dirn[:, None, :].expand(R, N - 1, 3)
-    _, radiance = query(lambda x, v: model.forward(x, v)[:2], pm, view)
+    view = _mid_directions(dirn, pm, random_color_direction)
+    sdf_mid, radiance = query(lambda x, v: model.forward(x, v)[:2], pm, view)
     w = alpha_to_w(alpha)
     rgb = torch.sum(w[..., None] * radiance, dim=-2)
     d_final = dmid[:, :N - 1]
@@ -370,6 +388,8 @@ def _composite_autograd(model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf)
             ret["implicit_nablas"] = nablas
         ret.update(implicit_surface=sdf, radiance=radiance, alpha=alpha, cdf=cdf, visibility_weights=w,
                    d_final=d_final, d_all=d, near_far=nf)
+        if samples_output:
+            ret.update(xyz=pm, dirs=dirn[:, None, :].expand(R, N - 1, 3), density=sdf_mid, colors=radiance)
     return ret
 
 
@@ -385,12 +405,13 @@ def volume_render(rays_o, rays_d, model, obj_bounding_radius=1.0, batched=False,
         lead = [B, -1]
     else:
         lead = [-1]
-    if samples_output or random_color_direction or not use_view_dirs:
-        raise NotImplementedError(
-            "neumesh_amd.volume_render: samples_output / random_color_direction / use_view_dirs=False are not implemented "
-            "(unused by render.py, the editing renders and the default training configuration)")
+    if not use_view_dirs:
+        raise NotImplementedError("neumesh_amd.volume_render: use_view_dirs=False (the NeuMesh colour branch always takes view "
+                                  "directions: models/frameworks/neumesh/neumesh.py:239-260)")
     training = torch.is_grad_enabled() or perturb   # trainer.py:75-81: autograd through the field + compositing
-    fused = isinstance(model, NeuMesh) and not training   # plain NeuMesh field, inference: one C call per chunk
+    # plain NeuMesh field, inference, the rays' own directions: one C call per chunk.  Per-sample outputs and random
+    # colour directions (training-side options, trainer.py:70-79,139-146) go through the staged form.
+    fused = isinstance(model, NeuMesh) and not training and not samples_output and not random_color_direction
     cfg = make_render_cfg(obj_bounding_radius, N_samples, N_importance, N_upsample_iters, bounded_near_far, calc_normal,
                           white_bkgd, near_bypass, far_bypass)
     progress = None
@@ -406,7 +427,8 @@ def volume_render(rays_o, rays_d, model, obj_bounding_radius=1.0, batched=False,
         ret = render_rays_fused(model, flat_o, flat_d, cfg, rayschunk, detailed=detailed_output, progress=progress)
     else:   # wrapper model (editing tools): per-ray stages on HIP, field through the wrapper's methods
         ret = render_rays_staged(model, flat_o, flat_d, cfg, rayschunk, netchunk, detailed=detailed_output, progress=progress,
-                                 differentiable=torch.is_grad_enabled(), perturb=perturb)
+                                 differentiable=torch.is_grad_enabled(), perturb=perturb, samples_output=samples_output,
+                                 random_color_direction=random_color_direction)
     for k in list(ret.keys()):
         v = ret[k]
         ret[k] = v.reshape(*lead, *v.shape[1:]) if batched else v

@@ -350,6 +350,96 @@ def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=8
     )
 
 
+class StubTeacher:
+    """Deterministic stand-in for the NeuS teacher of the distillation losses (models/trainer.py:211-221):
+    teacher(xyz, dirs) -> (sdf [...], radiance [..., 3]).  Analytic, so the product-side test can rebuild it."""
+
+    def to(self, *_a, **_k):
+        return self
+
+    def eval(self):
+        return self
+
+    def __call__(self, xyz, dirs):
+        import torch
+        return torch.linalg.norm(xyz, dim=-1) - 0.75, torch.sigmoid(2.0 * dirs + xyz)
+
+
+def gen_train_step_fixture(tag="train_step_v3000", V=3000, mlp_state=None):
+    """One optimisation step's forward + backward through the REFERENCE's Trainer (models/trainer.py:50-117,174-285):
+    random pixel selection, render with autograd (calc_normal on: eikonal weight > 0), per-sample outputs for the
+    distillation terms (stub teacher), every loss term, and d total / d parameter.  perturb is switched off
+    (its torch.rand stream is device-specific); the pixel selection uses the CPU generator on both sides."""
+    import torch
+    print(f"[{tag}] reference Trainer.forward + backward, V={V}")
+    mesh = synthetic.fibonacci_blob(V)
+    lw = {"img": 1.0, "mask": 0.1, "eikonal": 0.1, "distill_density": 1.0, "distill_color": 1.0, "indicator_reg": 0.001}
+    model, kw_test, renderer, args = harness.build_reference(mesh, seed=0, mlp_state=mlp_state,
+                                                             overrides={"training:loss_weights": dict(lw), "data:N_rays": 96})
+    from models.trainer import Trainer  # reference
+    trainer = Trainer(model, loss_weights=dict(lw), teacher_model=None, device_ids=["cpu"])
+    trainer.teacher_model = StubTeacher()
+    H = W = 40
+    c2w, K = synthetic.orbit_pose(9), synthetic.pinhole_intrinsics(H, W, 1.0)
+    rng = np.random.default_rng(31)
+    gt_rgb = rng.uniform(0, 1, (1, H * W, 3)).astype(np.float32)
+    obj_mask = rng.uniform(0, 1, (1, H * W)) > 0.4
+    kw = dict(kw_test)
+    kw.pop("rayschunk", None)
+    kw.update(perturb=False, calc_normal=True, H=H, W=W, N_samples=64, N_importance=64, rayschunk=4096)
+    model_input = {"intrinsics": torch.from_numpy(K)[None], "c2w": torch.from_numpy(c2w)[None], "object_mask": torch.from_numpy(obj_mask)}
+    ground_truth = {"rgb": torch.from_numpy(gt_rgb)}
+    model.train()
+    torch.manual_seed(123)
+    ret = trainer.forward(args, None, model_input, ground_truth, kw, 0, device="cpu")
+    losses = ret["losses"]
+    losses["total"].backward()
+    out = {"loss." + k: np.float32(v.item()) for k, v in losses.items()}
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach().numpy().astype(np.float32)
+        out["norm." + name] = np.float32(np.linalg.norm(g.astype(np.float64)))
+        if g.ndim == 2 and g.size > 4096:
+            rows = np.sort(np.argsort(-np.linalg.norm(g, axis=1))[:48]).astype(np.int32)
+            out["rows." + name] = rows
+            g = g[rows]
+        out["grad." + name] = g
+    print("    losses:", {k: round(float(v), 6) for k, v in out.items() if k.startswith("loss.")})
+    print(f"    psnr {float(ret['extras']['psnr']):.3f}, 1/s {float(ret['extras']['scalars']['1/s']):.5f}, "
+          f"|grad ln_s| {abs(float(out['grad.ln_s'])):.3e}")
+    np.savez_compressed(os.path.join(GOLDEN, f"{tag}.npz"), V=np.int64(V), H=np.int64(H), W=np.int64(W), c2w=c2w, intrinsics=K,
+                        gt_rgb=gt_rgb, object_mask=obj_mask, select_inds=ret["extras"]["select_inds"].numpy(),
+                        psnr=np.float32(ret["extras"]["psnr"].item()), rgb=ret["extras"]["mask_volume_clipped"].detach().numpy(),
+                        loss_weight_keys=np.array(sorted(lw)), loss_weight_vals=np.array([lw[k] for k in sorted(lw)], np.float32), **out)
+    # compute_loss alone on fixed tensors, the three masking variants (CPU-side test of the product's Trainer)
+    rng = np.random.default_rng(32)
+    B, R, N = 1, 50, 12
+    rgb = torch.from_numpy(rng.uniform(0, 1, (B, R, 3)).astype(np.float32))
+    tgt = torch.from_numpy(rng.uniform(0, 1, (B, R, 3)).astype(np.float32))
+    acc = torch.from_numpy(rng.uniform(0, 1, (B, R)).astype(np.float32))
+    nab = torch.from_numpy(rng.normal(0, 1, (B, R, N, 3)).astype(np.float32))
+    xyz = torch.from_numpy(rng.uniform(-1, 1, (B, R, N - 1, 3)).astype(np.float32))
+    dirs = torch.nn.functional.normalize(torch.from_numpy(rng.normal(0, 1, (B, R, N - 1, 3)).astype(np.float32)), dim=-1)
+    dens = torch.from_numpy(rng.normal(0, 0.2, (B, R, N - 1, 1)).astype(np.float32))
+    cols = torch.from_numpy(rng.uniform(0, 1, (B, R, N - 1, 3)).astype(np.float32))
+    m = torch.from_numpy(rng.uniform(0, 1, (B, R)) > 0.3)
+    mi = torch.from_numpy(rng.uniform(0, 1, (B, R)) > 0.2)
+    cl = {"rgb": rgb.numpy(), "target": tgt.numpy(), "mask_volume": acc.numpy(), "implicit_nablas": nab.numpy(), "xyz": xyz.numpy(),
+          "dirs": dirs.numpy(), "density": dens.numpy(), "colors": cols.numpy(), "mask": m.numpy(), "mask_ignore": mi.numpy(),
+          "indicator_vector": model.indicator_vector.detach().numpy(), "vertex_normals": model.mesh_grid.get_vertex_normal_torch().numpy(),
+          "s": np.float32(model.forward_s().item())}
+    with torch.no_grad():
+        for vname, mk, mik in (("both", m, mi), ("mask_only", m, None), ("ignore_only", None, mi), ("none", None, None)):
+            ex = {"mask_volume": acc.clone(), "implicit_nablas": nab, "xyz": xyz, "dirs": dirs, "density": dens, "colors": cols}
+            r = trainer.compute_loss(args, rgb, tgt, ex, mask=mk, mask_ignore=mik, use_eikonal_loss=True, use_distill_loss=True,
+                                     use_indicator_reg=True)
+            for k, v in r["losses"].items():
+                cl[f"{vname}.{k}"] = np.float32(v.item())
+            cl[f"{vname}.psnr"] = r["extras"]["psnr"].numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(GOLDEN, "trainer_compute_loss.npz"), **cl)
+
+
 def gen_rays_fixture():
     """rend_util.get_rays of the reference (utils/rend_util.py:123-176) for a skewed pin-hole camera."""
     import torch
@@ -371,9 +461,12 @@ def gen_rays_fixture():
 
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
-    if len(sys.argv) > 1 and sys.argv[1] == "scale":   # only the V = 140 000 fixture (the others are unchanged)
+    if len(sys.argv) > 1 and sys.argv[1] in ("scale", "train"):   # only one of the later fixtures (the others are unchanged)
         sd = dict(np.load(os.path.join(GOLDEN, "model_seed0.npz")))
-        gen_scale_fixture("render_v140k_dtu", mlp_state=sd)
+        if sys.argv[1] == "scale":
+            gen_scale_fixture("render_v140k_dtu", mlp_state=sd)
+        else:
+            gen_train_step_fixture("train_step_v3000", V=3000, mlp_state=sd)
         rp = os.path.join(GOLDEN, "REPORT.json")
         old = json.load(open(rp)) if os.path.exists(rp) else {}
         old.update(REPORT)
@@ -390,6 +483,7 @@ def main():
     gen_render_fixture("render_v3000_dtu", V=3000, H=6, W=12, frame=3, mlp_state=sd)
     gen_render_fixture("render_v3000_lego", V=3000, H=4, W=12, frame=17, white_bkgd=True, n_samples=32, mlp_state=sd)
     gen_grad_fixture("grad_v3000_dtu", "render_v3000_dtu", V=3000, mlp_state=sd)
+    gen_train_step_fixture("train_step_v3000", V=3000, mlp_state=sd)
     gen_scale_fixture("render_v140k_dtu", mlp_state=sd)
     with open(os.path.join(GOLDEN, "REPORT.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)

@@ -64,3 +64,17 @@ def make_model(mesh, state, device):
     missing = model.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in state.items()}, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     return model.to(device).eval()
+
+
+class StubTeacher:
+    """The analytic stand-in teacher the train-step fixture was generated with (oracle/gen_golden.py)."""
+
+    def to(self, *_a, **_k):
+        return self
+
+    def eval(self):
+        return self
+
+    def __call__(self, xyz, dirs):
+        import torch
+        return torch.linalg.norm(xyz, dim=-1) - 0.75, torch.sigmoid(2.0 * dirs + xyz)

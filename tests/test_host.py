@@ -134,3 +134,62 @@ def test_get_rays_matches_reference_fixture_cpu():
     ro2, rd2, sel2 = get_rays(torch.from_numpy(fx["c2w"])[None], torch.from_numpy(fx["intrinsics"])[None], H, W, N_rays=50)
     assert tuple(rd2.shape) == (1, 50, 3)
     np.testing.assert_allclose(rd2[0].numpy(), fx["rays_d"][sel2[0].numpy()], atol=3e-7)
+
+
+def test_trainer_compute_loss_matches_reference_fixture():
+    """neumesh_amd.trainer.Trainer.compute_loss against the REFERENCE Trainer's values on the same tensors
+    (tests/golden/trainer_compute_loss.npz, oracle/gen_golden.py): every loss term, the total and the PSNR, for
+    the four mask / mask_ignore combinations of models/trainer.py:240-266.  Pure torch: runs without a GPU."""
+    torch = pytest.importorskip("torch")
+    from neumesh_amd.trainer import Trainer
+    f = common.golden("trainer_compute_loss")
+
+    class Grid:
+        def get_vertex_normal_torch(self):
+            return torch.from_numpy(f["vertex_normals"])
+
+    class Model(torch.nn.Module):
+        learn_indicator_weight = False
+
+        def __init__(self):
+            super().__init__()
+            self.indicator_vector = torch.nn.Parameter(torch.from_numpy(f["indicator_vector"]))
+            self.mesh_grid = Grid()
+
+        def forward_s(self):
+            return torch.tensor([float(f["s"])])
+
+    lw = {"img": 1.0, "mask": 0.1, "eikonal": 0.1, "distill_density": 1.0, "distill_color": 1.0, "indicator_reg": 0.001}
+    tr = Trainer.__new__(Trainer)
+    torch.nn.Module.__init__(tr)
+    tr.model, tr.loss_weights, tr.teacher_model = Model(), lw, common.StubTeacher()
+    t = lambda k: torch.from_numpy(f[k])
+    for vname, mk, mik in (("both", t("mask"), t("mask_ignore")), ("mask_only", t("mask"), None), ("ignore_only", None, t("mask_ignore")),
+                           ("none", None, None)):
+        ex = {"mask_volume": t("mask_volume").clone(), "implicit_nablas": t("implicit_nablas"), "xyz": t("xyz"), "dirs": t("dirs"),
+              "density": t("density"), "colors": t("colors")}
+        with torch.no_grad():
+            r = tr.compute_loss({}, t("rgb"), t("target"), ex, mask=mk, mask_ignore=mik, use_eikonal_loss=True, use_distill_loss=True,
+                                use_indicator_reg=True)
+        want = {k.split(".", 1)[1]: f[k] for k in f.files if k.startswith(vname + ".") and not k.endswith(".psnr")}
+        assert list(r["losses"].keys()) == ["loss_img", "loss_eikonal", "loss_density", "loss_color", "loss_indicator_vector_reg"] + (
+            ["loss_mask"] if mk is not None else []) + ["total"]
+        for k, v in want.items():
+            assert abs(float(r["losses"][k]) - float(v)) <= 1e-6 * max(1.0, abs(float(v))), (vname, k)
+        np.testing.assert_allclose(r["extras"]["psnr"].numpy(), f[vname + ".psnr"], rtol=1e-5, atol=1e-5)
+        assert set(r["extras"]) >= {"mask_volume_clipped", "psnr", "implicit_nablas_norm", "scalars"}
+        assert abs(float(r["extras"]["scalars"]["1/s"]) - 1.0 / float(f["s"])) < 1e-6
+
+
+def test_get_model_returns_a_trainer_with_the_reference_signature():
+    """The factory's 5-tuple carries a Trainer whose forward / forward_painting / compute_loss take the reference's
+    arguments (models/trainer.py:50-60, 119-129, 174-185); no GPU: only the object graph is built around a stub grid."""
+    torch = pytest.importorskip("torch")
+    import inspect
+    from neumesh_amd.trainer import Trainer
+    sig = inspect.signature(Trainer.forward)
+    assert list(sig.parameters)[1:] == ["args", "indices", "model_input", "ground_truth", "render_kwargs_train", "it", "train_progress", "device"]
+    assert list(inspect.signature(Trainer.forward_painting).parameters)[1:] == list(sig.parameters)[1:]
+    assert list(inspect.signature(Trainer.compute_loss).parameters)[1:] == [
+        "args", "rgb", "target_rgb", "extras", "mask", "mask_ignore", "use_eikonal_loss", "use_distill_loss", "use_indicator_reg"]
+    assert list(inspect.signature(Trainer.__init__).parameters)[1:] == ["model", "loss_weights", "teacher_model", "device_ids", "batched"]
