@@ -10,6 +10,9 @@ missing -- there is no CPU fallback in the product path.
     from neumesh_amd import build_framework          # models/frameworks/__init__.py
     from neumesh_amd import MeshGrid, NeuMesh, SingleRenderer, volume_render
     from neumesh_amd import frnn                     # drop-in for `import frnn`
+    from neumesh_amd import Trainer                  # models/trainer.py (2nd element of get_model's tuple)
+    from neumesh_amd import TextureEditableNeuMesh   # editing/texture_neumesh/texture_neumesh.py
+    from neumesh_amd import ray_casting              # models/ray_casting.py (surface_render, root finding, sphere tracing)
 """
 from . import synthetic  # noqa: F401  (numpy only)
 
@@ -18,10 +21,12 @@ def __getattr__(name):  # lazy: torch is imported only when the model classes ar
     import importlib
     table = {
         "MeshGrid": "mesh_grid", "MeshPrimitive": "mesh_grid", "NeuMesh": "neumesh", "SingleRenderer": "renderer",
-        "volume_render": "renderer", "get_model": "framework", "build_framework": "framework",
+        "volume_render": "renderer", "get_model": "framework", "build_framework": "framework", "Trainer": "trainer",
+        "TextureEditableNeuMesh": "editing", "surface_render": "ray_casting",
     }
     if name in table:
         return getattr(importlib.import_module(f".{table[name]}", __name__), name)
-    if name in ("frnn", "mesh_grid", "neumesh", "renderer", "framework", "ply", "sharded", "rays", "build", "_lib"):
+    if name in ("frnn", "mesh_grid", "neumesh", "renderer", "framework", "ply", "sharded", "rays", "build", "_lib", "trainer", "editing",
+                "ray_casting"):
         return importlib.import_module(f".{name}", __name__)
     raise AttributeError(name)

@@ -440,6 +440,45 @@ def gen_train_step_fixture(tag="train_step_v3000", V=3000, mlp_state=None):
     np.savez_compressed(os.path.join(GOLDEN, "trainer_compute_loss.npz"), **cl)
 
 
+def gen_surface_fixture(tag="surface_v3000", V=3000, mlp_state=None):
+    """models/ray_casting.py of the reference (dead code there: imported nowhere) run on the reference's NeuMesh
+    field: root_finding_surface_points (256 proposals + 8 secant steps) and sphere_tracing_surface_points, on the
+    rays of the render fixture.  The SDF handed in is model.forward_density_only."""
+    import torch
+    print(f"[{tag}] reference ray_casting.py on the reference field, V={V}")
+    mesh = synthetic.fibonacci_blob(V)
+    model, kw, renderer, _ = harness.build_reference(mesh, seed=0, mlp_state=mlp_state)
+    import models.ray_casting as rc  # reference
+    rf = np.load(os.path.join(GOLDEN, "render_v3000_dtu.npz"))
+    ro = torch.from_numpy(rf["rays_o"])[None]
+    rd = torch.nn.functional.normalize(torch.from_numpy(rf["rays_d"]), dim=-1)[None]
+
+    def sdf(p):
+        with torch.no_grad():
+            return model.forward_density_only(p).squeeze(-1)
+
+    out = {}
+    # (the default-init field is negative everywhere, ~-0.09..-0.05 along these rays: the level sets chosen through
+    #  logit_tau are the ones the rays actually cross)
+    for name, tau in (("tau_a", -0.085), ("tau_b", -0.075)):
+        d, pt, m, msc = rc.root_finding_surface_points(sdf, ro.clone(), rd.clone(), near=0.8, far=3.6, batched=True, N_steps=256,
+                                                       logit_tau=tau, method="secant", N_secant_steps=8, fill_inf=False)
+        out.update({f"{name}.d": d[0].numpy(), f"{name}.pt": pt[0].numpy(), f"{name}.mask": m[0].numpy(), f"{name}.sign_change": msc[0].numpy(),
+                    f"{name}.tau": np.float32(tau)})
+        print(f"    root finding tau={tau}: {int(m.sum())}/{m.numel()} rays hit, {int(msc.sum())} with a sign change; depth of hits "
+              f"{float(d[m].min()) if m.any() else float('nan'):.3f}..{float(d[m].max()) if m.any() else float('nan'):.3f}")
+
+    class Surf:   # the same field shifted to the -0.08 level set, so that the marching has something to converge to
+        def forward(self, p):
+            return sdf(p) + 0.08
+
+    d, pt, m = rc.sphere_tracing_surface_points(Surf(), ro.clone(), rd.clone(), near=0.8, far=3.6, batched=True, N_iters=20)
+    out.update({"st.d": d[0].numpy(), "st.pt": pt[0].numpy(), "st.mask": m[0].numpy()})
+    print(f"    sphere tracing: {int(m.sum())}/{m.numel()} rays still inside [0, far] after 20 steps")
+    np.savez_compressed(os.path.join(GOLDEN, f"{tag}.npz"), V=np.int64(V), rays_o=rf["rays_o"], rays_d=rf["rays_d"], near=np.float32(0.8),
+                        far=np.float32(3.6), **out)
+
+
 def gen_rays_fixture():
     """rend_util.get_rays of the reference (utils/rend_util.py:123-176) for a skewed pin-hole camera."""
     import torch
@@ -461,12 +500,14 @@ def gen_rays_fixture():
 
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
-    if len(sys.argv) > 1 and sys.argv[1] in ("scale", "train"):   # only one of the later fixtures (the others are unchanged)
+    if len(sys.argv) > 1 and sys.argv[1] in ("scale", "train", "surface"):   # only one of the later fixtures (the others are unchanged)
         sd = dict(np.load(os.path.join(GOLDEN, "model_seed0.npz")))
         if sys.argv[1] == "scale":
             gen_scale_fixture("render_v140k_dtu", mlp_state=sd)
-        else:
+        elif sys.argv[1] == "train":
             gen_train_step_fixture("train_step_v3000", V=3000, mlp_state=sd)
+        else:
+            gen_surface_fixture("surface_v3000", V=3000, mlp_state=sd)
         rp = os.path.join(GOLDEN, "REPORT.json")
         old = json.load(open(rp)) if os.path.exists(rp) else {}
         old.update(REPORT)
@@ -484,6 +525,7 @@ def main():
     gen_render_fixture("render_v3000_lego", V=3000, H=4, W=12, frame=17, white_bkgd=True, n_samples=32, mlp_state=sd)
     gen_grad_fixture("grad_v3000_dtu", "render_v3000_dtu", V=3000, mlp_state=sd)
     gen_train_step_fixture("train_step_v3000", V=3000, mlp_state=sd)
+    gen_surface_fixture("surface_v3000", V=3000, mlp_state=sd)
     gen_scale_fixture("render_v140k_dtu", mlp_state=sd)
     with open(os.path.join(GOLDEN, "REPORT.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)

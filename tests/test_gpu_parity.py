@@ -734,3 +734,115 @@ def test_trainer_step_matches_reference_trainer(cuda_device, torch_mod, fused_au
         assert np.abs(g - f["grad." + name]).max() <= 1e-2 * max(np.abs(f["grad." + name]).max(), 1e-8) + 1e-6, name
         checked += 1
     assert checked >= 20
+
+
+@pytest.mark.gpu
+def test_surface_rendering_matches_reference_ray_casting(small, cuda_device, torch_mod):
+    """neumesh_amd.ray_casting against the reference's models/ray_casting.py run on the
+    reference's field (tests/golden/surface_v3000.npz): first-hit depths / points / masks of
+    root_finding_surface_points (256 proposals + 8 secant steps, two level sets) and of
+    sphere_tracing_surface_points; then surface_render end to end (colour, depth, normals at the hits)."""
+    torch = torch_mod
+    from neumesh_amd import ray_casting as rc
+    mesh, state, model = small
+    f = common.golden("surface_v3000")
+    ro = _t(f["rays_o"], cuda_device)[None]
+    rd = torch.nn.functional.normalize(_t(f["rays_d"], cuda_device), dim=-1)[None]
+    near, far = float(f["near"]), float(f["far"])
+
+    def sdf(p):
+        with torch.no_grad():
+            return model.forward_density_only(p).squeeze(-1)
+
+    for name in ("tau_a", "tau_b"):
+        d, pt, m, msc = rc.root_finding_surface_points(sdf, ro.clone(), rd.clone(), near=near, far=far, batched=True, N_steps=256,
+                                                       logit_tau=float(f[name + ".tau"]), method="secant", N_secant_steps=8, fill_inf=False)
+        m_ref = f[name + ".mask"]
+        # a ray whose bracket value is within the field's parity bound of the level can flip; everything else must agree
+        assert (m[0].cpu().numpy() != m_ref).mean() <= 0.03, name
+        assert np.array_equal(msc[0].cpu().numpy(), f[name + ".sign_change"]) or (msc[0].cpu().numpy() != f[name + ".sign_change"]).mean() <= 0.03
+        both = m[0].cpu().numpy() & m_ref
+        assert both.sum() >= 10
+        # the field is flat here (|d sdf / d depth| ~ 0.02..0.1), so a 3e-6 field difference moves the root by up to ~1e-4
+        np.testing.assert_allclose(d[0].cpu().numpy()[both], f[name + ".d"][both], atol=5e-4)
+        np.testing.assert_allclose(pt[0].cpu().numpy()[both], f[name + ".pt"][both], atol=5e-4)
+        miss = ~m[0].cpu().numpy() & ~m_ref
+        np.testing.assert_allclose(d[0].cpu().numpy()[miss], f[name + ".d"][miss], atol=1e-6)   # `far` or 0 exactly as the reference fills them
+
+    class Surf:
+        def forward(self, p):
+            return sdf(p) + 0.08
+
+    d, pt, m = rc.sphere_tracing_surface_points(Surf(), ro.clone(), rd.clone(), near=near, far=far, batched=True, N_iters=20)
+    assert np.array_equal(m[0].cpu().numpy(), f["st.mask"])
+    np.testing.assert_allclose(d[0].cpu().numpy(), f["st.d"], atol=2e-4)
+    # surface_render on the NeuMesh field: colour / nabla at the hit points equal the field queried there
+    model_tau = float(f["tau_a.tau"])
+    col, dep, ex = rc.surface_render(ro, _t(f["rays_d"], cuda_device)[None], model, calc_normal=True, batched=True, ray_casting_algo="root_finding",
+                                     ray_casting_cfgs=dict(near=near, far=far, logit_tau=model_tau, fill_inf=False))
+    hit = ex["mask_surface"][0]
+    assert tuple(col.shape) == (1, ro.shape[1], 3) and int(hit.sum()) >= 10
+    assert float(col[0][~hit].abs().max()) == 0.0 and float(ex["normals_surface"][0][~hit].abs().max()) == 0.0
+    pts_hit = (ro[0] + dep[0][:, None] * rd[0])[hit]
+    with torch.no_grad():
+        sdf_h, rgb_h = model.forward(pts_hit, rd[0][hit])
+        _, nab_h = model.forward_with_nablas(pts_hit)
+    # the hits sit on the requested level set: exactly for most rays, within the secant method's 8-step residual on the
+    # piecewise field (K-NN set changes) for the rest -- the reference's own hits carry the same residual
+    res = (sdf_h[:, 0] - model_tau).abs()
+    assert float(res.median()) < 1e-5 and float(res.max()) < 0.03
+    np.testing.assert_allclose(col[0][hit].cpu().numpy(), rgb_h.cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(ex["normals_surface"][0][hit].cpu().numpy(), torch.nn.functional.normalize(nab_h, dim=-1).cpu().numpy(), atol=2e-4)
+    with pytest.raises(NotImplementedError):
+        rc.surface_render(ro, rd, model, ray_casting_algo="")
+
+
+@pytest.mark.gpu
+def test_texture_editable_wrapper_forward_and_render(small, cuda_device, torch_mod):
+    """neumesh_amd.editing.TextureEditableNeuMesh (editing/texture_neumesh/texture_neumesh.py:53-122): its fused forward
+    equals the reference's formulas evaluated with torch ops on the oracle-checked pieces, unpainted points keep the main
+    colour bit for bit, and volume_render drives it through the staged path."""
+    torch = torch_mod
+    from neumesh_amd.editing import TextureEditableNeuMesh
+    from neumesh_amd.renderer import volume_render
+    mesh, state, model = small
+    V = mesh.num_vertices
+    ref_state = dict(state)
+    rng = np.random.default_rng(8)
+    ref_state["color_features"] = rng.standard_normal((V, 32)).astype(np.float32)
+    ref_model = common.make_model(mesh, ref_state, cuda_device)
+    mask = torch.from_numpy(mesh.vertices[:, 2] > 0.2).to(cuda_device)[None]          # paint the top cap
+    edit_feats = _t(rng.standard_normal((V, 32)).astype(np.float32), cuda_device)
+    th = 0.3
+    T = torch.tensor([[np.cos(th), -np.sin(th), 0, 0.1], [np.sin(th), np.cos(th), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=torch.float32,
+                     device=cuda_device)
+    wrap = TextureEditableNeuMesh(model, [ref_model], mask, edit_feats, T_r_m_list=[T])
+    fx = common.golden("field_v3000")
+    q, dirs = _t(fx["q"], cuda_device), _t(fx["dirs"], cuda_device)
+    with torch.no_grad():
+        sdf, rgb = wrap(q, dirs)
+        # the reference's formulas, piece by piece, on the same model methods
+        s2, nab, ds, idx, w = model.forward(q, dirs, need_nablas=True, nablas_only=True, return_ds=True)
+        base = model.forward_color(ds, dirs, model.color_features, indices=idx, weights=w, nabla=nab)
+        pm = mask[0][idx]
+        pw, uw = (w * pm).sum(-1), (w * (~pm)).sum(-1)
+        region = pw > 0
+        rw = w * pm
+        rw = rw / (rw.sum(-1, keepdim=True) + 1e-8)
+        R = T[:3, :3]
+        rc_ = ref_model.forward_color(ds[region], (dirs @ R.T)[region], edit_feats, indices=idx[region], weights=rw[region], nabla=(nab @ R.T)[region])
+        want = base.clone()
+        want[region] = base[region] * (uw / (pw + uw))[region, None] + rc_ * (pw / (pw + uw))[region, None]
+    assert torch.equal(sdf, s2)
+    assert 0.05 < float(region.float().mean()) < 0.95
+    assert torch.equal(rgb[~region], base[~region])                      # untouched where no neighbour is painted
+    np.testing.assert_allclose(rgb.cpu().numpy(), want.cpu().numpy(), atol=2e-6)
+    assert float((rgb[region] - base[region]).abs().max()) > 1e-3        # ... and the paint is visible
+    rf = common.golden("render_v3000_dtu")
+    with torch.no_grad():
+        img, depth, ex = volume_render(_t(rf["rays_o"], cuda_device), _t(rf["rays_d"], cuda_device), wrap, calc_normal=True, perturb=False,
+                                       detailed_output=False, rayschunk=4096)
+        img0, depth0, _ = volume_render(_t(rf["rays_o"], cuda_device), _t(rf["rays_d"], cuda_device), model, calc_normal=True, perturb=False,
+                                        detailed_output=False, rayschunk=4096)
+    assert torch.equal(depth, depth0) and bool(torch.isfinite(img).all())   # geometry untouched, colours edited
+    assert float((img - img0).abs().max()) > 1e-3
