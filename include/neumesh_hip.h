@@ -55,7 +55,9 @@ int nm_device_count(void);
  * Builds the search structure over `V` vertices (device, [V,3] fp32, row-major).
  * leaf_level = 0 picks the octree depth automatically (about 8-12 vertices per occupied
  * leaf).  The vertex data is COPIED (sorted copy lives in the handle); `verts` may be
- * freed afterwards.  One-off call: copies to the host, builds, uploads, synchronises. */
+ * freed afterwards.  The build runs on the device (Morton codes, radix sort, per-level node
+ * kernels; a deformed mesh is re-indexed in about a millisecond); a few scalars -- bounding box,
+ * per-level node counts -- pass through the host, so the call synchronises `stream`. */
 int nm_grid_create(const float* verts_device, int64_t V, int leaf_level, nm_stream_t stream,
                    nm_grid_t* out);
 int nm_grid_destroy(nm_grid_t g);
@@ -67,6 +69,7 @@ typedef struct nm_grid_info {
     float origin[3];            /* min corner of the root cube */
     float root_size;            /* edge of the root cube */
     int64_t device_bytes;       /* memory held by the handle */
+    int64_t num_nodes;          /* octree node records (64 bytes each) */
 } nm_grid_info;
 int nm_grid_get_info(nm_grid_t g, nm_grid_info* out);
 

@@ -17,7 +17,7 @@ MAX_K = 32
 
 class GridInfo(C.Structure):
     _fields_ = [("num_vertices", C.c_int64), ("leaf_level", C.c_int32), ("occupied_leaves", C.c_int32),
-                ("origin", C.c_float * 3), ("root_size", C.c_float), ("device_bytes", C.c_int64)]
+                ("origin", C.c_float * 3), ("root_size", C.c_float), ("device_bytes", C.c_int64), ("num_nodes", C.c_int64)]
 
 
 class FieldDesc(C.Structure):
@@ -98,6 +98,8 @@ SIGNATURES = {
 # test hook, not part of the public header
 _EXTRA = {
     "nm_debug_phase_log": (C.c_int, [_P]),
+    "nm_grid_create_host": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.POINTER(_P)]),
+    "nm_grid_debug_export": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64]),
     "nm_selfcheck_field": (C.c_int, [_P, _P, C.POINTER(FieldTables), _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P]),
 }
 

@@ -16,6 +16,7 @@
 
 #include "../../include/neumesh_hip.h"
 #include "nm_grid_build.h"
+#include "nm_grid_build_dev.h"
 #include "nm_kernels.h"
 #include "nm_mlp.h"
 #include "nm_mlp_f16.h"
@@ -94,8 +95,9 @@ static inline size_t nm_align(size_t x) { return (x + 255) & ~(size_t)255; }
 struct nm_grid_s {
     NmGridView view;        // device pointers
     float* verts = nullptr;  // device copy of the vertices in ORIGINAL order [V,3]
-    void* blob = nullptr;    // one allocation holding nodes | sverts | verts
-    size_t blob_bytes = 0;
+    void* mem[3] = {nullptr, nullptr, nullptr};  // owned allocations (host build: one blob; device build: nodes, sverts, verts)
+    size_t bytes = 0;
+    size_t n_nodes = 0;
     int occupied = 0;
     float origin[3] = {0, 0, 0};
     float root_size = 0;
@@ -129,7 +131,48 @@ int nm_device_count(void) {
 }
 
 // ================================================================================ grid
+// Device-side build (nm_grid_build_dev.h): all O(V) work on the GPU, a few scalars through the host.
 int nm_grid_create(const float* verts_device, int64_t V, int leaf_level, nm_stream_t stream_, nm_grid_t* out) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!out) return nm_fail("nm_grid_create: out is NULL");
+    if (V < 1 || V > 0x7ffffff0LL) return nm_fail("nm_grid_create: V=%lld", (long long)V);
+    if (leaf_level < 0 || leaf_level > NM_MAX_LEVEL) return nm_fail("nm_grid_create: leaf_level %d out of [0,%d]", leaf_level, NM_MAX_LEVEL);
+    if (!verts_device) return nm_fail("nm_grid_create: verts is NULL");
+    NmDevGrid dg;
+    bool bad = false;
+    const hipError_t e = nm_build_device_grid(verts_device, V, leaf_level, stream, dg, &bad);
+    if (bad) return nm_fail("nm_grid_create: non-finite vertex coordinates");
+    if (e != hipSuccess) return nm_fail("nm_grid_create: device build failed: %s", hipGetErrorString(e));
+    nm_grid_s* g = new nm_grid_s();
+    float* vcopy = nullptr;
+    hipError_t e2 = hipMalloc((void**)&vcopy, (size_t)V * 12);
+    if (e2 == hipSuccess) e2 = hipMemcpyAsync(vcopy, verts_device, (size_t)V * 12, hipMemcpyDeviceToDevice, stream);
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(stream);
+    if (e2 != hipSuccess) {
+        hipFree(dg.nodes); hipFree(dg.sverts);
+        if (vcopy) hipFree(vcopy);
+        delete g;
+        return nm_fail("nm_grid_create: vertex copy failed: %s", hipGetErrorString(e2));
+    }
+    g->mem[0] = dg.nodes; g->mem[1] = dg.sverts; g->mem[2] = vcopy;
+    g->bytes = dg.n_nodes * sizeof(NmNode) + ((size_t)V + 4) * sizeof(float4) + (size_t)V * 12;
+    g->n_nodes = dg.n_nodes;
+    g->view.L = dg.L;
+    g->view.V = (int)V;
+    g->view.coop_extent = 0.75f * dg.root.root_size;   // (as nm_host_view)
+    g->view.nodes = dg.nodes;
+    g->view.sverts = dg.sverts;
+    g->verts = vcopy;
+    g->origin[0] = dg.root.ox; g->origin[1] = dg.root.oy; g->origin[2] = dg.root.oz;
+    g->root_size = dg.root.root_size;
+    g->occupied = dg.occupied_leaves;
+    *out = g;
+    return 0;
+}
+
+// Host build (nm_grid_build.h), the reference implementation the device build is checked against: device->host copy,
+// CPU sort, upload.  Test hook, not part of the public header.
+int nm_grid_create_host(const float* verts_device, int64_t V, int leaf_level, nm_stream_t stream_, nm_grid_t* out) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!out) return nm_fail("nm_grid_create: out is NULL");
     if (V < 1) return nm_fail("nm_grid_create: V=%lld", (long long)V);
@@ -143,18 +186,18 @@ int nm_grid_create(const float* verts_device, int64_t V, int leaf_level, nm_stre
     const size_t b_nodes = nm_align(hg.nodes.size() * sizeof(NmNode));
     const size_t b_sv = nm_align(hg.sverts.size() * sizeof(float4));
     const size_t b_v = nm_align(hv.size() * sizeof(float));
-    g->blob_bytes = b_nodes + b_sv + b_v;
-    if (hipMalloc(&g->blob, g->blob_bytes) != hipSuccess) {
+    g->bytes = b_nodes + b_sv + b_v;
+    if (hipMalloc(&g->mem[0], g->bytes) != hipSuccess) {
         delete g;
         return nm_fail("nm_grid_create: hipMalloc(%zu) failed", b_nodes + b_sv + b_v);
     }
-    char* base = (char*)g->blob;
+    char* base = (char*)g->mem[0];
     hipError_t e = hipMemcpyAsync(base, hg.nodes.data(), hg.nodes.size() * sizeof(NmNode), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(base + b_nodes, hg.sverts.data(), hg.sverts.size() * sizeof(float4), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(base + b_nodes + b_sv, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) {
-        hipFree(g->blob);
+        hipFree(g->mem[0]);
         delete g;
         return nm_fail("nm_grid_create: upload failed: %s", hipGetErrorString(e));
     }
@@ -162,6 +205,7 @@ int nm_grid_create(const float* verts_device, int64_t V, int leaf_level, nm_stre
     g->view.nodes = (const NmNode*)base;
     g->view.sverts = (const float4*)(base + b_nodes);
     g->verts = (float*)(base + b_nodes + b_sv);
+    g->n_nodes = hg.nodes.size();
     g->origin[0] = hg.ox; g->origin[1] = hg.oy; g->origin[2] = hg.oz;
     g->root_size = hg.root_size;
     g->occupied = hg.occupied_leaves;
@@ -169,9 +213,20 @@ int nm_grid_create(const float* verts_device, int64_t V, int leaf_level, nm_stre
     return 0;
 }
 
+// Test hook: the node records and sorted vertices of a handle, copied to host buffers (sizes from nm_grid_get_info).
+int nm_grid_debug_export(nm_grid_t g, void* nodes_host, int64_t nodes_bytes, void* sverts_host, int64_t sverts_bytes) {
+    if (!g || !nodes_host || !sverts_host) return nm_fail("nm_grid_debug_export: NULL argument");
+    if (nodes_bytes != (int64_t)(g->n_nodes * sizeof(NmNode)) || sverts_bytes != (int64_t)(((size_t)g->view.V + 4) * sizeof(float4)))
+        return nm_fail("nm_grid_debug_export: buffer sizes %lld / %lld do not match the handle", (long long)nodes_bytes, (long long)sverts_bytes);
+    NM_HIP(hipMemcpy(nodes_host, g->view.nodes, (size_t)nodes_bytes, hipMemcpyDeviceToHost));
+    NM_HIP(hipMemcpy(sverts_host, g->view.sverts, (size_t)sverts_bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int nm_grid_destroy(nm_grid_t g) {
     if (!g) return 0;
-    if (g->blob) hipFree(g->blob);
+    for (void* m : g->mem)
+        if (m) hipFree(m);
     delete g;
     return 0;
 }
@@ -183,7 +238,8 @@ int nm_grid_get_info(nm_grid_t g, nm_grid_info* out) {
     out->occupied_leaves = g->occupied;
     out->origin[0] = g->origin[0]; out->origin[1] = g->origin[1]; out->origin[2] = g->origin[2];
     out->root_size = g->root_size;
-    out->device_bytes = (int64_t)g->blob_bytes;
+    out->device_bytes = (int64_t)g->bytes;
+    out->num_nodes = (int64_t)g->n_nodes;
     return 0;
 }
 

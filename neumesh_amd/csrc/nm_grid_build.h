@@ -20,7 +20,7 @@ struct NmHostGrid {
     std::vector<float4> sverts;  // V + 4 (padding)
 };
 
-static inline uint32_t nm_spread3(uint32_t v) {  // 8 bits -> every third bit
+NM_HD uint32_t nm_spread3(uint32_t v) {  // 8 bits -> every third bit
     v &= 0xffu;
     v = (v | (v << 8)) & 0x00f00fu;
     v = (v | (v << 4)) & 0x0c30c3u;
@@ -34,7 +34,7 @@ static inline uint32_t nm_compact3(uint32_t v) {  // inverse of nm_spread3
     v = (v | (v >> 8)) & 0x0000ffu;
     return v;
 }
-static inline uint32_t nm_morton(uint32_t x, uint32_t y, uint32_t z) {
+NM_HD uint32_t nm_morton(uint32_t x, uint32_t y, uint32_t z) {
     return nm_spread3(x) | (nm_spread3(y) << 1) | (nm_spread3(z) << 2);
 }
 

@@ -54,7 +54,7 @@ class GridHandle:
         gi = _lib.GridInfo()
         _lib.check(_lib.load().nm_grid_get_info(self._h, C.byref(gi)), "nm_grid_get_info")
         return {"num_vertices": gi.num_vertices, "leaf_level": gi.leaf_level, "occupied_leaves": gi.occupied_leaves,
-                "origin": tuple(gi.origin), "root_size": gi.root_size, "device_bytes": gi.device_bytes}
+                "origin": tuple(gi.origin), "root_size": gi.root_size, "device_bytes": gi.device_bytes, "num_nodes": gi.num_nodes}
 
     def __del__(self):
         try:

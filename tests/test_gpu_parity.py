@@ -846,3 +846,50 @@ def test_texture_editable_wrapper_forward_and_render(small, cuda_device, torch_m
                                         detailed_output=False, rayschunk=4096)
     assert torch.equal(depth, depth0) and bool(torch.isfinite(img).all())   # geometry untouched, colours edited
     assert float((img - img0).abs().max()) > 1e-3
+
+
+@pytest.mark.gpu
+def test_device_octree_build_is_bit_identical_to_host_build(cuda_device, torch_mod):
+    """nm_grid_create builds the index ON THE DEVICE (nm_grid_build_dev.h: Morton codes, radix sort, per-level node
+    kernels); the host build of nm_grid_build.h -- the one tests/hostcheck checks against brute force on the CPU -- is
+    the reference implementation.  Node records and sorted vertices must be identical byte for byte: benchmark-scale
+    mesh, small meshes, duplicated vertices, forced leaf levels, degenerate clouds (all points equal, points on a line,
+    two clusters far apart) and non-finite input."""
+    torch = torch_mod
+    from neumesh_amd import _lib
+    lib = _lib.load()
+    st = _lib.current_stream(cuda_device)
+    rng = np.random.default_rng(3)
+
+    def export(h, V):
+        gi = _lib.GridInfo()
+        _lib.check(lib.nm_grid_get_info(h, C.byref(gi)), "info")
+        nodes = np.empty(gi.num_nodes * 64, np.uint8)
+        sv = np.empty((V + 4) * 16, np.uint8)
+        _lib.check(lib.nm_grid_debug_export(h, nodes.ctypes.data_as(C.c_void_p), nodes.nbytes, sv.ctypes.data_as(C.c_void_p), sv.nbytes), "export")
+        return gi, nodes, sv
+
+    line = np.stack([np.linspace(-1, 1, 5000), np.zeros(5000), np.full(5000, 0.25)], -1)
+    clusters = np.concatenate([rng.normal(0, 1e-3, (3000, 3)) - 5.0, rng.normal(0, 1e-3, (3000, 3)) + 5.0])
+    cases = [("S-DTU 140k", common.scene_mesh(140000).vertices, 0), ("3000", common.scene_mesh(3000).vertices, 0),
+             ("1200 + 64 duplicates", common.scene_mesh(1200, dup=64).vertices, 0), ("20000, leaf level 5", common.scene_mesh(20000).vertices, 5),
+             ("20000, leaf level 8", common.scene_mesh(20000).vertices, 8), ("5 vertices", rng.normal(0, 1, (5, 3)), 0),
+             ("one vertex", np.array([[0.3, -0.2, 0.9]]), 0), ("all equal", np.tile(np.array([[0.1, 0.2, 0.3]]), (257, 1)), 0),
+             ("line", line, 0), ("two far clusters", clusters, 0), ("uniform cloud 100k", rng.uniform(-1, 1, (100000, 3)), 0)]
+    for name, verts, level in cases:
+        v = _t(np.ascontiguousarray(verts, np.float32), cuda_device)
+        V = v.shape[0]
+        hd, hh = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.nm_grid_create(_lib.ptr(v), V, level, st, C.byref(hd)), "nm_grid_create")
+        _lib.check(lib.nm_grid_create_host(_lib.ptr(v), V, level, st, C.byref(hh)), "nm_grid_create_host")
+        gd, nd, sd = export(hd, V)
+        gh, nh, sh = export(hh, V)
+        lib.nm_grid_destroy(hd)
+        lib.nm_grid_destroy(hh)
+        assert (gd.leaf_level, gd.occupied_leaves, gd.num_nodes, tuple(gd.origin), gd.root_size) == \
+               (gh.leaf_level, gh.occupied_leaves, gh.num_nodes, tuple(gh.origin), gh.root_size), name
+        assert np.array_equal(sd, sh), name + ": sorted vertices differ"
+        assert np.array_equal(nd, nh), name + ": node records differ"
+    bad = _t(np.array([[0, 0, 0], [np.nan, 0, 0], [1, 1, 1]], np.float32), cuda_device)
+    h = C.c_void_p()
+    assert lib.nm_grid_create(_lib.ptr(bad), 3, 0, st, C.byref(h)) != 0 and b"non-finite" in lib.nm_last_error()
