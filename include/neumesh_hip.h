@@ -182,11 +182,14 @@ typedef struct nm_render_cfg {
  *                 instead of only those before the first / after the last one below the threshold
  *   NO_ZERO_SKIP  evaluate the mid-points whose visibility weight is exactly 0 as well
  *   NO_RAY_SORT   process the rays in the caller's order (default: Morton order of closest approach)
- *   NO_MID_ORDER  hand the mid-points to waves as (16 rays x 4 samples) tiles, not by depth buckets */
+ *   NO_MID_ORDER  hand the mid-points to waves as (16 rays x 4 samples) tiles, not by depth buckets
+ *   EAGER_NABLAS  (calc_normal) evaluate the nabla of every sample point inside the sampling passes instead of
+ *                 afterwards and only where the sample's visibility weight is not zero */
 #define NM_RENDER_FULL_PROBES 1u
 #define NM_RENDER_NO_ZERO_SKIP 2u
 #define NM_RENDER_NO_RAY_SORT 4u
 #define NM_RENDER_NO_MID_ORDER 8u
+#define NM_RENDER_EAGER_NABLAS 16u
 
 int64_t nm_render_workspace_bytes(const nm_render_cfg* cfg, int64_t R);
 

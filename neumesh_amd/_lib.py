@@ -47,7 +47,7 @@ class RenderCfg(C.Structure):
 
 
 # nm_render_cfg.flags (include/neumesh_hip.h)
-RENDER_FULL_PROBES, RENDER_NO_ZERO_SKIP, RENDER_NO_RAY_SORT, RENDER_NO_MID_ORDER = 1, 2, 4, 8
+RENDER_FULL_PROBES, RENDER_NO_ZERO_SKIP, RENDER_NO_RAY_SORT, RENDER_NO_MID_ORDER, RENDER_EAGER_NABLAS = 1, 2, 4, 8, 16
 
 
 class Camera(C.Structure):

@@ -267,7 +267,7 @@ int nm_knn(nm_grid_t g, const float* q, int64_t Q, int K, int64_t* idx, float* d
     return 0;
 }
 
-static const NmRecMap NM_COMPACT = {1, 0, 0, nullptr};
+static const NmRecMap NM_COMPACT = {1, 0, 0, nullptr, 0};
 
 struct NmGather {  // optional gather-interpolation outputs of the distance kernel
     const float* geo_table; int gdim; float* fg;
@@ -862,6 +862,11 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     // deterministic kernel => bit-identical record), and every later search is warm-started with
     // the cached K-th-neighbour radius of the neighbouring sample on its ray.
     const bool want_grad = c->calc_normal != 0;
+    // (decided further down; needed here already) zero-weight skip active => the nablas of the N sample points are
+    // evaluated AFTER the sampling passes, and only where the visibility weight is not zero (see below)
+    const bool lazy_nabla_possible = want_grad && f->precision == 2 && !(dbg && (dbg->nablas_all || dbg->radiance)) &&
+                                     nm_mid_group_rays(c, c->N_samples + c->N_importance) > 0 &&
+                                     !(c->flags & (NM_RENDER_NO_MID_ORDER | NM_RENDER_NO_ZERO_SKIP | NM_RENDER_EAGER_NABLAS));
     const NmGather ga_slots = {t->geometry_features, f->geo.gdim, ws.slots.fg, nullptr, 0, nullptr};
     src.mode = 2;
     src.chain = nm_chain_tiles(c, R, c->N_samples);
@@ -878,10 +883,11 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     // value rows of the tangent kernel are bit-identical to the forward-only kernel, so the nablas
     // are written per slot now (into the buffer the mid-point pass overwrites later) and merely
     // permuted at the end -- instead of a second pass of N evaluations per ray.
-    float* nab_slot = want_grad ? ws.nab_mid : nullptr;
+    const bool eager_nabla = want_grad && !lazy_nabla_possible;   // tangent rows in the sampling passes themselves
+    float* nab_slot = eager_nabla ? ws.nab_mid : nullptr;
     {
-        const NmRecMap rm = {c->N_samples, cap, 0, nullptr};
-        if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, want_grad ? ws.slots.grad : nullptr, (long long)R * c->N_samples, want_grad, ws.sdf, c->N_samples, cap, 0, nab_slot, stream, rm, 1)) return 1;
+        const NmRecMap rm = {c->N_samples, cap, 0, nullptr, 0};
+        if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, want_grad ? ws.slots.grad : nullptr, (long long)R * c->N_samples, eager_nabla, ws.sdf, c->N_samples, cap, 0, nab_slot, stream, rm, 1)) return 1;
     }
     if (dbg && dbg->sdf_coarse) {
         hipLaunchKernelGGL(nm_rows_out_kernel, dim3(nm_blocks(R * c->N_samples, 256)), dim3(256), 0, stream, ws.sdf, (long long)R, c->N_samples, cap, perm, dbg->sdf_coarse);
@@ -918,8 +924,8 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
                 src.order_rays = fine_g;
             }
             if (nm_launch_distance(g, src, (long long)R * n_new, t->indicator_vector, t->indicator_weight, ws.slots.ds, nullptr, nullptr, nullptr, want_grad ? ws.slots.grad : nullptr, stream, ws.radius, ga_slots)) return 1;
-            const NmRecMap rm = {n_new, cap, n, nullptr};
-            if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, want_grad ? ws.slots.grad : nullptr, (long long)R * n_new, want_grad, ws.sdf, n_new, cap, n, nab_slot, stream, rm, 1)) return 1;
+            const NmRecMap rm = {n_new, cap, n, nullptr, 0};
+            if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, want_grad ? ws.slots.grad : nullptr, (long long)R * n_new, eager_nabla, ws.sdf, n_new, cap, n, nab_slot, stream, rm, 1)) return 1;
             n += n_new;
             pending = n_new;
         }
@@ -929,7 +935,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     // SDF (+ nablas) at all N sample points (renderer.py:264, 271-276): no new search and no new
     // MLP pass -- the SDF values merged above ARE forward_with_nablas(pts)[0] (same points, same
     // arithmetic), the nablas are brought into sorted order through the slot permutation.
-    if (c->calc_normal) {
+    if (eager_nabla) {
         hipLaunchKernelGGL(nm_permute_rows3_kernel, dim3(nm_blocks(R * N, 256)), dim3(256), 0, stream, nab_slot, ws.slot, (long long)R, cap, N, ws.nab_pts);
         NM_LAUNCH_CHECK();
     }
@@ -958,6 +964,16 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
         smap.P = N - 1;
         smap.E = (mid_g * (N - 1) + 63) & ~63;
         mid_pts = ((long long)(R + mid_g - 1) / mid_g) * smap.E;  // list positions (incl. padding)
+    }
+    // Nablas of the N sample points (renderer.py:271-276) where they can reach the normals at all: sample j enters
+    // normals_volume with visibility weight w_j (renderer.py:336-341), the same weight the mid-point list was cut by, so
+    // the list's (ray, j) entries are exactly the sample points that need a nabla.  Their K-NN records sit in the slot
+    // arrays of the sampling passes (which therefore ran the forward-only MLP: 64 instead of 32 points per tile, no
+    // tangent rows); the tangent kernel reads them through the slot permutation and writes nab_pts[ray][j].
+    if (want_grad && !eager_nabla) {
+        if (!(use_order && skip_zero)) return nm_fail("nm_render_rays: internal: lazy nablas need the zero-weight list");
+        const NmRecMap rm = {N - 1, cap, 0, ws.slot, 1};
+        if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, ws.slots.grad, mid_pts, true, nullptr, 1, N, 0, ws.nab_pts, stream, rm, 1, smap, true)) return 1;
     }
     src.mode = 1;
     src.P = N - 1;
@@ -1096,7 +1112,7 @@ int nm_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* unit
     std::lock_guard<std::mutex> lk(g_prof.mu);
     double ms = 0.0;
     int64_t n = 0, u = 0;
-    bool used[NM_CNT_N] = {false, false};
+    int used[NM_CNT_N] = {0, 0};   // launches of this kind that processed "counter i" points
     for (auto& r : g_prof.recs) {
         if (r.kind != kind) continue;
         if (hipEventSynchronize(r.b) != hipSuccess) return nm_fail("nm_profile_read: event sync failed");
@@ -1105,13 +1121,22 @@ int nm_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* unit
         ms += e;
         n += 1;
         u += r.units;
-        if (r.counter >= 0 && r.counter < NM_CNT_N) used[r.counter] = true;
+        if (r.counter >= 0 && r.counter < NM_CNT_N) used[r.counter] += 1;
     }
-    if (g_prof.counters && (used[0] || used[1])) {  // every kind that used a counter processed those points once
+    if (g_prof.counters && (used[0] || used[1])) {  // every such launch processed the counted points once per frame
         unsigned long long c[NM_CNT_N] = {0, 0};
         NM_HIP(hipMemcpy(c, g_prof.counters, sizeof(c), hipMemcpyDeviceToHost));
+        // The device counters accumulate over all calls since nm_profile_enable (one increment per call: the mid-point
+        // list / the probe walk); a kind with k counted launches per call therefore processed k * counter points.  The
+        // number of calls = the colour kernel's counted launches (exactly one per call).
+        int calls = 0;
+        for (auto& r : g_prof.recs)
+            if (r.kind == NM_K_COLOR && r.counter == NM_CNT_MID) ++calls;
         for (int i = 0; i < NM_CNT_N; ++i)
-            if (used[i]) u += (int64_t)c[i];
+            if (used[i]) {
+                const int k = (i == NM_CNT_MID && calls > 0) ? (used[i] + calls - 1) / calls : 1;
+                u += (int64_t)c[i] * k;
+            }
     }
     *total_ms = ms;
     *launches = n;

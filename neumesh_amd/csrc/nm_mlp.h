@@ -61,6 +61,9 @@ struct NmLayer {
 struct NmRecMap {
     int P, stride, off;
     const int* slot;
+    // by_list (nm_mlp_h2.h geometry kernel with a point list): the list entry names (ray, sample position p); the
+    // record is ray*stride + slot[ray*stride + off + p] and the outputs go to ray*out_stride + out_off + p
+    int by_list;
 };
 __device__ __forceinline__ long long nm_rec_index(const NmRecMap& m, long long q) {
     if (m.stride == 0) return q;
@@ -78,6 +81,11 @@ struct NmDivBase {
 __device__ __forceinline__ NmDivBase nm_div_base(long long base, int P) {
     NmDivBase d;
     d.P = (unsigned)P;
+    if (P == 1) {  // compact lists (the mid-point pass): no division at all
+        d.r0 = base;
+        d.p0 = 0u;
+        return d;
+    }
     d.r0 = base / P;
     d.p0 = (unsigned)(base - d.r0 * P);
     return d;

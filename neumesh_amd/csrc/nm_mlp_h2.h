@@ -452,6 +452,25 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
     const long long base = (long long)blockIdx.x * PTS;
     if (smap.order && smap.order[base] == 0xffffu) return;  // no point in this tile (valid entries lead each group)
     const NmDivBase rdiv = nm_div_base(base, rmap.stride ? rmap.P : 1), odiv = nm_div_base(base, P);
+    // by_list: records and outputs addressed by the (ray, sample) the list entry names (the nablas of the sample points
+    // whose visibility weight is not zero, evaluated after the sampling passes from their slot records)
+    const bool by_list = rmap.by_list && smap.order;
+    const long long ray0 = by_list ? (base / smap.E) * smap.G : 0;  // uniform: one division per workgroup
+    auto locate = [&](int p_local, long long& rq, long long& oidx) {   // record index / (ray, sample) output index of point base + p_local
+        if (by_list) {
+            long long ray;
+            int sp;
+            nm_slot_ray(smap, base + p_local, ray0, ray, sp);
+            rq = ray * rmap.stride + (rmap.slot ? (long long)rmap.slot[ray * rmap.stride + rmap.off + sp] : rmap.off + sp);
+            oidx = ray * stride + off + sp;
+        } else {
+            rq = nm_rec_index_local(rmap, rdiv, base, p_local);
+            long long orow;
+            int op;
+            nm_div_local(odiv, p_local, orow, op);
+            oidx = orow * stride + off + op;
+        }
+    };
     nm_phase_stamp(0);
     constexpr int DEPTH0 = (FIXED && NABLA) ? NM_H2_DEPTH0 : 2;  // layer-0 prefetch distance (nm_kloop_h2); the rolled loops use one set
     NmBPre<NM_H_CT> pre;
@@ -475,8 +494,9 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
         in_ds[rd] = 0.f;
         in_fg[rd][0] = in_fg[rd][1] = make_float4(0.f, 0.f, 0.f, 0.f);
         in_ok[rd] = base + p < npts && nm_slot_valid(smap, base + p);
-        if (NM_H2_EARLY_LOADS ? (base + p < npts) : in_ok[rd]) {
-            const long long rq = nm_rec_index_local(rmap, rdiv, base, p);
+        if ((NM_H2_EARLY_LOADS && !by_list) ? (base + p < npts) : in_ok[rd]) {
+            long long rq, unused_o;
+            locate(p, rq, unused_o);
             in_ds[rd] = ds[rq];
             if (j < nchunk) in_fg[rd][0] = *reinterpret_cast<const float4*>(fg_rec + rq * gdim + 4 * j);
             if (j + 8 < nchunk) in_fg[rd][1] = *reinterpret_cast<const float4*>(fg_rec + rq * gdim + 4 * (j + 8));
@@ -550,14 +570,11 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
         const long long q = base + t;
         if (q < npts && nm_slot_valid(smap, q)) {
             const float sdf = ((red[t] + red[NM_ROWS + t]) + (red[2 * NM_ROWS + t] + red[3 * NM_ROWS + t])) + prm.bd;
-            long long orow;
-            int op;
-            nm_div_local(odiv, t, orow, op);
-            const long long oidx = orow * stride + off + op;  // (ray, sample) addressed output position
+            long long rq, oidx;  // record / (ray, sample) addressed output position
+            locate(t, rq, oidx);
             if (sdf_out) sdf_out[oidx] = sdf;
             if (NABLA && nabla_out) {
                 const float dsdf = ((red[32 + t] + red[NM_ROWS + 32 + t]) + (red[2 * NM_ROWS + 32 + t] + red[3 * NM_ROWS + 32 + t])) * (1.0f / NM_TANGENT_SCALE);
-                const long long rq = nm_rec_index_local(rmap, rdiv, base, t);
                 const long long no = nabla_slotted ? oidx : q;
                 nabla_out[no * 3 + 0] = dsdf * grad[rq * 3 + 0];
                 nabla_out[no * 3 + 1] = dsdf * grad[rq * 3 + 1];

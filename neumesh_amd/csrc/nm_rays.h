@@ -225,7 +225,9 @@ NM_HD void nm_ray_composite(const float* sdf, const float* d, int N, float s, co
             b = nm_add(b, nm_mul(w, rgb_mid[3 * j + 2]));
         }
         wsum = nm_add(wsum, w);
-        if (nablas) {
+        // (normals: a zero-weight term adds +-0 to the sums, i.e. nothing; where the caller skipped the evaluation
+        //  -- evaluated_w given and 0 -- the nabla was never computed and must not be read)
+        if (nablas && (!evaluated_w || evaluated_w[j] != 0.0f)) {
             const float ax = nablas[3 * j], ay = nablas[3 * j + 1], az = nablas[3 * j + 2];
             const float nn = fmaxf(nm_sqrt(nm_add(nm_add(nm_mul(ax, ax), nm_mul(ay, ay)), nm_mul(az, az))), 1e-12f);
             nx = nm_add(nx, nm_mul(nm_div(ax, nn), w));

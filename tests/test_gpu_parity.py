@@ -401,13 +401,14 @@ def test_render_frame_properties_dtu_scale(dtu_scale, cuda_device, torch_mod):
     try:
         with torch.no_grad():
             for env in ({"NEUMESH_NO_ZERO_SKIP": "1"}, {"NEUMESH_MID_GROUP": "16"}, {"NEUMESH_MID_GROUP": "32"}, {"NEUMESH_NO_MID_ORDER": "1"},
-                        {"NEUMESH_NO_RAY_SORT": "1"}):   # (rays processed in the caller's order instead of Morton order)
+                        {"NEUMESH_NO_RAY_SORT": "1"},    # (rays processed in the caller's order instead of Morton order)
+                        {"NEUMESH_EAGER_NABLAS": "1"}):  # (sample-point nablas inside the sampling passes, all of them)
                 os.environ.update(env)
                 variants.append(volume_render(_t(o, cuda_device), _t(d, cuda_device), model, rayschunk=16384, **kw))
                 for k in env:
                     os.environ.pop(k)
     finally:
-        for k in ("NEUMESH_NO_ZERO_SKIP", "NEUMESH_MID_GROUP", "NEUMESH_NO_MID_ORDER", "NEUMESH_NO_RAY_SORT"):
+        for k in ("NEUMESH_NO_ZERO_SKIP", "NEUMESH_MID_GROUP", "NEUMESH_NO_MID_ORDER", "NEUMESH_NO_RAY_SORT", "NEUMESH_EAGER_NABLAS"):
             os.environ.pop(k, None)
     for v_rgb, v_depth, v_ex in variants:
         assert torch.equal(v_rgb, b_rgb) and torch.equal(v_depth, b_depth) and torch.equal(v_ex["mask_volume"], b_ex["mask_volume"])
