@@ -53,8 +53,8 @@ int nm_device_count(void);
 
 /* ----------------------------------------------------------------------------- spatial index
  * Builds the search structure over `V` vertices (device, [V,3] fp32, row-major).
- * leaf_level = 0 picks the octree depth automatically (about 8-12 vertices per occupied
- * leaf).  The vertex data is COPIED (sorted copy lives in the handle); `verts` may be
+ * leaf_level = 0 picks the octree depth automatically (the smallest depth with <= 40 vertices
+ * per occupied leaf on average).  The vertex data is COPIED (sorted copy lives in the handle); `verts` may be
  * freed afterwards.  The build runs on the device (Morton codes, radix sort, per-level node
  * kernels; a deformed mesh is re-indexed in about a millisecond); a few scalars -- bounding box,
  * per-level node counts -- pass through the host, so the call synchronises `stream`. */

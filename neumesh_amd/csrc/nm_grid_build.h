@@ -79,7 +79,7 @@ static inline bool nm_build_host_grid(const float* verts, int64_t V, int leaf_le
             std::vector<uint32_t> s(codes);
             std::sort(s.begin(), s.end());
             const size_t occ = (size_t)(std::unique(s.begin(), s.end()) - s.begin());
-            if ((double)V / (double)occ <= 12.0) break;
+            if ((double)V / (double)occ <= NM_LEAF_TARGET) break;
         }
     }
     L = std::min(std::max(L, 1), NM_MAX_LEVEL);

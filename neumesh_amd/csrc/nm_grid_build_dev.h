@@ -8,7 +8,7 @@
 // 1.4e5 vertices and the upload.  Here all O(V) work runs on the GPU:
 //   1. bounding box (block reduction + atomics on order-preserving keys)            -> 6 floats to the host
 //   2. level-8 Morton codes, one keys-only radix sort, occupied cells per level     -> 7 counts to the host,
-//      which picks the leaf level L exactly as the host build does (<= 12 vertices per occupied leaf)
+//      which picks the leaf level L exactly as the host build does (<= NM_LEAF_TARGET vertices per occupied leaf)
 //   3. radix sort of (level-L code, vertex index) pairs (stable: ties by index), gather of the sorted vertices
 //   4. per level, leaves first: segment heads by adjacent-difference + exclusive scan, tight boxes by one thread
 //      per node over its vertices / children                                         -> 1 count per level to the host
@@ -267,7 +267,7 @@ static hipError_t nm_build_device_grid(const float* verts, long long V, int leaf
         g.oz = 0.5f * (lo[2] + hi[2]) - 0.5f * g.root_size;
         g.slack = 4e-6f * (amax + g.root_size);
     }
-    // ---- 2. leaf level: smallest depth with <= 12 vertices per occupied leaf on average (as the host build)
+    // ---- 2. leaf level: smallest depth with <= NM_LEAF_TARGET vertices per occupied leaf on average (as the host build)
     if (L <= 0) {
         hipLaunchKernelGGL(nm_codes_kernel, blocks(V), dim3(T), 0, stream, verts, V, g, NM_MAX_LEVEL, code_a, (uint32_t*)nullptr);
         size_t tb = tmp_bytes;
@@ -277,7 +277,7 @@ static hipError_t nm_build_device_grid(const float* verts, long long V, int leaf
         NM_DG(hipMemcpyAsync(hcounts, small, sizeof(hcounts), hipMemcpyDeviceToHost, stream));
         NM_DG(hipStreamSynchronize(stream));
         for (L = 1; L < NM_MAX_LEVEL; ++L)
-            if ((double)V / (double)hcounts[L] <= 12.0) break;
+            if ((double)V / (double)hcounts[L] <= NM_LEAF_TARGET) break;
     }
     L = std::min(std::max(L, 1), NM_MAX_LEVEL);
     // ---- 3. vertices in (leaf code, index) order
