@@ -585,17 +585,37 @@ __device__ __forceinline__ NmRayLds nm_ray_lds(float* base, int cap) {
 }
 static inline size_t nm_ray_lds_bytes(int cap) { return (size_t)2 * 64 * (cap + 1) * 4 + (size_t)64 * (cap + 4); }
 
-// rows [0, n) of 64 rays: global -> LDS (slot == nullptr or first == true: identity slots)
+// rows [0, n) of 64 rays: global -> LDS (slot == nullptr or first == true: identity slots).
+// The (ray, sample) elements are walked as one flat range, eight per lane in flight: written as a row loop, every
+// iteration waited for its own two loads (s_waitcnt vmcnt(0) before the LDS store) -- 128 dependent memory round trips
+// per workgroup at one wave per SIMD, ~30 % of these kernels' time.
 __device__ __forceinline__ void nm_ray_rows_load(const NmRayLds& l, const float* __restrict__ d, const float* __restrict__ sdf,
                                                  const int* __restrict__ slot, bool identity, long long r0, long long R,
                                                  int cap, int n) {
     const int lane = threadIdx.x;
-    for (int rr = 0; rr < 64 && r0 + rr < R; ++rr) {
-        const long long g = (r0 + rr) * cap;
-        for (int j = lane; j < n; j += 64) {
-            l.d[rr * l.S + j] = d[g + j];
-            l.s[rr * l.S + j] = sdf[g + j];
-            if (slot) l.slot[rr * l.SB + j] = identity ? (unsigned char)j : (unsigned char)slot[g + j];
+    const int rows = (int)((R - r0) < 64 ? (R - r0) : 64);
+    const int total = rows * n;
+    constexpr int U = 8;
+    for (int e0 = 0; e0 < total; e0 += 64 * U) {
+        float dv[U], sv[U];
+        int sl[U], rr[U], jj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * 64 + lane;
+            const bool ok = e < total;
+            rr[u] = ok ? e / n : 0;
+            jj[u] = ok ? e - rr[u] * n : -1;
+            const long long g = (r0 + rr[u]) * cap + (ok ? jj[u] : 0);
+            dv[u] = ok ? d[g] : 0.f;
+            sv[u] = ok ? sdf[g] : 0.f;
+            sl[u] = (ok && slot && !identity) ? slot[g] : jj[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (jj[u] < 0) continue;
+            l.d[rr[u] * l.S + jj[u]] = dv[u];
+            l.s[rr[u] * l.S + jj[u]] = sv[u];
+            if (slot) l.slot[rr[u] * l.SB + jj[u]] = (unsigned char)sl[u];
         }
     }
     __syncthreads();
@@ -746,6 +766,7 @@ __global__ __launch_bounds__(256) void nm_rays_order_kernel(const float* __restr
                                                             int P, int G, int Npow2, unsigned short* __restrict__ order,
                                                             const float* __restrict__ wgt, unsigned long long* __restrict__ counter) {
     extern __shared__ unsigned long long nm_sort_keys[];
+    __shared__ int nm_cnt_total;
     const long long grp = blockIdx.x;
     const int n = G * P, E = (n + 63) & ~63;
     for (int i = threadIdx.x; i < Npow2; i += 256) {
@@ -763,9 +784,50 @@ __global__ __launch_bounds__(256) void nm_rays_order_kernel(const float* __restr
         nm_sort_keys[i] = ((unsigned long long)key << 32) | id;
     }
     __syncthreads();
-    for (int k = 2; k <= Npow2; k <<= 1) {
+    // Dropped samples (zero weight: often most of them) would only be sorted to the tail: compact the kept keys to the
+    // front first and sort just the next power of two above their number (bitonic cost ~ n log^2 n).
+    int nsort = Npow2;
+    if (wgt) {
+        __shared__ int nm_cnt[256];
+        const int per = Npow2 / 256;           // Npow2 >= 256 for every group size the callers use with a weight array
+        if (per >= 1 && per <= 32) {
+            unsigned long long mine[32];   // this thread's contiguous chunk, in registers (static indices only)
+            int c = 0;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                mine[u] = u < per ? nm_sort_keys[threadIdx.x * per + u] : ~0ull;
+                c += (mine[u] >> 32) != 0xffffffffull ? 1 : 0;
+            }
+            nm_cnt[threadIdx.x] = c;
+            __syncthreads();
+            if (threadIdx.x < 64) {  // exclusive scan of the 256 counts by one wave
+                int v[4], tot = 0;
+                for (int u = 0; u < 4; ++u) { v[u] = nm_cnt[threadIdx.x * 4 + u]; tot += v[u]; }
+                int incl = tot;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int up = __shfl_up(incl, o);
+                    if ((int)threadIdx.x >= o) incl += up;
+                }
+                int run = incl - tot;
+                for (int u = 0; u < 4; ++u) { nm_cnt[threadIdx.x * 4 + u] = run; run += v[u]; }
+                if (threadIdx.x == 63) nm_cnt_total = incl;
+            }
+            __syncthreads();
+            const int kept_all = nm_cnt_total;
+            int pos = nm_cnt[threadIdx.x];     // (every chunk has been read: in-place compaction is safe)
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                if ((mine[u] >> 32) != 0xffffffffull) nm_sort_keys[pos++] = mine[u];
+            nsort = 64;
+            while (nsort < kept_all) nsort <<= 1;
+            __syncthreads();
+            for (int i = kept_all + threadIdx.x; i < Npow2; i += 256) nm_sort_keys[i] = 0xffffffff0000ffffull;   // padding: behind every kept key
+            __syncthreads();
+        }
+    }
+    for (int k = 2; k <= nsort; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < Npow2; i += 256) {
+            for (int i = threadIdx.x; i < nsort; i += 256) {
                 const int x = i ^ j;
                 if (x > i) {
                     const unsigned long long a = nm_sort_keys[i], b = nm_sort_keys[x];
