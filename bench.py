@@ -25,7 +25,7 @@ Prints ONE JSON line (rank 0):
   cpu_baseline the CPU oracle (numpy + kd-tree K-NN) on a bounded ray sample of the same frame
   parity_vs_reference   the same frame's 1536 fixture rays against the imported reference's output
   extra        short runs (2 steps each, N = 1 only) of the variants the headline does not show:
-               data-independent frame, fp32 MLP, calc_normal=False, BASELINE config 3 shape, config 5
+               data-independent frame, fp32 MLP, calc_normal=False, BASELINE config 3 / 4 shapes, config 5
 """
 from __future__ import annotations
 
@@ -325,19 +325,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(steps, warmup, precision="f16x2", samples=128, normals=True, white=False, flags=0, keep_frame0=False, gather=True):
+    def run(steps, warmup, precision="f16x2", samples=128, normals=True, white=False, flags=0, keep_frame0=False, gather=True, hw=None):
         """warmup + `steps` timed frames of one variant; returns (elapsed s [max over ranks], profile dict, rgb of frame 0 or None)."""
         model.mlp_precision = precision
         cfg = make_render_cfg(calc_normal=normals, N_samples=samples // 2, N_importance=samples // 2, white_bkgd=white, flags=flags)
         total = warmup + steps
+        H, W = hw or (args.H, args.W)
+        r_intr = synthetic.pinhole_intrinsics(H, W) if hw else intr
         # every rank builds the rays of ITS frame of the orbit on ITS GPU (nm_make_rays): resident before timing
-        rays = [make_rays(synthetic.orbit_pose(s * world + rank), intr, args.H, args.W, dev) for s in range(total)]
+        rays = [make_rays(synthetic.orbit_pose(s * world + rank), r_intr, H, W, dev) for s in range(total)]
         tables = model.field_tables()
         model.field_handle()
-        gathered = torch.empty((world * n_rays, 8 if normals else 5), dtype=torch.float32, device=dev) if (world > 1 and gather) else None
+        gathered = torch.empty((world * H * W, 8 if normals else 5), dtype=torch.float32, device=dev) if (world > 1 and gather) else None
 
         def step(i):
-            ret = render_rays_fused(model, rays[i][0], rays[i][1], cfg, args.rayschunk or n_rays, tables=tables)
+            ret = render_rays_fused(model, rays[i][0], rays[i][1], cfg, args.rayschunk or n_rays, tables=tables)   # hw frames: chunks of one headline frame
             if gathered is not None:
                 packed, _ = pack_outputs(ret)
                 dist.all_gather_into_tensor(gathered, packed)   # the path's only collective: final pixels
@@ -430,7 +432,8 @@ def main():
                 try:
                     e, pr, _, _ = run(2, 1, **kw)
                     d, pp, a, pk, sp = mlp_summary(pr, kw.get("precision", "f16x2"))
-                    extra[name] = {"value": n_rays * 2 / e, "unit": "rays/s", "ms_per_frame": e / 2 * 1e3, "steps": 2,
+                    nr = kw["hw"][0] * kw["hw"][1] if "hw" in kw else n_rays
+                    extra[name] = {"value": nr * 2 / e, "unit": "rays/s", "ms_per_frame": e / 2 * 1e3, "steps": 2,
                                    "dominant_kernel": d, "achieved_tflops_algorithmic": a, "frac_of_pipe_peak": a / pk,
                                    "knn_ms_per_frame": pr["knn_distance"]["ms"] / 2, "knn_searched_per_frame": pr["knn_distance"]["points"] / 2,
                                    "mlp_points_per_frame": {k: pr[k]["points"] / 2 for k in ("geo_mlp", "geo_mlp_tangent", "color_mlp")}}
@@ -441,6 +444,7 @@ def main():
             short("mlp_precision_fp32 (fp32-input MFMA)", precision="fp32")
             short("calc_normal_false", normals=False)
             short("config3_shape (64 samples/ray, white background)", samples=64, white=True)
+            short("config4_shape (1600x1200 rays/frame in chunks of one 800x800 frame, 64+64 samples)", hw=(1200, 1600))
             model.mlp_precision = args.mlp_precision
         if world == 1 and args.cpu_rays > 0:
             try:
