@@ -343,6 +343,7 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
     for (int l = 0; l < d->D_density; ++l) need += (size_t)NM_W * nm_round16(l == 0 ? in_geo : NM_W) + NM_W;
     for (int l = 0; l < d->D_color; ++l) need += (size_t)NM_W * nm_round16(l == 0 ? in_col : NM_W) + NM_W;
     need += NM_W + 3 * NM_W + 64;
+    need += (size_t)(d->D_density + 1) * NM_W;  // precision 2: geometry biases and density weights in log2 units (nm_mlp_h2.h)
     if (need > f->blob_floats) {
         if (f->blob) hipFree(f->blob);
         f->blob = nullptr;
@@ -439,12 +440,20 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
         _Float16* ph = f->blob_h;
         memset(&f->geo_h2, 0, sizeof(f->geo_h2));
         memset(&f->col_h2, 0, sizeof(f->col_h2));
-        auto pack_h2 = [&](const float* src, int in_dim, const NmColSeg& seg, NmLayerH& L, const float* packed_bias) {
+        auto pack_h2 = [&](const float* src, int in_dim, const NmColSeg& seg, NmLayerH& L, const float* packed_bias, float scale) {
             L.Kpad = nm_round16(in_dim);
             L.W = ph;
             L.b = packed_bias;
-            hipLaunchKernelGGL(nm_pack_weight_h2_kernel, dim3(nm_blocks((long long)NM_W * L.Kpad, 256)), dim3(256), 0, stream, src, in_dim, L.Kpad, seg, ph);
+            hipLaunchKernelGGL(nm_pack_weight_h2_kernel, dim3(nm_blocks((long long)NM_W * L.Kpad, 256)), dim3(256), 0, stream, src, in_dim, L.Kpad, seg, scale, ph);
             ph += (size_t)NM_W * L.Kpad * 2;
+        };
+        // geometry MLP in log2 units: biases x S, density weights x 1/S (fp32 copies behind the unscaled ones), layer-0 weights x S
+        float* ps = p;
+        auto scaled = [&](const float* src, float scale) -> const float* {
+            float* dst = ps;
+            hipLaunchKernelGGL(nm_scale_copy_kernel, dim3(1), dim3(NM_W), 0, stream, src, scale, NM_W, dst);
+            ps += NM_W;
+            return dst;
         };
         NmColSeg ident;
         memset(&ident, 0, sizeof(ident));
@@ -472,11 +481,13 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
         sc.len[3] = 3;   sc.src[3] = lo_v;
         sc.len[4] = nb;  sc.src[4] = 0;
         sc.len[5] = 1;   sc.src[5] = lo_d;
-        for (int l = 0; l < d->D_density; ++l) pack_h2(d->geo_weight[l], l == 0 ? in_geo : NM_W, l == 0 ? sg : ident, f->geo_h2.layer[l], f->geo.layer[l].b);
-        for (int l = 0; l < d->D_color; ++l) pack_h2(d->col_weight[l], l == 0 ? in_col : NM_W, l == 0 ? sc : ident, f->col_h2.layer[l], f->col.layer[l].b);
+        for (int l = 0; l < d->D_density; ++l)
+            pack_h2(d->geo_weight[l], l == 0 ? in_geo : NM_W, l == 0 ? sg : ident, f->geo_h2.layer[l], scaled(f->geo.layer[l].b, NM_H2_S), l == 0 ? NM_H2_S : 1.0f);
+        for (int l = 0; l < d->D_color; ++l) pack_h2(d->col_weight[l], l == 0 ? in_col : NM_W, l == 0 ? sc : ident, f->col_h2.layer[l], f->col.layer[l].b, 1.0f);
+        f->geo_h2.wd = scaled(f->geo.wd, 1.0f / NM_H2_S);
         NM_LAUNCH_CHECK();
         NM_HIP(hipStreamSynchronize(stream));
-        f->geo_h2.D = f->geo.D; f->geo_h2.wd = f->geo.wd; f->geo_h2.bd = f->geo.bd;
+        f->geo_h2.D = f->geo.D; f->geo_h2.bd = f->geo.bd;
         f->geo_h2.multires_d = f->geo.multires_d; f->geo_h2.multires_fg = f->geo.multires_fg; f->geo_h2.gdim = f->geo.gdim;
         f->geo_h2.fg_w = FG; f->geo_h2.in_dim = f->geo.in_dim;
         f->col_h2.D = f->col.D; f->col_h2.wrgb = f->col.wrgb;

@@ -298,11 +298,17 @@ __device__ void nm_mlp_layer_valu(float* act, float* tmp /*[64][256] global*/, c
 // minimax polynomials on [-pi/4, pi/4].  Max abs error vs float64 9.2e-8 for |x| <= 1e5 (libm
 // fp32: 7e-8), checked in tests/test_hostlogic.py::test_fast_sincos_formula; larger arguments
 // take the libm path.
+#define NM_SINCOS_FAST_MAX 1.0e5f  // beyond: libm's sincosf (full range reduction)
+__device__ __forceinline__ void nm_sincos_fast(float x, float* sn, float* cs);
 __device__ __forceinline__ void nm_sincos(float x, float* sn, float* cs) {
-    if (fabsf(x) > 1.0e5f) {
+    if (fabsf(x) > NM_SINCOS_FAST_MAX) {
         sincosf(x, sn, cs);
         return;
     }
+    nm_sincos_fast(x, sn, cs);
+}
+// |x| <= NM_SINCOS_FAST_MAX (the caller has checked): three-term Cody-Waite reduction + degree-7 / degree-8 polynomials
+__device__ __forceinline__ void nm_sincos_fast(float x, float* sn, float* cs) {
     const float k = rintf(x * 0.63661977236758134f);
     float r = fmaf(k, -1.57079637050628662109e+00f, x);
     r = fmaf(k, 4.37113882867379288655e-08f, r);

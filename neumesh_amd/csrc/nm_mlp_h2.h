@@ -54,7 +54,7 @@ struct NmColSeg {
 // weights: fp32 [256][in_dim] (PyTorch layout, logical columns) -> split halves in MFMA A-operand
 // fragment order [column tile 8][k-step Kpad/16][plane 2][lane 64][8 halves]; lane = (row i of the
 // tile) | (k-half << 5) with row i = 4h + 8g + e holding output column 16h + 4g + e (header comment).
-__global__ void nm_pack_weight_h2_kernel(const float* __restrict__ src, int in_dim, int Kpad, NmColSeg seg, _Float16* __restrict__ dst) {
+__global__ void nm_pack_weight_h2_kernel(const float* __restrict__ src, int in_dim, int Kpad, NmColSeg seg, float scale, _Float16* __restrict__ dst) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (n, k)
     if (e >= NM_W * Kpad) return;
     const int n = e / Kpad, k = e - n * Kpad;
@@ -63,7 +63,7 @@ __global__ void nm_pack_weight_h2_kernel(const float* __restrict__ src, int in_d
         if (kl < 0 && k >= base && k < base + seg.len[s]) kl = seg.src[s] + (k - base);
         base += seg.len[s];
     }
-    const float w = (kl >= 0 && kl < in_dim) ? src[(size_t)n * in_dim + kl] : 0.f;
+    const float w = (kl >= 0 && kl < in_dim) ? src[(size_t)n * in_dim + kl] * scale : 0.f;
     _Float16 h1, h2;
     nm_split_half(w, &h1, &h2);
     const int ct = n >> 5, c = n & 31;
@@ -75,10 +75,15 @@ __global__ void nm_pack_weight_h2_kernel(const float* __restrict__ src, int in_d
     dst[o + 64 * 8 + (size_t)lane * 8 + el] = h2;
 }
 
+__global__ void nm_scale_copy_kernel(const float* __restrict__ src, float scale, int n, float* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] * scale;
+}
+
 struct NmGeoParamsH2 {
-    NmLayerH layer[NM_MAX_LAYERS];
+    NmLayerH layer[NM_MAX_LAYERS];  // log2 units (nm_softplus_l2): layer 0 weights and every bias x S
     int D;
-    const float* wd;  // [256]
+    const float* wd;  // [256], x 1/S
     float bd;
     int multires_d, multires_fg, gdim;
     int fg_w, in_dim;  // fg_w = gdim*(1+2*multires_fg): width of the code-embedding block = first column of the ds block
@@ -100,6 +105,17 @@ __device__ __forceinline__ void nm_h2_split(float a, _Float16& h1, _Float16& h2)
     h1 = (_Float16)a;
     h2 = (_Float16)fmaf((float)h1, -2048.0f, a * 2048.0f);
 }
+// Two values at once, as packed pairs (low half = a): h1 = one v_cvt_pk_f16_f32, the residuals by v_fma_mix{lo,hi}_f16,
+// which read their f16 operand straight from the packed pair and round the fp32 fma result to f16 once -- the same
+// arithmetic as nm_h2_split, 4 instructions per pair instead of 6 (the compiler only finds the mix form now and then).
+__device__ __forceinline__ void nm_h2_split2(float a, float b, unsigned& p1, unsigned& p2) {
+    p1 = __builtin_bit_cast(unsigned, nm_h2{(_Float16)a, (_Float16)b});
+    const float a2 = a * 2048.0f, b2 = b * 2048.0f, m = -2048.0f;
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p1), "s"(m), "v"(a2));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(p1), "s"(m), "v"(b2));
+    p2 = r;
+}
 // (mx: running max of |value| for the fp16-range check; pairs go through one max3)
 __device__ __forceinline__ void nm_h2_store1(_Float16* p, float a, float& mx) {
     _Float16 h1, h2;
@@ -109,40 +125,31 @@ __device__ __forceinline__ void nm_h2_store1(_Float16* p, float a, float& mx) {
     mx = fmaxf(mx, fabsf(a));
 }
 __device__ __forceinline__ void nm_h2_store2(_Float16* p, float a, float b, float& mx) {  // p 4-byte aligned
-    _Float16 a1, a2, b1, b2;
-    nm_h2_split(a, a1, a2);
-    nm_h2_split(b, b1, b2);
-    *reinterpret_cast<nm_h2*>(p) = nm_h2{a1, b1};
-    *reinterpret_cast<nm_h2*>(p + NM_H_PLANE) = nm_h2{a2, b2};
+    unsigned p1, p2;
+    nm_h2_split2(a, b, p1, p2);
+    *reinterpret_cast<unsigned*>(p) = p1;
+    *reinterpret_cast<unsigned*>(p + NM_H_PLANE) = p2;
     mx = fmaxf(mx, fmaxf(fabsf(a), fabsf(b)));
 }
 __device__ __forceinline__ void nm_h2_store4(_Float16* p, const float (&v)[4], float& mx) {  // p 8-byte aligned
-    nm_h4 a, b;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        _Float16 h1, h2;
-        nm_h2_split(v[e], h1, h2);
-        a[e] = h1;
-        b[e] = h2;
-    }
+    uint2 a, b;
+    nm_h2_split2(v[0], v[1], a.x, b.x);
+    nm_h2_split2(v[2], v[3], a.y, b.y);
     mx = fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1])));
     mx = fmaxf(mx, fmaxf(fabsf(v[2]), fabsf(v[3])));
-    *reinterpret_cast<nm_h4*>(p) = a;
-    *reinterpret_cast<nm_h4*>(p + NM_H_PLANE) = b;
+    *reinterpret_cast<uint2*>(p) = a;
+    *reinterpret_cast<uint2*>(p + NM_H_PLANE) = b;
 }
 __device__ __forceinline__ void nm_h2_store8(_Float16* p, const float (&v)[8], float& mx) {  // p 16-byte aligned
-    nm_h8 a, b;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        _Float16 h1, h2;
-        nm_h2_split(v[e], h1, h2);
-        a[e] = h1;
-        b[e] = h2;
-    }
+    uint4 a, b;
+    nm_h2_split2(v[0], v[1], a.x, b.x);
+    nm_h2_split2(v[2], v[3], a.y, b.y);
+    nm_h2_split2(v[4], v[5], a.z, b.z);
+    nm_h2_split2(v[6], v[7], a.w, b.w);
 #pragma unroll
     for (int e = 0; e < 8; e += 2) mx = fmaxf(fmaxf(mx, fabsf(v[e])), fabsf(v[e + 1]));
-    *reinterpret_cast<nm_h8*>(p) = a;
-    *reinterpret_cast<nm_h8*>(p + NM_H_PLANE) = b;
+    *reinterpret_cast<uint4*>(p) = a;
+    *reinterpret_cast<uint4*>(p + NM_H_PLANE) = b;
 }
 // zero columns [c0, c1) of a tile row, both planes (c0 a multiple of 8: 16-byte stores, then singles)
 __device__ __forceinline__ void nm_h2_zero_cols(_Float16* row, int c0, int c1, int j) {
@@ -161,14 +168,17 @@ __device__ __forceinline__ void nm_h2_zero_cols(_Float16* row, int c0, int c1, i
 // x and its sin/cos bands for 4 consecutive dims of a `dim`-wide code vector, into an embedding block
 // that starts at blk[0]: 8-byte stores (dim is a multiple of 4).  Odd bands from the even band below
 // by the double-angle identities, as nm_embed4_h.
-__device__ __forceinline__ void nm_h2_embed_chunk(_Float16* blk, int dim, int bands, int chunk, float4 x, float& mx) {
-    const float xs[4] = {x.x, x.y, x.z, x.w};
+template <bool FAST>
+__device__ __forceinline__ void nm_h2_embed_chunk_t(_Float16* blk, int dim, int bands, int chunk, const float (&xs)[4], float& mx) {
     nm_h2_store4(blk + 4 * chunk, xs, mx);
     float f = 1.0f;
     for (int b = 0; b < bands; b += 2) {
         float s[4], c[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) nm_sincos(xs[e] * f, &s[e], &c[e]);
+        for (int e = 0; e < 4; ++e) {
+            if (FAST) nm_sincos_fast(xs[e] * f, &s[e], &c[e]);
+            else nm_sincos(xs[e] * f, &s[e], &c[e]);
+        }
         nm_h2_store4(blk + dim * (1 + 2 * b) + 4 * chunk, s, mx);
         nm_h2_store4(blk + dim * (2 + 2 * b) + 4 * chunk, c, mx);
         if (b + 1 < bands) {
@@ -184,6 +194,32 @@ __device__ __forceinline__ void nm_h2_embed_chunk(_Float16* blk, int dim, int ba
         f *= 4.0f;
     }
 }
+// One range test per chunk instead of one per sincos: the straight-line fast path (every argument within the polynomial
+// reduction's range -- always, for trained codes) lets the four evaluations of a band overlap; same values either way.
+__device__ __forceinline__ void nm_h2_embed_chunk(_Float16* blk, int dim, int bands, int chunk, float4 x, float& mx) {
+    const float xs[4] = {x.x, x.y, x.z, x.w};
+    const float top = fmaxf(fmaxf(fabsf(xs[0]), fabsf(xs[1])), fmaxf(fabsf(xs[2]), fabsf(xs[3]))) * (float)(1 << ((bands > 0 ? bands - 1 : 0) & ~1));  // (largest frequency evaluated directly: the highest even band)
+    if (top <= NM_SINCOS_FAST_MAX) nm_h2_embed_chunk_t<true>(blk, dim, bands, chunk, xs, mx);
+    else nm_h2_embed_chunk_t<false>(blk, dim, bands, chunk, xs, mx);
+}
+
+// Softplus(beta = 100) in "log2 units".  With S = 100 / ln 2 the reference's y = softplus(z) = log2(1 + 2^(S z)) / S, so
+// carrying m = S y between the geometry layers instead of y makes the activation m = log2(1 + 2^z') of the
+// pre-activation z' = S z, and the next layer's z' = S (W y + b) = W m + S b needs NO rescaling of its weights:
+// only layer 0's weights (x S), every bias (x S) and the density head (x 1/S) are scaled, once, when the field is
+// packed (nm_field_pack).  Two multiplies per element less than softplus100 on unscaled values, and the exponent
+// argument comes straight from the accumulator.  Clamp, threshold behaviour and gradient as nm_softplus100
+// (30.2965958 = 21 log2 e <-> 100 z = 21); d m / d z' = d y / d z = 2^z' / (1 + 2^z'), so tangent rows carry S dy
+// the same way and the scaled head returns d sdf.
+#define NM_H2_S 144.26950408889634f
+__device__ __forceinline__ float nm_softplus_l2(float zp, float* grad) {
+    const float e = __builtin_amdgcn_exp2f(fminf(zp, 30.2965958f));
+    const float u = 1.0f + e;
+    if (grad) *grad = e * __builtin_amdgcn_rcpf(u);
+    return fmaxf(zp, __builtin_amdgcn_logf(u));
+}
+// tangent rows enter layer 0 scaled by 2^-15 (~ 2^-8 / S: the same fp16 head room as the unscaled kernels' 2^-8)
+#define NM_H2_TANGENT_SCALE 3.0517578125e-05f
 
 // --------------------------------------------------------------------------------- K loop
 // As nm_kloop_h (B fragments two k-steps ahead in three rotating register sets, A fragments one step
@@ -246,9 +282,18 @@ __device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16*
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) c.hi[1][ct] = c.lo[1][ct] = nm_f32x16{0};
         }
+#ifdef NM_EXP_NOB
+        if (ks + DEPTH < KS) f[(ks + DEPTH) % (DEPTH + 1)] = pre.s[0];
+#else
         if (ks + DEPTH < KS) f[(ks + DEPTH) % (DEPTH + 1)] = nm_ld_bu<CT>(bp, lane, ks + DEPTH);
+#endif
+#ifdef NM_EXP_NOA
+        if (false) {
+            const int oa = 0;
+#else
         if (ks + 1 < KS) {
             const int oa = (ks + 1) * 16;
+#endif
             a[(ks + 1) & 1][0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
             a[(ks + 1) & 1][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
             if (ks + 1 >= KT0) {
@@ -257,10 +302,15 @@ __device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16*
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef NM_EXP_NOA
+#define NM_A_SEL a[0]
+#else
+#define NM_A_SEL a[ks & 1]
+#endif
         if (ks >= KT0) {
-            NM_H2_MFMAS(a[ks & 1], f[ks % (DEPTH + 1)], 2)
+            NM_H2_MFMAS(NM_A_SEL, f[ks % (DEPTH + 1)], 2)
         } else {
-            NM_H2_MFMAS(a[ks & 1], f[ks % (DEPTH + 1)], 1)
+            NM_H2_MFMAS(NM_A_SEL, f[ks % (DEPTH + 1)], 1)
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -341,11 +391,32 @@ __device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L
 #pragma unroll
     for (int c = 0; c < CT; ++c) bp[c] = nm_b_rsrc(L.W, L.Kpad, wave * CT + c);
     NmAccH<CT> c;
+    // the main accumulators of the value rows start at the bias (one add per element less in the epilogue); tangent rows at 0
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int ct = 0; ct < CT; ++ct) {
+        const int colb = n0 + 32 * ct + 16 * h;  // this lane's 16 columns of the tile: register r <-> column colb + r
+        float4 b4[4];
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-            if (rt == 0 || !(KSF > 0 && KT0F > 0)) c.hi[rt][ct] = c.lo[rt][ct] = nm_f32x16{0};  // (else: initialised at k-step KT0F)
+        for (int q = 0; q < 4; ++q) {
+            if (bias_row >= 0) {  // (two address spaces: LDS for the first layers, global beyond -- never a generic pointer)
+                b4[q] = *reinterpret_cast<const float4*>(cst + bias_row * NM_W + colb + 4 * q);
+            } else {  // (buffer loads: a different instruction class, so the two paths are never merged into flat loads)
+                const nm_rsrc rb = __builtin_amdgcn_make_buffer_rsrc((void*)L.b, 0, NM_W * 4, 0x00020000);
+                b4[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, (colb + 4 * q) * 4, 0, 0));
+            }
+        }
+        nm_f32x16 bv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bv[4 * q + 0] = b4[q].x; bv[4 * q + 1] = b4[q].y; bv[4 * q + 2] = b4[q].z; bv[4 * q + 3] = b4[q].w;
+        }
+        c.hi[0][ct] = bv;
+        c.lo[0][ct] = nm_f32x16{0};
+        if (!(KSF > 0 && KT0F > 0)) {  // (else: row tile 1 is initialised at k-step KT0F -- tangent rows, zero)
+            c.hi[1][ct] = TANGENT ? nm_f32x16{0} : bv;
+            c.lo[1][ct] = nm_f32x16{0};
+        }
+    }
     if (KSF > 0) nm_kloop_h2<(KSF > 0 ? KSF : 1), CT, KT0F, DEPTH>(a0p, a1p, bp, lane, pre, c);  // one straight-line loop, no run-time dispatch
     else nm_kloop_h2_generic<CT>(L.Kpad >> 4, kt0, a0p, a1p, bp, lane, pre, c);
     if (has_next) nm_prefetch_bn<CT>(next, pre, 2);
@@ -360,35 +431,24 @@ __device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {  // 8 columns at a time: one 16-byte store per row and plane, short live ranges
             const int col0 = n0 + 32 * ct + 16 * h + 8 * hf;  // this lane's columns: register 8*hf + r <-> column col0 + r
-            float4 b0, b1;  // (two address spaces: LDS for the first layers, global beyond -- never a generic pointer)
-            if (bias_row >= 0) {
-                b0 = *reinterpret_cast<const float4*>(cst + bias_row * NM_W + col0);
-                b1 = *reinterpret_cast<const float4*>(cst + bias_row * NM_W + col0 + 4);
-            } else {  // (buffer loads: a different instruction class, so the two paths are never merged into flat loads)
-                const nm_rsrc rb = __builtin_amdgcn_make_buffer_rsrc((void*)L.b, 0, NM_W * 4, 0x00020000);
-                b0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, col0 * 4, 0, 0));
-                b1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, col0 * 4 + 16, 0, 0));
-            }
-            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
             float y0[8], y1[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const float z0 = fmaf(c.lo[0][ct][8 * hf + r], sc, c.hi[0][ct][8 * hf + r]) + bv[r];
-                const float t1 = fmaf(c.lo[1][ct][8 * hf + r], sc, c.hi[1][ct][8 * hf + r]);
+                const float z0 = fmaf(c.lo[0][ct][8 * hf + r], sc, c.hi[0][ct][8 * hf + r]);  // (bias: in the accumulator)
+                const float z1 = fmaf(c.lo[1][ct][8 * hf + r], sc, c.hi[1][ct][8 * hf + r]);
                 if (TANGENT) {
                     float g0;
                     if (ACT == 0) {
-                        y0[r] = nm_softplus100(z0, &g0);
+                        y0[r] = nm_softplus_l2(z0, &g0);
                     } else {
                         y0[r] = fmaxf(z0, 0.f);
                         g0 = z0 > 0.f ? 1.f : 0.f;
                     }
-                    y1[r] = t1 * g0;
+                    y1[r] = z1 * g0;
                 } else {
-                    const float z1 = t1 + bv[r];
                     if (ACT == 0) {
-                        y0[r] = nm_softplus100(z0, nullptr);
-                        y1[r] = nm_softplus100(z1, nullptr);
+                        y0[r] = nm_softplus_l2(z0, nullptr);
+                        y1[r] = nm_softplus_l2(z1, nullptr);
                     } else {
                         y0[r] = fmaxf(z0, 0.f);
                         y1[r] = fmaxf(z1, 0.f);
@@ -434,6 +494,23 @@ __device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L
     nm_phase_stamp(stamp_slot + 1);
 }
 
+// Two workgroups share a CU, one wave of each per SIMD.  Started together they run their phases in step (both in
+// the K loops, then both in the epilogues) and the matrix pipe idles while the vector ALU works.  The second
+// generation-0 workgroup of each CU therefore starts NM_H2_STAGGER * 64 cycles late; later workgroups inherit the
+// offset of the one they replace.
+#ifndef NM_H2_STAGGER
+#define NM_H2_STAGGER 0
+#endif
+__device__ __forceinline__ void nm_h2_stagger() {
+#if NM_H2_STAGGER > 0
+    if (blockIdx.x >= 256u && blockIdx.x < 512u) {
+#pragma unroll
+        for (int i = 0; i < NM_H2_STAGGER / 64; ++i) __builtin_amdgcn_s_sleep(64);
+        __builtin_amdgcn_s_sleep(NM_H2_STAGGER % 64);
+    }
+#endif
+}
+
 __device__ __forceinline__ void nm_h2_raise(int* overflow, float mx) {
     if (overflow && !(mx < NM_H2_FP16_MAX)) *overflow = 1;  // (benign race: every writer stores 1)
 }
@@ -471,6 +548,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
             oidx = orow * stride + off + op;
         }
     };
+    nm_h2_stagger();
     nm_phase_stamp(0);
     constexpr int DEPTH0 = (FIXED && NABLA) ? NM_H2_DEPTH0 : 2;  // layer-0 prefetch distance (nm_kloop_h2); the rolled loops use one set
     NmBPre<NM_H_CT> pre;
@@ -502,11 +580,13 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
             if (j + 8 < nchunk) in_fg[rd][1] = *reinterpret_cast<const float4*>(fg_rec + rq * gdim + 4 * (j + 8));
         }
     }
+    nm_phase_stamp(10);
     {
         const int nb = prm.D < NM_H2_BIAS_LAYERS ? prm.D : NM_H2_BIAS_LAYERS;
         for (int l = 0; l < nb; ++l) cst[l * NM_W + threadIdx.x] = prm.layer[l].b[threadIdx.x];
         cst[NM_H2_BIAS_LAYERS * NM_W + threadIdx.x] = prm.wd[threadIdx.x];
     }
+    nm_phase_stamp(11);
     float mx = 0.f;
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
@@ -528,11 +608,11 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
             float s, co;
             nm_sincos(dsv * f, &s, &co);
             nm_h2_store2(vrow + FG + 2 * b, s, co, mx);
-            if (NABLA) nm_h2_store2(trow + FG + 2 * b, (NM_TANGENT_SCALE * f) * co, -(NM_TANGENT_SCALE * f) * s, mx);
+            if (NABLA) nm_h2_store2(trow + FG + 2 * b, (NM_H2_TANGENT_SCALE * f) * co, -(NM_H2_TANGENT_SCALE * f) * s, mx);
         }
         if (j == 0) {
             nm_h2_store1(vrow + FG + 2 * md, dsv, mx);
-            if (NABLA) nm_h2_store1(trow + FG + 2 * md, NM_TANGENT_SCALE, mx);
+            if (NABLA) nm_h2_store1(trow + FG + 2 * md, NM_H2_TANGENT_SCALE, mx);
         }
         for (int c = in_dim + j; c < Kpad0; c += 8) {  // padding columns
             vrow[c] = (_Float16)0.0f;
@@ -548,6 +628,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
                 trow[NM_H_PLANE + c] = (_Float16)0.0f;
             }
     }
+    nm_phase_stamp(12);
     __syncthreads();
     nm_phase_stamp(1);
     // layer 0: straight-line K loop for the reference widths (FIXED), rolled loops otherwise; hidden layers are
@@ -574,7 +655,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
             locate(t, rq, oidx);
             if (sdf_out) sdf_out[oidx] = sdf;
             if (NABLA && nabla_out) {
-                const float dsdf = ((red[32 + t] + red[NM_ROWS + 32 + t]) + (red[2 * NM_ROWS + 32 + t] + red[3 * NM_ROWS + 32 + t])) * (1.0f / NM_TANGENT_SCALE);
+                const float dsdf = ((red[32 + t] + red[NM_ROWS + 32 + t]) + (red[2 * NM_ROWS + 32 + t] + red[3 * NM_ROWS + 32 + t])) * (1.0f / NM_H2_TANGENT_SCALE);
                 const long long no = nabla_slotted ? oidx : q;
                 nabla_out[no * 3 + 0] = dsdf * grad[rq * 3 + 0];
                 nabla_out[no * 3 + 1] = dsdf * grad[rq * 3 + 1];
@@ -600,6 +681,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
     if (smap.order && smap.order[base] == 0xffffu) return;  // no point in this tile
     const NmDivBase ddiv = nm_div_base(base, dir_div);
     const long long ray0 = smap.order ? (base / smap.E) * smap.G : 0;  // uniform: one division per workgroup
+    nm_h2_stagger();
     nm_phase_stamp(0);
     constexpr int DEPTH0 = 2;
     NmBPre<NM_H_CT> pre;

@@ -55,6 +55,7 @@ for mode in modes:
             lib.nm_debug_phase_log(None)
             a = log.cpu().numpy().reshape(32, 16)
             used = [c for c in range(16) if a[:, c].min() > 0]
+            used.sort(key=lambda c: float(np.median(a[:, c] - a[:, 0])))   # in time order (the input-phase stamps use slots 10-12)
             d = np.diff(a[:, used], axis=1)
             print("      stamps", used, "median cycles per phase:", np.median(d, axis=0).astype(int).tolist(), " total",
                   int(np.median(a[:, used[-1]] - a[:, used[0]])))
