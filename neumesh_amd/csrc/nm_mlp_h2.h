@@ -282,18 +282,9 @@ __device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16*
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) c.hi[1][ct] = c.lo[1][ct] = nm_f32x16{0};
         }
-#ifdef NM_EXP_NOB
-        if (ks + DEPTH < KS) f[(ks + DEPTH) % (DEPTH + 1)] = pre.s[0];
-#else
         if (ks + DEPTH < KS) f[(ks + DEPTH) % (DEPTH + 1)] = nm_ld_bu<CT>(bp, lane, ks + DEPTH);
-#endif
-#ifdef NM_EXP_NOA
-        if (false) {
-            const int oa = 0;
-#else
         if (ks + 1 < KS) {
             const int oa = (ks + 1) * 16;
-#endif
             a[(ks + 1) & 1][0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
             a[(ks + 1) & 1][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
             if (ks + 1 >= KT0) {
@@ -302,15 +293,10 @@ __device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16*
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-#ifdef NM_EXP_NOA
-#define NM_A_SEL a[0]
-#else
-#define NM_A_SEL a[ks & 1]
-#endif
         if (ks >= KT0) {
-            NM_H2_MFMAS(NM_A_SEL, f[ks % (DEPTH + 1)], 2)
+            NM_H2_MFMAS(a[ks & 1], f[ks % (DEPTH + 1)], 2)
         } else {
-            NM_H2_MFMAS(NM_A_SEL, f[ks % (DEPTH + 1)], 1)
+            NM_H2_MFMAS(a[ks & 1], f[ks % (DEPTH + 1)], 1)
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -494,23 +480,6 @@ __device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L
     nm_phase_stamp(stamp_slot + 1);
 }
 
-// Two workgroups share a CU, one wave of each per SIMD.  Started together they run their phases in step (both in
-// the K loops, then both in the epilogues) and the matrix pipe idles while the vector ALU works.  The second
-// generation-0 workgroup of each CU therefore starts NM_H2_STAGGER * 64 cycles late; later workgroups inherit the
-// offset of the one they replace.
-#ifndef NM_H2_STAGGER
-#define NM_H2_STAGGER 0
-#endif
-__device__ __forceinline__ void nm_h2_stagger() {
-#if NM_H2_STAGGER > 0
-    if (blockIdx.x >= 256u && blockIdx.x < 512u) {
-#pragma unroll
-        for (int i = 0; i < NM_H2_STAGGER / 64; ++i) __builtin_amdgcn_s_sleep(64);
-        __builtin_amdgcn_s_sleep(NM_H2_STAGGER % 64);
-    }
-#endif
-}
-
 __device__ __forceinline__ void nm_h2_raise(int* overflow, float mx) {
     if (overflow && !(mx < NM_H2_FP16_MAX)) *overflow = 1;  // (benign race: every writer stores 1)
 }
@@ -548,7 +517,6 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
             oidx = orow * stride + off + op;
         }
     };
-    nm_h2_stagger();
     nm_phase_stamp(0);
     constexpr int DEPTH0 = (FIXED && NABLA) ? NM_H2_DEPTH0 : 2;  // layer-0 prefetch distance (nm_kloop_h2); the rolled loops use one set
     NmBPre<NM_H_CT> pre;
@@ -681,7 +649,6 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
     if (smap.order && smap.order[base] == 0xffffu) return;  // no point in this tile
     const NmDivBase ddiv = nm_div_base(base, dir_div);
     const long long ray0 = smap.order ? (base / smap.E) * smap.G : 0;  // uniform: one division per workgroup
-    nm_h2_stagger();
     nm_phase_stamp(0);
     constexpr int DEPTH0 = 2;
     NmBPre<NM_H_CT> pre;
