@@ -122,7 +122,9 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
                                                      float rx, float ry, float rz, unsigned long long (&kk)[K], float init_d2) {
 #pragma unroll
     for (int k = 0; k < K; ++k) kk[k] = nm_key(init_d2, 0x7fffffff);
-    const uint32_t kx = nm_float_key(rx), ky = nm_float_key(ry), kz = nm_float_key(rz);  // wave-uniform
+    const uint32_t kx = (uint32_t)NM_UNIFORM_I(nm_float_key(rx)), ky = (uint32_t)NM_UNIFORM_I(nm_float_key(ry)),
+                   kz = (uint32_t)NM_UNIFORM_I(nm_float_key(rz));  // wave-uniform, kept in SGPRs
+    const unsigned long long act_mask = __builtin_amdgcn_ballot_w64(active);
     NmNode rec = nm_ld_node(g.nodes, 0);
     int first = nm_octant(rec, kx, ky, kz);
     unsigned om = nm_visit_mask(rec, first);
@@ -148,8 +150,11 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
         const int c = first ^ nm_perm(i);
         const uint32_t mask = rec.info & 255u;
         const NmNode crec = nm_ld_node(g.nodes, rec.first + (uint32_t)__popc(mask & ((1u << c) - 1u)));
-        const bool want = active && (nm_box_lb2(crec, qx, qy, qz) <= nm_key_d2(kk[K - 1]));
-        if (!__any(want)) continue;
+        // every lane tests (an inactive lane's result is masked out of the vote): no divergent region around the bound,
+        // and the vote is a scalar compare of the mask (__any() goes through a vector select + compare)
+        const bool nearer = nm_box_lb2(crec, qx, qy, qz) <= nm_key_d2(kk[K - 1]);
+        if ((__builtin_amdgcn_ballot_w64(nearer) & act_mask) == 0ull) continue;
+        const bool want = active && nearer;
         if ((crec.info & 255u) == 0u) {  // leaf: 4 vertices per step (the array is padded)
             for (uint32_t p = crec.first; p < crec.end; p += 4) {
                 const float4 v0 = nm_ld_vert(g.sverts, p), v1 = nm_ld_vert(g.sverts, p + 1);
