@@ -325,10 +325,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(steps, warmup, precision="f16x2", samples=128, normals=True, white=False, flags=0, keep_frame0=False, gather=True, hw=None):
+    def run(steps, warmup, precision="f16x2", samples=128, normals=True, white=False, flags=0, keep_frame0=False, gather=True, hw=None, weight_eps=0.0):
         """warmup + `steps` timed frames of one variant; returns (elapsed s [max over ranks], profile dict, rgb of frame 0 or None)."""
         model.mlp_precision = precision
-        cfg = make_render_cfg(calc_normal=normals, N_samples=samples // 2, N_importance=samples // 2, white_bkgd=white, flags=flags)
+        cfg = make_render_cfg(calc_normal=normals, N_samples=samples // 2, N_importance=samples // 2, white_bkgd=white, flags=flags, weight_eps=weight_eps)
         total = warmup + steps
         H, W = hw or (args.H, args.W)
         r_intr = synthetic.pinhole_intrinsics(H, W) if hw else intr
@@ -430,19 +430,23 @@ def main():
         if world == 1 and not args.no_extras and not args.data_independent and args.samples == 128 and not args.no_normals and not args.white_bkgd:
             def short(name, **kw):
                 try:
-                    e, pr, _, _ = run(2, 1, **kw)
+                    e, pr, img, _ = run(2, 1, **kw)
                     d, pp, a, pk, sp = mlp_summary(pr, kw.get("precision", "f16x2"))
                     nr = kw["hw"][0] * kw["hw"][1] if "hw" in kw else n_rays
                     extra[name] = {"value": nr * 2 / e, "unit": "rays/s", "ms_per_frame": e / 2 * 1e3, "steps": 2,
                                    "dominant_kernel": d, "achieved_tflops_algorithmic": a, "frac_of_pipe_peak": a / pk,
                                    "knn_ms_per_frame": pr["knn_distance"]["ms"] / 2, "knn_searched_per_frame": pr["knn_distance"]["points"] / 2,
                                    "mlp_points_per_frame": {k: pr[k]["points"] / 2 for k in ("geo_mlp", "geo_mlp_tangent", "color_mlp")}}
+                    if img is not None and rgb0 is not None and img.shape == rgb0.shape:   # same frame 0 as the headline run
+                        extra[name]["max_abs_rgb_vs_headline_frame"] = float(np.abs(img - rgb0).max())
                 except Exception as ex:  # a variant must never sink the headline
                     extra[name] = {"error": str(ex)}
             short("data_independent_frame (every probe + every mid-point evaluated: the reference's work)",
                   flags=_lib.RENDER_FULL_PROBES | _lib.RENDER_NO_ZERO_SKIP)
             short("mlp_precision_fp32 (fp32-input MFMA)", precision="fp32")
             short("calc_normal_false", normals=False)
+            short("weight_eps_1e-10 (mid-points of visibility weight < 1e-10 not evaluated: the one variant that is not bit-identical; "
+                  "rgb / normals move by < 127e-10, depth / acc not at all)", weight_eps=1e-10, keep_frame0=True)
             short("config3_shape (64 samples/ray, white background)", samples=64, white=True)
             short("config4_shape (1600x1200 rays/frame in chunks of one 800x800 frame, 64+64 samples)", hw=(1200, 1600))
             model.mlp_precision = args.mlp_precision

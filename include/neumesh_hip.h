@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 4
+#define NM_ABI_VERSION 5
 #define NM_MAX_K 32
 
 typedef struct nm_grid_s* nm_grid_t;    /* spatial index over the mesh vertices */
@@ -174,6 +174,11 @@ typedef struct nm_render_cfg {
     int32_t chain_tiles;         /* regular-grid passes: max 4-sample tiles a wave chains; 0 = default (32) */
     int32_t fine_group_rays;     /* rays per depth-bucket group of an importance pass: 64/128/256/512; 0 = default (128) */
     int32_t mid_group_rays;      /* rays per depth-bucket group of the mid-point pass: 16/32/64; 0 = default (64) */
+    float weight_eps;            /* 0 = exact (default).  > 0: a mid-point (and the nabla of a sample) whose visibility
+                                    weight is below weight_eps is treated like one of weight 0 in the radiance / normal
+                                    sums, i.e. never evaluated: rgb and normals move by less than (N-1) * weight_eps,
+                                    depth and acc not at all (their weights come from the sample SDFs).  The one
+                                    setting that is NOT bit-identical to evaluating everything. */
 } nm_render_cfg;
 
 /* nm_render_cfg.flags.  None of them changes a result bit (tests compare the variants); they select

@@ -11,7 +11,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_K = 32
 
 
@@ -43,7 +43,7 @@ class RenderCfg(C.Structure):
                 ("white_bkgd", C.c_int32), ("probe_grid", C.c_int32), ("probe_thresh", C.c_float),
                 ("near_bypass", C.c_float), ("far_bypass", C.c_float),
                 ("flags", C.c_uint32), ("chain_tiles", C.c_int32), ("fine_group_rays", C.c_int32),
-                ("mid_group_rays", C.c_int32)]
+                ("mid_group_rays", C.c_int32), ("weight_eps", C.c_float)]
 
 
 # nm_render_cfg.flags (include/neumesh_hip.h)

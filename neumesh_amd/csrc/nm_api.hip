@@ -941,7 +941,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
             pending = n_new;
         }
     }
-    hipLaunchKernelGGL(nm_rays_finalize_kernel, rgrid, rblock, ray_lds, stream, ws.d, ws.sdf, ws.slot, ws.radius, (long long)R, cap, n, pending, ws.dmid, ws.bound_mid, t->s, skip_zero ? ws.bound : (float*)nullptr);
+    hipLaunchKernelGGL(nm_rays_finalize_kernel, rgrid, rblock, ray_lds, stream, ws.d, ws.sdf, ws.slot, ws.radius, (long long)R, cap, n, pending, ws.dmid, ws.bound_mid, t->s, skip_zero ? ws.bound : (float*)nullptr, c->weight_eps > 0.f ? c->weight_eps : 0.f);
     NM_LAUNCH_CHECK();
     // SDF (+ nablas) at all N sample points (renderer.py:264, 271-276): no new search and no new
     // MLP pass -- the SDF values merged above ARE forward_with_nablas(pts)[0] (same points, same
@@ -1072,7 +1072,7 @@ int nm_rays_finalize(float* d, float* sdf, int64_t R, int cap, int n, int m, flo
     if (R == 0) return 0;
     size_t ray_lds = 0;
     if (nm_ray_lds_prepare(cap, &ray_lds)) return 1;
-    hipLaunchKernelGGL(nm_rays_finalize_kernel, dim3(nm_blocks(R, 64)), dim3(64), ray_lds, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (long long)R, cap, n, m, d_mid, (float*)nullptr, 0.f, (float*)nullptr);
+    hipLaunchKernelGGL(nm_rays_finalize_kernel, dim3(nm_blocks(R, 64)), dim3(64), ray_lds, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (long long)R, cap, n, m, d_mid, (float*)nullptr, 0.f, (float*)nullptr, 0.f);
     NM_LAUNCH_CHECK();
     return 0;
 }

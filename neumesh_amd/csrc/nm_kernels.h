@@ -720,7 +720,7 @@ __global__ __launch_bounds__(64) void nm_rays_upsample_kernel(float* __restrict_
 __global__ __launch_bounds__(64) void nm_rays_finalize_kernel(float* __restrict__ d, float* __restrict__ sdf, int* __restrict__ slot,
                                                               const float* __restrict__ radius, long long R, int cap, int n, int m,
                                                               float* __restrict__ d_mid, float* __restrict__ bound_mid,
-                                                              float s_val, float* __restrict__ w_mid) {
+                                                              float s_val, float* __restrict__ w_mid, float w_eps) {
     extern __shared__ float nm_ray_smem[];
     const NmRayLds l = nm_ray_lds(nm_ray_smem, cap);
     const long long r0 = (long long)blockIdx.x * 64;
@@ -738,7 +738,10 @@ __global__ __launch_bounds__(64) void nm_rays_finalize_kernel(float* __restrict_
         if (r < R) nm_ray_weights(l.s + threadIdx.x * l.S, n, s_val, l.s + threadIdx.x * l.S);
         __syncthreads();
         for (int rr = 0; rr < 64 && r0 + rr < R; ++rr)
-            for (int j = lane; j + 1 < n; j += 64) w_mid[(r0 + rr) * cap + j] = l.s[rr * l.S + j];
+            for (int j = lane; j + 1 < n; j += 64) {  // (w_eps = 0: the weights themselves; else weights below it count as 0)
+                const float wv = l.s[rr * l.S + j];
+                w_mid[(r0 + rr) * cap + j] = wv < w_eps ? 0.0f : wv;
+            }
         __syncthreads();
     }
     // the sdf rows are no longer needed in LDS: reuse them for the radius rows (coalesced loads)

@@ -50,9 +50,11 @@ _ENV_TUNING = (("NEUMESH_CHAIN_TILES", "chain_tiles"), ("NEUMESH_FINE_GROUP", "f
 
 def make_render_cfg(obj_bounding_radius=1.0, N_samples=64, N_importance=64, N_upsample_iters=4, bounded_near_far=True,
                     calc_normal=False, white_bkgd=False, near_bypass=None, far_bypass=None, flags=None,
-                    **tuning) -> _lib.RenderCfg:
+                    weight_eps=None, **tuning) -> _lib.RenderCfg:
     """nm_render_cfg for volume_render's arguments.  flags: NM_RENDER_* bits (None = take them from the
-    NEUMESH_* environment variables); tuning: chain_tiles / fine_group_rays / mid_group_rays (0 = default)."""
+    NEUMESH_* environment variables); tuning: chain_tiles / fine_group_rays / mid_group_rays (0 = default);
+    weight_eps: visibility weights below it count as 0 (None = NEUMESH_WEIGHT_EPS, else 0 = exact; the only
+    setting that changes pixels: by less than (N-1) * weight_eps)."""
     c = _lib.RenderCfg()
     c.obj_bounding_radius = float(obj_bounding_radius)
     c.N_samples, c.N_importance, c.N_upsample_iters = int(N_samples), int(N_importance), int(N_upsample_iters)
@@ -66,6 +68,12 @@ def make_render_cfg(obj_bounding_radius=1.0, N_samples=64, N_importance=64, N_up
             if os.environ.get(env):
                 flags |= bit
     c.flags = int(flags)
+    if weight_eps is None:
+        try:
+            weight_eps = float(os.environ.get("NEUMESH_WEIGHT_EPS", "0"))
+        except ValueError:
+            weight_eps = 0.0
+    c.weight_eps = max(0.0, float(weight_eps))
     for env, field in _ENV_TUNING:
         v = tuning.get(field)
         if v is None:

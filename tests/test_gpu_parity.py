@@ -485,6 +485,39 @@ def test_render_headline_scale_matches_reference_fixture(dtu_scale, cuda_device,
 
 
 @pytest.mark.gpu
+def test_weight_eps_drops_only_negligible_terms(dtu_scale, cuda_device, torch_mod):
+    """nm_render_cfg.weight_eps (the one setting that is not bit-identical): mid-points whose visibility weight is below it
+    are not evaluated.  On the headline fixture rays with weight_eps = 1e-10: depth and acc bit-identical to the exact
+    render (their weights come from the sample SDFs), rgb / normals within (N-1) * weight_eps + fp32 rounding of the sums,
+    parity with the reference unchanged, and far fewer mid-points evaluated."""
+    torch = torch_mod
+    from neumesh_amd import _lib
+    from neumesh_amd.renderer import make_render_cfg, render_rays_fused
+    mesh, state, model = dtu_scale
+    f = common.golden("render_v140k_dtu")
+    ro, rd = _t(f["rays_o"], cuda_device), _t(f["rays_d"], cuda_device)
+    lib = _lib.load()
+    out, pts = {}, {}
+    for name, eps in (("exact", 0.0), ("eps", 1e-10)):
+        cfg = make_render_cfg(calc_normal=True, weight_eps=eps, flags=0)
+        lib.nm_profile_enable(1)
+        with torch.no_grad():
+            out[name] = render_rays_fused(model, ro, rd, cfg, 65536)
+        torch.cuda.synchronize()
+        ms, n, u = C.c_double(), C.c_int64(), C.c_int64()
+        lib.nm_profile_read(3, C.byref(ms), C.byref(n), C.byref(u))   # kind 3: colour MLP = evaluated mid-points
+        pts[name] = u.value
+        lib.nm_profile_enable(0)
+    a, b = out["exact"], out["eps"]
+    assert torch.equal(a["depth_volume"], b["depth_volume"]) and torch.equal(a["mask_volume"], b["mask_volume"])
+    d_rgb = float((a["rgb"] - b["rgb"]).abs().max()), float((a["normals_volume"] - b["normals_volume"]).abs().max())
+    print(f"weight_eps 1e-10: evaluated mid-points {pts['exact']} -> {pts['eps']}, max |rgb| change {d_rgb[0]:.2e}, normals {d_rgb[1]:.2e}")
+    assert d_rgb[0] <= 127e-10 + 2.5e-7 and d_rgb[1] <= 127e-10 + 5e-7   # dropped terms + a few last-place units of the sums
+    assert np.abs(b["rgb"].cpu().numpy() - f["rgb"]).max() <= 1e-4
+    assert 0 < pts["eps"] < 0.8 * pts["exact"]
+
+
+@pytest.mark.gpu
 def test_config5_stress_kernels_1M_vertices_256d(cuda_device, torch_mod):
     """BASELINE config 5: V = 1 000 000 vertices, one 256-d feature table, kernels = K-NN +
     gather-interpolate only (nm_distance_interpolate).  Coherent queries (points of adjacent camera
