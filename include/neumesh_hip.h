@@ -260,6 +260,19 @@ typedef struct nm_camera {
 int nm_make_rays(const nm_camera* cam, int64_t first_pixel, int64_t count, float* rays_o,
                  float* rays_d, nm_stream_t stream);
 
+/* ----------------------------------------------------------------------------- image assembly
+ * What render.py:219-249 does on the host with the three outputs of a frame, per pixel, on the device
+ * (the frame then leaves the GPU as 7 bytes per pixel instead of 28):
+ *   rgb8[p][c]    = (uint8)(rgb[p][c] * 255.0f)                 integerify, render.py:183-184 (fp32 product, truncation)
+ *   depth8[p]     = (uint8)((depth[p] / max_q depth[q]) * 255)  render.py:221-222, 253
+ *   normal8[p][c] = (uint8)((normals[p][c] / 2 + 0.5) * 255)    render.py:233, 246-248
+ * bgr != 0 writes rgb8 in B,G,R order (the channel swap before cv2.imwrite, render.py:236).  depth / normals and
+ * their outputs may be NULL.  depth_max_scratch: one float of device scratch (the maximum is taken over THIS call's
+ * count pixels: call it on whole frames).  Values outside [0, 256/255) are clamped to 0 / 255 (numpy's cast of
+ * such values is undefined). */
+int nm_assemble_frame(const float* rgb, const float* depth, const float* normals, int64_t count, int bgr,
+                      uint8_t* rgb8, uint8_t* depth8, uint8_t* normal8, float* depth_max_scratch, nm_stream_t stream);
+
 /* -------------------------------------------------------------------------- instrumentation
  * In-stream timing of the hot kernels inside ordinary calls (nm_render_rays, nm_field_*):
  * nm_profile_enable(1) clears the log and starts bracketing every launch of the K-NN/distance,

@@ -13,6 +13,7 @@ missing -- there is no CPU fallback in the product path.
     from neumesh_amd import Trainer                  # models/trainer.py (2nd element of get_model's tuple)
     from neumesh_amd import TextureEditableNeuMesh   # editing/texture_neumesh/texture_neumesh.py
     from neumesh_amd import ray_casting              # models/ray_casting.py (surface_render, root finding, sphere tracing)
+    from neumesh_amd import frames                   # render.py:183-184, 219-249 (uint8 images of a frame, on the device)
 """
 from . import synthetic  # noqa: F401  (numpy only)
 
@@ -27,6 +28,6 @@ def __getattr__(name):  # lazy: torch is imported only when the model classes ar
     if name in table:
         return getattr(importlib.import_module(f".{table[name]}", __name__), name)
     if name in ("frnn", "mesh_grid", "neumesh", "renderer", "framework", "ply", "sharded", "rays", "build", "_lib", "trainer", "editing",
-                "ray_casting"):
+                "ray_casting", "frames"):
         return importlib.import_module(f".{name}", __name__)
     raise AttributeError(name)

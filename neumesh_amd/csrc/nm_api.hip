@@ -1087,6 +1087,24 @@ int nm_rays_composite(const float* sdf, const float* d, int64_t R, int cap, int 
 }
 
 // ============================================================================== ray set-up
+int nm_assemble_frame(const float* rgb, const float* depth, const float* normals, int64_t count, int bgr, uint8_t* rgb8,
+                      uint8_t* depth8, uint8_t* normal8, float* depth_max_scratch, nm_stream_t stream_) {
+    if (count < 0) return nm_fail("nm_assemble_frame: count < 0");
+    if (count == 0) return 0;
+    if ((rgb8 && !rgb) || (depth8 && !depth) || (normal8 && !normals)) return nm_fail("nm_assemble_frame: output without its input");
+    if (depth8 && !depth_max_scratch) return nm_fail("nm_assemble_frame: depth8 needs depth_max_scratch");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (depth8) {
+        NM_HIP(hipMemsetAsync(depth_max_scratch, 0, sizeof(float), stream));
+        const unsigned blocks = (unsigned)std::min<long long>(nm_blocks(count, 256), 2048);
+        hipLaunchKernelGGL(nm_depth_max_kernel, dim3(blocks), dim3(256), 0, stream, depth, (long long)count, reinterpret_cast<unsigned*>(depth_max_scratch));
+    }
+    hipLaunchKernelGGL(nm_assemble_kernel, dim3(nm_blocks(count, 256)), dim3(256), 0, stream, rgb, depth, normals, (long long)count, bgr,
+                       rgb8, depth8, normal8, (const float*)depth_max_scratch);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
 int nm_make_rays(const nm_camera* cam, int64_t first_pixel, int64_t count, float* rays_o, float* rays_d, nm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!cam) return nm_fail("nm_make_rays: cam is NULL");

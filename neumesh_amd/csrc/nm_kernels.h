@@ -962,6 +962,35 @@ __global__ void nm_make_rays_kernel(NmCamera cam, long long first, long long cou
     }
 }
 
+// ------------------------------------------------------------------------------- image assembly (render.py:183-184, 219-249)
+__device__ __forceinline__ unsigned char nm_integerify(float v) {  // (uint8)(v * 255.0f), clamped where numpy's cast is undefined
+    const float x = __fmul_rn(v, 255.0f);
+    return (unsigned char)(x >= 256.0f ? 255 : (x > 0.0f ? (int)x : 0));   // (NaN -> 0)
+}
+__global__ void nm_depth_max_kernel(const float* __restrict__ depth, long long n, unsigned* __restrict__ max_bits) {
+    float m = 0.f;  // depths are >= 0: their bit patterns order like unsigned integers
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) m = fmaxf(m, depth[i]);
+    m = nm_wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(max_bits, __float_as_uint(m));
+}
+__global__ void nm_assemble_kernel(const float* __restrict__ rgb, const float* __restrict__ depth, const float* __restrict__ normals,
+                                   long long n, int bgr, unsigned char* __restrict__ rgb8, unsigned char* __restrict__ depth8,
+                                   unsigned char* __restrict__ normal8, const float* __restrict__ depth_max) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (rgb8) {
+        const unsigned char c0 = nm_integerify(rgb[3 * p]), c1 = nm_integerify(rgb[3 * p + 1]), c2 = nm_integerify(rgb[3 * p + 2]);
+        rgb8[3 * p] = bgr ? c2 : c0;
+        rgb8[3 * p + 1] = c1;
+        rgb8[3 * p + 2] = bgr ? c0 : c2;
+    }
+    if (depth8) depth8[p] = nm_integerify(__fdiv_rn(depth[p], depth_max[0]));
+    if (normal8) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) normal8[3 * p + c] = nm_integerify(__fadd_rn(__fmul_rn(normals[3 * p + c], 0.5f), 0.5f));
+    }
+}
+
 // ------------------------------------------------------------------------------- utilities
 __global__ void nm_pack_weight_kernel(const float* __restrict__ src, int rows, int in_dim, int Kpad,
                                       float* __restrict__ dst) {

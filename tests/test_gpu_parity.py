@@ -518,6 +518,38 @@ def test_weight_eps_drops_only_negligible_terms(dtu_scale, cuda_device, torch_mo
 
 
 @pytest.mark.gpu
+def test_frame_assembly_matches_render_py_arithmetic(cuda_device, torch_mod):
+    """nm_assemble_frame vs the host arithmetic of render.py:183-184, 219-249 (numpy float32, truncating uint8 cast):
+    bit-exact on values inside the cast's defined range, clamped outside; BGR swap; optional outputs."""
+    torch = torch_mod
+    from neumesh_amd.frames import assemble_images
+    rng = np.random.default_rng(5)
+    H, W = 37, 53
+    rgb = rng.random((H * W, 3), dtype=np.float32)
+    rgb[:8] = [[0.0, 1.0, 0.999999], [1.0000001, 0.5, 0.25], [1e-9, 0.0039215689, 0.0039215684], [0.5, 0.5, 0.5],
+               [1.5, -0.25, 2.0], [0.99609375, 0.99609381, 0.996], [0.2, 0.4, 0.6], [1.0, 1.0, 1.0]]
+    depth = (rng.random(H * W, dtype=np.float32) * 3.0).astype(np.float32)
+    nrm = rng.standard_normal((H * W, 3)).astype(np.float32)
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    out = assemble_images(_t(rgb, cuda_device), _t(depth, cuda_device), _t(nrm, cuda_device), H, W)
+    out_bgr = assemble_images(_t(rgb, cuda_device), H=H, W=W, bgr=True)
+
+    def integerify(img):   # render.py:183-184, with the clamp where numpy's cast is undefined
+        return np.clip(np.trunc(img * np.float32(255.0)), 0, 255).astype(np.uint8)
+    want_rgb = integerify(rgb).reshape(H, W, 3)
+    want_depth = integerify(depth / depth.max()).reshape(H, W, 1)
+    want_nrm = integerify(nrm / np.float32(2.0) + np.float32(0.5)).reshape(H, W, 3)
+    inside = ((rgb * np.float32(255.0) >= 0) & (rgb * np.float32(255.0) < 256)).all()
+    assert not inside   # the clamped cases are part of the test
+    assert np.array_equal(out["rgb"].cpu().numpy(), want_rgb)
+    assert np.array_equal(out["depth"].cpu().numpy(), want_depth)
+    assert np.array_equal(out["normal"].cpu().numpy(), want_nrm)
+    assert set(out_bgr) == {"rgb"} and np.array_equal(out_bgr["rgb"].cpu().numpy(), want_rgb[..., ::-1])
+    ok = (rgb * np.float32(255.0) < 256).all(-1) & (rgb >= 0).all(-1)
+    assert np.array_equal(out["rgb"].cpu().numpy().reshape(-1, 3)[ok], (rgb[ok] * 255.0).astype(np.uint8))   # numpy's own cast
+
+
+@pytest.mark.gpu
 def test_config5_stress_kernels_1M_vertices_256d(cuda_device, torch_mod):
     """BASELINE config 5: V = 1 000 000 vertices, one 256-d feature table, kernels = K-NN +
     gather-interpolate only (nm_distance_interpolate).  Coherent queries (points of adjacent camera

@@ -193,3 +193,31 @@ def test_get_model_returns_a_trainer_with_the_reference_signature():
     assert list(inspect.signature(Trainer.compute_loss).parameters)[1:] == [
         "args", "rgb", "target_rgb", "extras", "mask", "mask_ignore", "use_eikonal_loss", "use_distill_loss", "use_indicator_reg"]
     assert list(inspect.signature(Trainer.__init__).parameters)[1:] == ["model", "loss_weights", "teacher_model", "device_ids", "batched"]
+
+
+def test_write_png_roundtrip(tmp_path):
+    """frames.write_png: an 8-bit RGB / grey PNG that decodes back to the same bytes (zlib + filter type 0)."""
+    import struct, zlib
+    from neumesh_amd.frames import write_png
+    rng = np.random.default_rng(0)
+    for shape in ((5, 7, 3), (4, 6, 1), (3, 9)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        path = str(tmp_path / "t.png")
+        write_png(path, img)
+        raw = open(path, "rb").read()
+        assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, idat, ihdr = 8, b"", None
+        while pos < len(raw):
+            n, tag = struct.unpack(">I", raw[pos:pos + 4])[0], raw[pos + 4:pos + 8]
+            data = raw[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + data) & 0xFFFFFFFF
+            if tag == b"IHDR":
+                ihdr = struct.unpack(">IIBBBBB", data)
+            if tag == b"IDAT":
+                idat += data
+            pos += 12 + n
+        h, w = shape[0], shape[1]
+        ch = 3 if (len(shape) == 3 and shape[2] == 3) else 1
+        assert ihdr == (w, h, 8, 2 if ch == 3 else 0, 0, 0, 0)
+        rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * ch)
+        assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:].reshape(h, w, ch), img.reshape(h, w, ch))
