@@ -155,18 +155,31 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
         const bool nearer = nm_box_lb2(crec, qx, qy, qz) <= nm_key_d2(kk[K - 1]);
         if ((__builtin_amdgcn_ballot_w64(nearer) & act_mask) == 0ull) continue;
         const bool want = active && nearer;
-        if ((crec.info & 255u) == 0u) {  // leaf: 4 vertices per step (the array is padded)
-            for (uint32_t p = crec.first; p < crec.end; p += 4) {
-                const float4 v0 = nm_ld_vert(g.sverts, p), v1 = nm_ld_vert(g.sverts, p + 1);
-                const float4 v2 = nm_ld_vert(g.sverts, p + 2), v3 = nm_ld_vert(g.sverts, p + 3);
-                const float4 vv[4] = {v0, v1, v2, v3};
+        if ((crec.info & 255u) == 0u) {  // leaf
+            // LDS-staged leaf scan: the wave fetches up to 64 vertices of the leaf with ONE coalesced vector load, every lane
+            // scores them from LDS (same-address reads: broadcast).  A/B on the 800x800 frame, same call: scalar-path scan
+            // (s_load_dwordx16 = 4 vertices per dependent load) 103.2 ms of K-NN per frame, this 100.9, vector load +
+            // v_readlane broadcast 115.5; the leaf level keeps its optimum (~32 vertices per leaf: 101 vs 127-130 ms at ~120).
+            __shared__ float4 nm_leaf_lds[4][64];  // (every kernel that traverses runs 4 waves per workgroup)
+            float4* stage = nm_leaf_lds[threadIdx.x >> 6];
+            const uint32_t ln = threadIdx.x & 63u;
+            for (uint32_t p0 = crec.first; p0 < crec.end; p0 += 64) {
+                const uint32_t cnt = crec.end - p0 < 64u ? crec.end - p0 : 64u;
+                stage[ln] = g.sverts[p0 + (ln < cnt ? ln : 0u)];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (uint32_t j0 = 0; j0 < cnt; j0 += 4) {
+                    const float4 vv[4] = {stage[j0], stage[(j0 + 1) & 63u], stage[(j0 + 2) & 63u], stage[(j0 + 3) & 63u]};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (p + j < crec.end) {
-                        const unsigned long long key = nm_key(nm_dist2(qx, qy, qz, vv[j].x, vv[j].y, vv[j].z), nm_as_int(vv[j].w));
-                        if (want && key < kk[K - 1]) nm_topk_insert<K>(kk, key);
+                    for (int j = 0; j < 4; ++j) {
+                        if (j0 + j < cnt) {
+                            const unsigned long long key = nm_key(nm_dist2(qx, qy, qz, vv[j].x, vv[j].y, vv[j].z), nm_as_int(vv[j].w));
+                            if (want && key < kk[K - 1]) nm_topk_insert<K>(kk, key);
+                        }
                     }
                 }
+                __builtin_amdgcn_wave_barrier();  // (the next chunk overwrites the stage)
             }
         } else {
             rec = crec;
