@@ -1194,7 +1194,18 @@ int nm_time_kernel(nm_field_t f, nm_grid_t g, const nm_field_tables* t, int whic
     const NmScratch s = nm_carve(scratch, P);
     const NmGather ga = {t->geometry_features, f->geo.gdim, s.fg, t->color_features, f->col.cdim, s.ft};
     // inputs of the MLP kernels come from one K-NN pass
+#ifdef NM_EXP_GATHER
+    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx, nullptr, s.w, s.grad, stream, nullptr, ga)) return 1;
+    {
+        const int* pi = s.idx; const float* pw = s.w; const float* pt = t->geometry_features;
+        NM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_nm_exp_idx), &pi, sizeof(pi), 0, hipMemcpyHostToDevice, stream));
+        NM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_nm_exp_w), &pw, sizeof(pw), 0, hipMemcpyHostToDevice, stream));
+        NM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_nm_exp_tab), &pt, sizeof(pt), 0, hipMemcpyHostToDevice, stream));
+        NM_HIP(hipStreamSynchronize(stream));
+    }
+#else
     if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr, s.grad, stream, nullptr, ga)) return 1;
+#endif
     if (which == 3 && nm_launch_geo(f, s.fg, s.ds, s.grad, P, true, nullptr, 1, 1, 0, s.nabla, stream)) return 1;
     hipEvent_t e0, e1;
     NM_HIP(hipEventCreate(&e0));

@@ -80,6 +80,12 @@ __global__ void nm_scale_copy_kernel(const float* __restrict__ src, float scale,
     if (i < n) dst[i] = src[i] * scale;
 }
 
+#ifdef NM_EXP_GATHER
+__device__ const int* g_nm_exp_idx = nullptr;
+__device__ const float* g_nm_exp_w = nullptr;
+__device__ const float* g_nm_exp_tab = nullptr;
+#endif
+
 struct NmGeoParamsH2 {
     NmLayerH layer[NM_MAX_LAYERS];  // log2 units (nm_softplus_l2): layer 0 weights and every bias x S
     int D;
@@ -544,8 +550,26 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
             long long rq, unused_o;
             locate(p, rq, unused_o);
             in_ds[rd] = ds[rq];
+#ifdef NM_EXP_GATHER  // A/B (tools/mlp_ab.py): the input phase gathers and interpolates the 8 code rows itself from idx / w records
+          if (g_nm_exp_idx) {
+            const int myi = g_nm_exp_idx[rq * 8 + j];
+            const float myw = g_nm_exp_w[rq * 8 + j];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int l0 = (threadIdx.x & 63) & ~7;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int ik = __shfl(myi, l0 | k);
+                const float wk = __shfl(myw, l0 | k);
+                const float4 r = *reinterpret_cast<const float4*>(g_nm_exp_tab + (size_t)ik * gdim + 4 * j);
+                acc.x = fmaf(r.x, wk, acc.x); acc.y = fmaf(r.y, wk, acc.y); acc.z = fmaf(r.z, wk, acc.z); acc.w = fmaf(r.w, wk, acc.w);
+            }
+            in_fg[rd][0] = acc;
+          } else
+#endif
+          {
             if (j < nchunk) in_fg[rd][0] = *reinterpret_cast<const float4*>(fg_rec + rq * gdim + 4 * j);
             if (j + 8 < nchunk) in_fg[rd][1] = *reinterpret_cast<const float4*>(fg_rec + rq * gdim + 4 * (j + 8));
+          }
         }
     }
     nm_phase_stamp(10);
