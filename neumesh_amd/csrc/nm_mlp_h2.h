@@ -573,10 +573,13 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
         }
     }
     nm_phase_stamp(10);
+    // biases / head weights: requested now, stored to LDS after the embedding work (their latency under it, one wait less)
+    float cst_v[NM_H2_BIAS_LAYERS + 1];
     {
         const int nb = prm.D < NM_H2_BIAS_LAYERS ? prm.D : NM_H2_BIAS_LAYERS;
-        for (int l = 0; l < nb; ++l) cst[l * NM_W + threadIdx.x] = prm.layer[l].b[threadIdx.x];
-        cst[NM_H2_BIAS_LAYERS * NM_W + threadIdx.x] = prm.wd[threadIdx.x];
+#pragma unroll
+        for (int l = 0; l < NM_H2_BIAS_LAYERS; ++l) cst_v[l] = l < nb ? prm.layer[l].b[threadIdx.x] : 0.f;
+        cst_v[NM_H2_BIAS_LAYERS] = prm.wd[threadIdx.x];
     }
     nm_phase_stamp(11);
     float mx = 0.f;
@@ -620,6 +623,8 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
                 trow[NM_H_PLANE + c] = (_Float16)0.0f;
             }
     }
+#pragma unroll
+    for (int l = 0; l <= NM_H2_BIAS_LAYERS; ++l) cst[l * NM_W + threadIdx.x] = cst_v[l];
     nm_phase_stamp(12);
     __syncthreads();
     nm_phase_stamp(1);
@@ -715,11 +720,13 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
             in_dv[rd][2] = dirs[ray * 3 + 2];
         }
     }
+    float cst_v[NM_H2_BIAS_LAYERS + 3];  // (requested now, stored to LDS after the embedding work)
     {
         const int nb = prm.D < NM_H2_BIAS_LAYERS ? prm.D : NM_H2_BIAS_LAYERS;
-        for (int l = 0; l < nb; ++l) cst[l * NM_W + threadIdx.x] = prm.layer[l].b[threadIdx.x];
 #pragma unroll
-        for (int o = 0; o < 3; ++o) cst[(NM_H2_BIAS_LAYERS + o) * NM_W + threadIdx.x] = prm.wrgb[o * NM_W + threadIdx.x];
+        for (int l = 0; l < NM_H2_BIAS_LAYERS; ++l) cst_v[l] = l < nb ? prm.layer[l].b[threadIdx.x] : 0.f;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) cst_v[NM_H2_BIAS_LAYERS + o] = prm.wrgb[o * NM_W + threadIdx.x];
     }
     float mx = 0.f;
 #pragma unroll
@@ -756,6 +763,8 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
             vrow[NM_H_PLANE + c] = (_Float16)0.0f;
         }
     }
+#pragma unroll
+    for (int l = 0; l < NM_H2_BIAS_LAYERS + 3; ++l) cst[l * NM_W + threadIdx.x] = cst_v[l];
     __syncthreads();
     nm_phase_stamp(1);
     constexpr int KS0 = FIXED ? 13 : 0;
