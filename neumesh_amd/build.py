@@ -12,8 +12,7 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(CSRC, "libneumesh_hip.so")
 SOURCES = ["nm_api.hip"]
-HEADERS = ["nm_grid.h", "nm_grid_build.h", "nm_distance.h", "nm_rays.h", "nm_kernels.h", "nm_mlp.h", "nm_mlp_f16.h",
-           os.path.join("..", "..", "include", "neumesh_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "neumesh_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wno-unused-value"]
 
