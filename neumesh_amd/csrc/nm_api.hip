@@ -21,6 +21,7 @@
 #include "nm_mlp.h"
 #include "nm_mlp_f16.h"
 #include "nm_mlp_h2.h"
+#include "nm_mlp_h3.h"
 
 // ------------------------------------------------------------------------------ error state
 static thread_local std::string g_err;
@@ -109,7 +110,8 @@ struct nm_field_s {
     NmColParams col;
     float* blob = nullptr;  // packed weights
     size_t blob_floats = 0;
-    int precision = 0;       // 0 fp32, 1 split-half f16 (first layout), 2 split-half f16 (nm_mlp_h2.h, default)
+    int precision = 0;       // 0 fp32, 1 split-half f16 (first layout), 2 split-half f16 (nm_mlp_h2.h); mlp_precision 3 = 2 + use_h3
+    bool use_h3 = false;     // reference configuration with >= 2 layers: the pipelined kernels of nm_mlp_h3.h (same weights / numerics as mode 2)
     NmGeoParamsH geo_h;
     NmColParamsH col_h;
     NmGeoParamsH2 geo_h2;
@@ -326,7 +328,7 @@ static int nm_field_validate(const nm_field_desc* d) {
     if (d->multires_d < 0 || d->multires_fg < 0 || d->multires_ft < 0 || d->multires_view < 0) return nm_fail("nm_field: negative multires (identity embedders) unsupported");
     if (d->multires_d > 16 || d->multires_view > 16) return nm_fail("nm_field: multires too large");
     if (!d->use_view_dirs) return nm_fail("nm_field: use_view_dirs=0 unsupported");
-    if (d->mlp_precision < 0 || d->mlp_precision > 2) return nm_fail("nm_field: mlp_precision=%d (0 = fp32, 1 = split-half f16 first layout, 2 = split-half f16)", d->mlp_precision);
+    if (d->mlp_precision < 0 || d->mlp_precision > 3) return nm_fail("nm_field: mlp_precision=%d (0 = fp32, 1 = split-half f16 first layout, 2 = split-half f16, 3 = split-half f16 with pipelined epilogues)", d->mlp_precision);
     const int in_geo = 1 + 2 * d->multires_d + d->geometry_dim * (1 + 2 * d->multires_fg);
     const int in_col = (d->enable_nablas_input ? 3 : 0) + 1 + 2 * d->multires_d + 3 * (1 + 2 * d->multires_view) + d->color_dim * (1 + 2 * d->multires_ft);
     if (in_geo > 256 || in_col > 256) return nm_fail("nm_field: MLP input width %d/%d exceeds the 256-column LDS tile", in_geo, in_col);
@@ -396,7 +398,8 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
     f->col.d_emb = 1 + 2 * d->multires_d;
     f->col.in_dim = in_col;
     f->desc = *d;
-    f->precision = d->mlp_precision;
+    f->precision = d->mlp_precision == 3 ? 2 : d->mlp_precision;
+    f->use_h3 = d->mlp_precision == 3;
     if (d->mlp_precision >= 1) {
         size_t need_h = 0;
         for (int l = 0; l < d->D_density; ++l) need_h += (size_t)NM_W * nm_round16(l == 0 ? in_geo : NM_W) * 2;
@@ -436,7 +439,7 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
         f->col_h.multires_d = f->col.multires_d; f->col_h.multires_ft = f->col.multires_ft; f->col_h.multires_view = f->col.multires_view;
         f->col_h.cdim = f->col.cdim; f->col_h.use_nabla = f->col.use_nabla; f->col_h.d_emb = f->col.d_emb; f->col_h.in_dim = f->col.in_dim;
     }
-    if (d->mlp_precision == 2) {
+    if (f->precision == 2) {
         _Float16* ph = f->blob_h;
         memset(&f->geo_h2, 0, sizeof(f->geo_h2));
         memset(&f->col_h2, 0, sizeof(f->col_h2));
@@ -579,6 +582,13 @@ static int nm_launch_geo(nm_field_t f, const float* fg, const float* ds, const f
                          NmRecMap rmap = NM_COMPACT, int nabla_slotted = 0, NmSlotMap smap = NM_NO_SLOTS, bool counted = false) {
     if (P <= 0) return 0;
     NmProfScope prof(nabla ? NM_K_GEO_NABLA : NM_K_GEO, counted ? 0 : P, stream, counted ? NM_CNT_MID : NM_CNT_NONE);
+    if (f->precision == 2 && f->use_h3 && f->geo_fixed && f->geo_h2.D >= 2) {
+        const dim3 gr(nm_blocks(P, nabla ? 64 : 128)), bl(NM_H3_THREADS);
+        if (nabla) hipLaunchKernelGGL((nm_geo_mlp_h3_kernel<true>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow);
+        else hipLaunchKernelGGL((nm_geo_mlp_h3_kernel<false>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow);
+        NM_LAUNCH_CHECK();
+        return 0;
+    }
     if (f->precision == 2) {
         const dim3 gr(nm_blocks(P, nabla ? 32 : 64)), bl(NM_H_THREADS);
         if (nabla && f->geo_fixed) hipLaunchKernelGGL((nm_geo_mlp_h2_kernel<true, true>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow);
@@ -609,6 +619,11 @@ static int nm_launch_col(nm_field_t f, const float* ft, const float* ds, const f
                          long long P, float* rgb, hipStream_t stream, NmSlotMap smap = NM_NO_SLOTS, bool counted = false) {
     if (P <= 0) return 0;
     NmProfScope prof(NM_K_COLOR, counted ? 0 : P, stream, counted ? NM_CNT_MID : NM_CNT_NONE);
+    if (f->precision == 2 && f->use_h3 && f->col_fixed && f->col_h2.D >= 2) {
+        hipLaunchKernelGGL(nm_col_mlp_h3_kernel, dim3(nm_blocks(P, NM_H3_ROWS)), dim3(NM_H3_THREADS), 0, stream, f->col_h2, ft, ds, nabla, dirs, dir_div, P, rgb, smap, f->overflow);
+        NM_LAUNCH_CHECK();
+        return 0;
+    }
     if (f->precision == 2) {
         if (f->col_fixed) hipLaunchKernelGGL((nm_col_mlp_h2_kernel<true>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h2, ft, ds, nabla, dirs, dir_div, P, rgb, smap, f->overflow);
         else hipLaunchKernelGGL((nm_col_mlp_h2_kernel<false>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h2, ft, ds, nabla, dirs, dir_div, P, rgb, smap, f->overflow);

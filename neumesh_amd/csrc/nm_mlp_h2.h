@@ -123,20 +123,23 @@ __device__ __forceinline__ void nm_h2_split2(float a, float b, unsigned& p1, uns
     p2 = r;
 }
 // (mx: running max of |value| for the fp16-range check; pairs go through one max3)
+template <int PLANE = NM_H_PLANE>
 __device__ __forceinline__ void nm_h2_store1(_Float16* p, float a, float& mx) {
     _Float16 h1, h2;
     nm_h2_split(a, h1, h2);
     p[0] = h1;
-    p[NM_H_PLANE] = h2;
+    p[PLANE] = h2;
     mx = fmaxf(mx, fabsf(a));
 }
+template <int PLANE = NM_H_PLANE>
 __device__ __forceinline__ void nm_h2_store2(_Float16* p, float a, float b, float& mx) {  // p 4-byte aligned
     unsigned p1, p2;
     nm_h2_split2(a, b, p1, p2);
     *reinterpret_cast<unsigned*>(p) = p1;
-    *reinterpret_cast<unsigned*>(p + NM_H_PLANE) = p2;
+    *reinterpret_cast<unsigned*>(p + PLANE) = p2;
     mx = fmaxf(mx, fmaxf(fabsf(a), fabsf(b)));
 }
+template <int PLANE = NM_H_PLANE>
 __device__ __forceinline__ void nm_h2_store4(_Float16* p, const float (&v)[4], float& mx) {  // p 8-byte aligned
     uint2 a, b;
     nm_h2_split2(v[0], v[1], a.x, b.x);
@@ -144,8 +147,9 @@ __device__ __forceinline__ void nm_h2_store4(_Float16* p, const float (&v)[4], f
     mx = fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1])));
     mx = fmaxf(mx, fmaxf(fabsf(v[2]), fabsf(v[3])));
     *reinterpret_cast<uint2*>(p) = a;
-    *reinterpret_cast<uint2*>(p + NM_H_PLANE) = b;
+    *reinterpret_cast<uint2*>(p + PLANE) = b;
 }
+template <int PLANE = NM_H_PLANE>
 __device__ __forceinline__ void nm_h2_store8(_Float16* p, const float (&v)[8], float& mx) {  // p 16-byte aligned
     uint4 a, b;
     nm_h2_split2(v[0], v[1], a.x, b.x);
@@ -155,28 +159,29 @@ __device__ __forceinline__ void nm_h2_store8(_Float16* p, const float (&v)[8], f
 #pragma unroll
     for (int e = 0; e < 8; e += 2) mx = fmaxf(fmaxf(mx, fabsf(v[e])), fabsf(v[e + 1]));
     *reinterpret_cast<uint4*>(p) = a;
-    *reinterpret_cast<uint4*>(p + NM_H_PLANE) = b;
+    *reinterpret_cast<uint4*>(p + PLANE) = b;
 }
 // zero columns [c0, c1) of a tile row, both planes (c0 a multiple of 8: 16-byte stores, then singles)
+template <int PLANE = NM_H_PLANE>
 __device__ __forceinline__ void nm_h2_zero_cols(_Float16* row, int c0, int c1, int j) {
     const nm_h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     const int full = (c1 - c0) >> 3;
     for (int b = j; b < full; b += 8) {
         *reinterpret_cast<nm_h8*>(row + c0 + 8 * b) = z;
-        *reinterpret_cast<nm_h8*>(row + NM_H_PLANE + c0 + 8 * b) = z;
+        *reinterpret_cast<nm_h8*>(row + PLANE + c0 + 8 * b) = z;
     }
     for (int c = c0 + 8 * full + j; c < c1; c += 8) {
         row[c] = (_Float16)0.0f;
-        row[NM_H_PLANE + c] = (_Float16)0.0f;
+        row[PLANE + c] = (_Float16)0.0f;
     }
 }
 
 // x and its sin/cos bands for 4 consecutive dims of a `dim`-wide code vector, into an embedding block
 // that starts at blk[0]: 8-byte stores (dim is a multiple of 4).  Odd bands from the even band below
 // by the double-angle identities, as nm_embed4_h.
-template <bool FAST>
+template <bool FAST, int PLANE = NM_H_PLANE>
 __device__ __forceinline__ void nm_h2_embed_chunk_t(_Float16* blk, int dim, int bands, int chunk, const float (&xs)[4], float& mx) {
-    nm_h2_store4(blk + 4 * chunk, xs, mx);
+    nm_h2_store4<PLANE>(blk + 4 * chunk, xs, mx);
     float f = 1.0f;
     for (int b = 0; b < bands; b += 2) {
         float s[4], c[4];
@@ -185,8 +190,8 @@ __device__ __forceinline__ void nm_h2_embed_chunk_t(_Float16* blk, int dim, int 
             if (FAST) nm_sincos_fast(xs[e] * f, &s[e], &c[e]);
             else nm_sincos(xs[e] * f, &s[e], &c[e]);
         }
-        nm_h2_store4(blk + dim * (1 + 2 * b) + 4 * chunk, s, mx);
-        nm_h2_store4(blk + dim * (2 + 2 * b) + 4 * chunk, c, mx);
+        nm_h2_store4<PLANE>(blk + dim * (1 + 2 * b) + 4 * chunk, s, mx);
+        nm_h2_store4<PLANE>(blk + dim * (2 + 2 * b) + 4 * chunk, c, mx);
         if (b + 1 < bands) {
             float s2[4], c2[4];
 #pragma unroll
@@ -194,19 +199,20 @@ __device__ __forceinline__ void nm_h2_embed_chunk_t(_Float16* blk, int dim, int 
                 s2[e] = 2.0f * s[e] * c[e];
                 c2[e] = (c[e] - s[e]) * (c[e] + s[e]);
             }
-            nm_h2_store4(blk + dim * (3 + 2 * b) + 4 * chunk, s2, mx);
-            nm_h2_store4(blk + dim * (4 + 2 * b) + 4 * chunk, c2, mx);
+            nm_h2_store4<PLANE>(blk + dim * (3 + 2 * b) + 4 * chunk, s2, mx);
+            nm_h2_store4<PLANE>(blk + dim * (4 + 2 * b) + 4 * chunk, c2, mx);
         }
         f *= 4.0f;
     }
 }
 // One range test per chunk instead of one per sincos: the straight-line fast path (every argument within the polynomial
 // reduction's range -- always, for trained codes) lets the four evaluations of a band overlap; same values either way.
+template <int PLANE = NM_H_PLANE>
 __device__ __forceinline__ void nm_h2_embed_chunk(_Float16* blk, int dim, int bands, int chunk, float4 x, float& mx) {
     const float xs[4] = {x.x, x.y, x.z, x.w};
     const float top = fmaxf(fmaxf(fabsf(xs[0]), fabsf(xs[1])), fmaxf(fabsf(xs[2]), fabsf(xs[3]))) * (float)(1 << ((bands > 0 ? bands - 1 : 0) & ~1));  // (largest frequency evaluated directly: the highest even band)
-    if (top <= NM_SINCOS_FAST_MAX) nm_h2_embed_chunk_t<true>(blk, dim, bands, chunk, xs, mx);
-    else nm_h2_embed_chunk_t<false>(blk, dim, bands, chunk, xs, mx);
+    if (top <= NM_SINCOS_FAST_MAX) nm_h2_embed_chunk_t<true, PLANE>(blk, dim, bands, chunk, xs, mx);
+    else nm_h2_embed_chunk_t<false, PLANE>(blk, dim, bands, chunk, xs, mx);
 }
 
 // Softplus(beta = 100) in "log2 units".  With S = 100 / ln 2 the reference's y = softplus(z) = log2(1 + 2^(S z)) / S, so

@@ -53,7 +53,7 @@ def get_embedder(multires: int, input_dim: int = 3):
 
 
 # mlp_precision -> nm_field_desc.mlp_precision ("f16x2_v1": the first split-half kernels, kept for A/B runs)
-_PRECISION_CODES = {"fp32": 0, "f16x2_v1": 1, "f16x2": 2}
+_PRECISION_CODES = {"fp32": 0, "f16x2_v1": 1, "f16x2": 2, "f16x2_v3": 3}
 
 
 def interpolation(features, indices, weights):
