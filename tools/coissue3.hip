@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512) void k(float* out, long long* cyc, int iters) 
 }
 
 template <int MODE>
-void run(const char* name, int fillers, bool mfma, float* out, long long* cyc) {
+void run(const char* name, int fillers, bool mfma, float* out, long long* cyc, int per_trip = 8) {
     const int iters = 2000;
     for (int threads = 256; threads <= 512; threads += 256) {
         for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<MODE>), dim3(256), dim3(threads), 0, 0, out, cyc, iters);
@@ -93,7 +93,7 @@ void run(const char* name, int fillers, bool mfma, float* out, long long* cyc) {
         (void)hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
         double t = 0; const int nw = threads / 64;
         for (int b = 0; b < 256; ++b) for (int w = 0; w < nw; ++w) t += (double)h[b * 8 + w];
-        t /= 256.0 * nw * iters * 8;   // per [MFMA + fillers] group of one wave
+        t /= 256.0 * nw * iters * per_trip;   // per [MFMA + fillers] group of one wave
         if (mfma) printf("%-34s %d wave/SIMD: %6.1f cycles per (MFMA + %2d fillers) of a wave = %5.1f per MFMA of the SIMD\n", name, threads / 256, t, fillers, t / (threads / 256));
         else printf("%-34s %d wave/SIMD: %6.2f cycles per filler instruction of a wave\n", name, threads / 256, t / fillers);
     }
@@ -114,18 +114,18 @@ int main() {
     run<7>("MFMA + 2 v_exp", 2, true, out, cyc);
     run<8>("MFMA + mix7 (5 plain, 2 trans)", 7, true, out, cyc);
     run<10>("MFMA + 2 x mix7", 14, true, out, cyc);
-    printf("dependency patterns (12 MFMAs per trip; the per-MFMA figure below is x 8/12 of the printed one):\n");
-    run<13>("v3 order (4 acc: h0 h1 l0 l1 l0 l1)", 0, true, out, cyc);
-    run<14>("v3 reordered (l0 h0 l1 h1 l0 l1)", 0, true, out, cyc);
-    run<15>("v2 order (8 acc)", 0, true, out, cyc);
-    run<16>("v3 order + 3 fillers", 3, true, out, cyc);
-    run<17>("v2 order + 3 fillers", 3, true, out, cyc);
-    run<20>("v3 order + ds_read_b128 per MFMA", 1, true, out, cyc);
-    run<21>("v3 order + global_load x4 per MFMA", 1, true, out, cyc);
-    run<22>("v3 order + ds_read + waitcnt", 2, true, out, cyc);
-    run<23>("v3 order + global_load + waitcnt", 2, true, out, cyc);
-    run<24>("v3 order + 3 valu + 1 mem", 4, true, out, cyc);
-    run<25>("v2 order + ds_read per MFMA", 1, true, out, cyc);
+    printf("dependency patterns of the real K loops (12 MFMAs per trip), memory instructions as fillers:\n");
+    run<13>("v3 order (4 acc: h0 h1 l0 l1 l0 l1)", 0, true, out, cyc, 12);
+    run<14>("v3 reordered (l0 h0 l1 h1 l0 l1)", 0, true, out, cyc, 12);
+    run<15>("v2 order (8 acc)", 0, true, out, cyc, 12);
+    run<16>("v3 order + 3 fillers", 3, true, out, cyc, 12);
+    run<17>("v2 order + 3 fillers", 3, true, out, cyc, 12);
+    run<20>("v3 order + ds_read_b128 per MFMA", 1, true, out, cyc, 12);
+    run<21>("v3 order + global_load x4 per MFMA", 1, true, out, cyc, 12);
+    run<22>("v3 order + ds_read + waitcnt", 2, true, out, cyc, 12);
+    run<23>("v3 order + global_load + waitcnt", 2, true, out, cyc, 12);
+    run<24>("v3 order + 3 valu + 1 mem", 4, true, out, cyc, 12);
+    run<25>("v2 order + ds_read per MFMA", 1, true, out, cyc, 12);
     run<11>("8 v_fma alone", 8, false, out, cyc);
     run<12>("mix7 alone", 7, false, out, cyc);
     return 0;
