@@ -26,6 +26,11 @@
 #define V3STEP(F) MF(0, 15) F MF(16, 31) F MF(32, 47) F MF(48, 63) F MF(32, 47) F MF(48, 63) F
 // v3 reordered: lo0 hi0 lo1 hi1 lo0 lo1
 #define V3RSTEP(F) MF(32, 47) F MF(0, 15) F MF(48, 63) F MF(16, 31) F MF(32, 47) F MF(48, 63) F
+// the kernels' real mix per k-step of 6 MFMAs: 2 weight loads (1 KiB each), 4 LDS reads, optionally 3 vector instructions per MFMA
+#define KSTEP_MEM MF(0, 15) GLD MF(16, 31) DSR MF(32, 47) DSR MF(48, 63) GLD MF(32, 47) DSR MF(48, 63) DSR
+#define KSTEP_ALL MF(0, 15) GLD FMA2 EXP1 MF(16, 31) DSR FMA2 EXP1 MF(32, 47) DSR FMA2 EXP1 MF(48, 63) GLD FMA2 EXP1 MF(32, 47) DSR FMA2 EXP1 MF(48, 63) DSR FMA2 EXP1
+#define KSTEP_VALU MF(0, 15) FMA2 EXP1 MF(16, 31) FMA2 EXP1 MF(32, 47) FMA2 EXP1 MF(48, 63) FMA2 EXP1 MF(32, 47) FMA2 EXP1 MF(48, 63) FMA2 EXP1
+#define KSTEP_GLD MF(0, 15) GLD MF(16, 31) MF(32, 47) MF(48, 63) GLD MF(32, 47) MF(48, 63)
 // v2: 8 accumulators, hi x4, lo x4, lo x4
 #define V2STEP(F) MF(0, 15) F MF(16, 31) F MF(32, 47) F MF(48, 63) F MF(64, 79) F MF(80, 95) F MF(96, 111) F MF(112, 127) F MF(64, 79) F MF(80, 95) F MF(96, 111) F MF(112, 127) F
 
@@ -60,6 +65,10 @@ __global__ __launch_bounds__(512) void k(float* out, long long* cyc, int iters) 
     if (MODE == 23) { LOOP(V3STEP(GLD WAITV) V3STEP(GLD WAITV)) }
     if (MODE == 24) { LOOP(V3STEP(FMA2 EXP1 DSR) V3STEP(FMA2 EXP1 GLD)) }
     if (MODE == 25) { LOOP(V2STEP(DSR)) }
+    if (MODE == 30) { LOOP(KSTEP_MEM KSTEP_MEM) }
+    if (MODE == 31) { LOOP(KSTEP_ALL KSTEP_ALL) }
+    if (MODE == 32) { LOOP(KSTEP_VALU KSTEP_VALU) }
+    if (MODE == 33) { LOOP(KSTEP_GLD KSTEP_GLD) }
     if (MODE == 0) { LOOP(TRIP(NOFILL)) }
     if (MODE == 1) { LOOP(TRIP(FMA2)) }
     if (MODE == 2) { LOOP(TRIP(FMA4)) }
@@ -126,6 +135,11 @@ int main() {
     run<23>("v3 order + global_load + waitcnt", 2, true, out, cyc, 12);
     run<24>("v3 order + 3 valu + 1 mem", 4, true, out, cyc, 12);
     run<25>("v2 order + ds_read per MFMA", 1, true, out, cyc, 12);
+    printf("the K loops' instruction mix (per 6 MFMAs: 2 x 1 KiB loads, 4 ds_read_b128, 18 vector instructions):\n");
+    run<33>("MFMA + the 2 weight loads only", 0, true, out, cyc, 12);
+    run<30>("MFMA + loads + LDS reads", 1, true, out, cyc, 12);
+    run<32>("MFMA + 3 vector per MFMA", 3, true, out, cyc, 12);
+    run<31>("MFMA + loads + LDS reads + 3 vector", 4, true, out, cyc, 12);
     run<11>("8 v_fma alone", 8, false, out, cyc);
     run<12>("mix7 alone", 7, false, out, cyc);
     return 0;
