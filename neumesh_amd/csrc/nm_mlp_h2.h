@@ -492,301 +492,6 @@ __device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L
     nm_phase_stamp(stamp_slot + 1);
 }
 
-// ------------------------------------------------------------------ layer with the column tiles one after the other
-// (NM_H2_CTSPLIT, straight-line layers of the reference-configuration kernels).  A wave's two column tiles run as two K
-// loops of 6 MFMAs per k-step; the epilogue ARITHMETIC of the first tile (combine, activation, split into halves, or the
-// head sums) is issued inside the K loop of the second one -- vector instructions between the MFMAs of the same wave are
-// free up to ~4 per MFMA (tools/coissue3.hip) -- and only its LDS stores wait for the barrier that ends the layer's reads
-// of the tile.  Weight traffic, barriers and the arithmetic of every accumulator are unchanged (bit-identical results);
-// the activation fragments are read twice from LDS (free beside MFMAs).  Half of each layer's epilogue leaves the
-// exposed part of the tile's life.
-#ifndef NM_H2_CTSPLIT
-#define NM_H2_CTSPLIT 1
-#endif
-#ifndef NM_H2_CT_SCHED
-#define NM_H2_CT_SCHED 1
-#endif
-#ifndef NM_H2_VPM
-#define NM_H2_VPM 3  // vector instructions the scheduling pattern places behind each MFMA of the second K loop
-#endif
-struct NmAccCt {  // one column tile of a wave: [row tile]
-    nm_f32x16 hi[2], lo[2];
-};
-__device__ __forceinline__ void nm_h2_pack8(const float (&v)[8], uint4& a, uint4& b, float& mx) {
-    nm_h2_split2(v[0], v[1], a.x, b.x);
-    nm_h2_split2(v[2], v[3], a.y, b.y);
-    nm_h2_split2(v[4], v[5], a.z, b.z);
-    nm_h2_split2(v[6], v[7], a.w, b.w);
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) mx = fmaxf(fmaxf(mx, fabsf(v[e])), fabsf(v[e + 1]));
-}
-// epilogue of one column tile in two chunks (hf = 0, 1: 8 of the lane's 16 columns, both row tiles -- the tangent row
-// tile needs the value row tile's act'(z)); results as packed halves (stored later) or added to the head sums
-template <int ACT, bool TANGENT, bool LAST, int NOUT>
-struct NmEpiCt {
-    const float (&z)[2][16];  // pre-activations of the tile: [row tile][register], main + scaled accumulator already combined
-    uint4 (&p1)[2][2];   // [row tile][hf] plane h1
-    uint4 (&p2)[2][2];
-    const float* head_w;  // LDS [NOUT][256] + first column of the lane in this tile (LAST)
-    float (&so)[2][NOUT];
-    float& mx;
-    static constexpr int NQ = 8;
-    // chunk q: 2 of the lane's 16 columns (registers 2 q, 2 q + 1), both row tiles: one chunk per k-step of the K loop it is
-    // spread over keeps its temporaries few and the loop's load issue points where the sched_barriers pin them
-    __device__ __forceinline__ void chunk(const int q) {
-        float y0[2], y1[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const float z0 = z[0][2 * q + r], z1 = z[1][2 * q + r];
-            if (TANGENT) {
-                float g0;
-                if (ACT == 0) {
-                    y0[r] = nm_softplus_l2(z0, &g0);
-                } else {
-                    y0[r] = fmaxf(z0, 0.f);
-                    g0 = z0 > 0.f ? 1.f : 0.f;
-                }
-                y1[r] = z1 * g0;
-            } else {
-                if (ACT == 0) {
-                    y0[r] = nm_softplus_l2(z0, nullptr);
-                    y1[r] = nm_softplus_l2(z1, nullptr);
-                } else {
-                    y0[r] = fmaxf(z0, 0.f);
-                    y1[r] = fmaxf(z1, 0.f);
-                }
-            }
-        }
-        if (!LAST) {
-            unsigned a0, b0, a1, b1;
-            nm_h2_split2(y0[0], y0[1], a0, b0);
-            nm_h2_split2(y1[0], y1[1], a1, b1);
-            const int hf = q >> 2, e = q & 3;
-            (e == 0 ? p1[0][hf].x : e == 1 ? p1[0][hf].y : e == 2 ? p1[0][hf].z : p1[0][hf].w) = a0;
-            (e == 0 ? p2[0][hf].x : e == 1 ? p2[0][hf].y : e == 2 ? p2[0][hf].z : p2[0][hf].w) = b0;
-            (e == 0 ? p1[1][hf].x : e == 1 ? p1[1][hf].y : e == 2 ? p1[1][hf].z : p1[1][hf].w) = a1;
-            (e == 0 ? p2[1][hf].x : e == 1 ? p2[1][hf].y : e == 2 ? p2[1][hf].z : p2[1][hf].w) = b1;
-            mx = fmaxf(fmaxf(mx, fabsf(y0[0])), fabsf(y0[1]));
-            mx = fmaxf(fmaxf(mx, fabsf(y1[0])), fabsf(y1[1]));
-        } else {
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o) {
-                const float2 w = *reinterpret_cast<const float2*>(head_w + o * NM_W + 2 * q);
-                so[0][o] = fmaf(y0[0], w.x, so[0][o]);
-                so[1][o] = fmaf(y1[0], w.x, so[1][o]);
-                so[0][o] = fmaf(y0[1], w.y, so[0][o]);
-                so[1][o] = fmaf(y1[1], w.y, so[1][o]);
-            }
-        }
-    }
-};
-struct NmNoEpiCt {
-    static constexpr int NQ = 0;
-    __device__ __forceinline__ void chunk(int) {}
-};
-// K loop of ONE column tile: k-steps [0, KS), row tile 1 from k-step KT0 on (its accumulators start there, at zero);
-// weight fragments two k-steps ahead in three register sets (k-steps 0 and 1 arrive in p0 / p1), activation fragments
-// one ahead; in four blocks, the epilogue chunks of `epi` spread over them.
-template <int KS, int KT0, class Epi>
-__device__ __forceinline__ void nm_kloop_h2_ct(const _Float16* a0p, const _Float16* a1p, const nm_rsrc bp, const int lane,
-                                               const NmBFrag<1>& p0, const NmBFrag<1>& p1, NmAccCt& c, Epi& epi) {
-    constexpr int NB = KS;  // one block per k-step: the sched_barriers pin the load issue points as in nm_kloop_h2
-    NmBFrag<1> f[3];
-    f[0] = p0;
-    f[1] = p1;
-    nm_h8 a[2][2][2];  // [buffer][row tile][plane]
-    a[0][0][0] = *reinterpret_cast<const nm_h8*>(a0p);
-    a[0][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
-    if (KT0 == 0) {
-        a[0][1][0] = *reinterpret_cast<const nm_h8*>(a1p);
-        a[0][1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE);
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        __builtin_amdgcn_sched_barrier(0);
-        int n_mfma = 0;
-#pragma unroll
-        for (int ks = b * KS / NB; ks < (b + 1) * KS / NB; ++ks) {
-            if (KT0 > 0 && ks == KT0) c.hi[1] = c.lo[1] = nm_f32x16{0};
-            if (ks + 2 < KS) {
-                f[(ks + 2) % 3].a[0] = __builtin_bit_cast(nm_h8, __builtin_amdgcn_raw_buffer_load_b128(bp, lane * 16, (ks + 2) * 2048, 0));
-                f[(ks + 2) % 3].b[0] = __builtin_bit_cast(nm_h8, __builtin_amdgcn_raw_buffer_load_b128(bp, lane * 16, (ks + 2) * 2048 + 1024, 0));
-            }
-            if (ks + 1 < KS) {
-                const int oa = (ks + 1) * 16;
-                a[(ks + 1) & 1][0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
-                a[(ks + 1) & 1][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
-                if (ks + 1 >= KT0) {
-                    a[(ks + 1) & 1][1][0] = *reinterpret_cast<const nm_h8*>(a1p + oa);
-                    a[(ks + 1) & 1][1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE + oa);
-                }
-            }
-            const NmBFrag<1>& F = f[ks % 3];
-            const int nrt = ks >= KT0 ? 2 : 1;
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                if (rt < nrt) c.hi[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[0], a[ks & 1][rt][0], c.hi[rt], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                if (rt < nrt) c.lo[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.b[0], a[ks & 1][rt][0], c.lo[rt], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-                if (rt < nrt) c.lo[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[0], a[ks & 1][rt][1], c.lo[rt], 0, 0, 0);
-            n_mfma += 3 * nrt;
-        }
-        if (Epi::NQ > 0) {
-#pragma unroll
-            for (int q = 0; q < (Epi::NQ > 0 ? Epi::NQ : 1); ++q)
-                if (q * NB / (Epi::NQ > 0 ? Epi::NQ : 1) == b) epi.chunk(q);
-#if NM_H2_CT_SCHED
-#pragma unroll
-            for (int m = 0; m < n_mfma; ++m) {  // issue pattern inside the block: one MFMA, a few vector instructions, one load
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x402, NM_H2_VPM, 0);
-                __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);
-            }
-#endif
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-// main + scaled accumulator -> pre-activation (the bias is already in the main accumulator): halves the registers a
-// finished column tile occupies while the next one accumulates
-__device__ __forceinline__ void nm_h2_combine_ct(const NmAccCt& c, float (&z)[2][16]) {
-    const float sc = 1.0f / 2048.0f;
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[rt][r] = fmaf(c.lo[rt][r], sc, c.hi[rt][r]);
-}
-__device__ __forceinline__ void nm_prefetch_ct(const NmLayerH L, int ctile, int lane, NmBFrag<1>& p0, NmBFrag<1>& p1) {
-    const nm_rsrc r = nm_b_rsrc(L.W, L.Kpad, ctile);
-    p0.a[0] = __builtin_bit_cast(nm_h8, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, 0, 0));
-    p0.b[0] = __builtin_bit_cast(nm_h8, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, 1024, 0));
-    p1.a[0] = __builtin_bit_cast(nm_h8, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, 2048, 0));
-    p1.b[0] = __builtin_bit_cast(nm_h8, __builtin_amdgcn_raw_buffer_load_b128(r, lane * 16, 2048 + 1024, 0));
-}
-// accumulators of one column tile: value rows start at the bias of the lane's 16 columns (colb ..), tangent rows at zero
-template <bool TANGENT>
-__device__ __forceinline__ void nm_h2_init_ct(NmAccCt& c, const float* cst, const int bias_row, const float* bias_global, const int colb, const bool rt1_later) {
-    float4 b4[4];
-    if (bias_row >= 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(cst + bias_row * NM_W + colb + 4 * q);
-    } else {
-        const nm_rsrc rb = __builtin_amdgcn_make_buffer_rsrc((void*)bias_global, 0, NM_W * 4, 0x00020000);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) b4[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, (colb + 4 * q) * 4, 0, 0));
-    }
-    nm_f32x16 bv;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        bv[4 * q + 0] = b4[q].x; bv[4 * q + 1] = b4[q].y; bv[4 * q + 2] = b4[q].z; bv[4 * q + 3] = b4[q].w;
-    }
-    c.hi[0] = bv;
-    c.lo[0] = nm_f32x16{0};
-    if (!rt1_later) {
-        c.hi[1] = TANGENT ? nm_f32x16{0} : bv;
-        c.lo[1] = nm_f32x16{0};
-    }
-}
-// contract as nm_mlp_layer_h2 (below) with KSF > 0; `pre`: only the column-tile-0 entries (s[i].a[0] / .b[0]) are used
-template <int ACT, bool TANGENT, bool LAST, int NOUT, int KSF, int KT0F>
-__device__ __forceinline__ void nm_mlp_layer_h2s(_Float16* tile, const NmLayerH L, const bool has_next, const NmLayerH next, NmBPre<2>& pre,
-                                                 const float* cst, const int bias_row, const float* head_w, float* red, float& mx, int stamp_slot) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int li = lane & 31, h = lane >> 5;
-    const int n0 = wave * 64;
-    const _Float16* a0p = tile + li * NM_H_STRIDE + 8 * h;
-    const _Float16* a1p = tile + (32 + li) * NM_H_STRIDE + 8 * h;
-    NmBFrag<1> q0, q1, r0, r1;   // first two k-steps of column tile 0 (from pre) and of column tile 1 (requested now)
-    q0.a[0] = pre.s[0].a[0]; q0.b[0] = pre.s[0].b[0];
-    q1.a[0] = pre.s[1].a[0]; q1.b[0] = pre.s[1].b[0];
-    nm_prefetch_ct(L, wave * 2 + 1, lane, r0, r1);
-    NmAccCt c0, c1;
-    uint4 p1[2][2], p2[2][2];
-    float so[2][NOUT];
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o) so[0][o] = so[1][o] = 0.f;
-    nm_h2_init_ct<TANGENT>(c0, cst, bias_row, L.b, n0 + 16 * h, KT0F > 0);
-    {
-        NmNoEpiCt none;
-        nm_kloop_h2_ct<KSF, KT0F>(a0p, a1p, nm_b_rsrc(L.W, L.Kpad, wave * 2), lane, q0, q1, c0, none);
-    }
-    float z0[2][16];
-    nm_h2_combine_ct(c0, z0);  // (before the first sched_barrier of the next loop: c0's 64 registers are free inside it)
-    nm_h2_init_ct<TANGENT>(c1, cst, bias_row, L.b, n0 + 32 + 16 * h, KT0F > 0);
-    {
-        NmEpiCt<ACT, TANGENT, LAST, NOUT> e = {z0, p1, p2, head_w + n0 + 16 * h, so, mx};
-        nm_kloop_h2_ct<KSF, KT0F>(a0p, a1p, nm_b_rsrc(L.W, L.Kpad, wave * 2 + 1), lane, r0, r1, c1, e);
-    }
-    if (has_next) {
-        NmBFrag<1> n0f, n1f;
-        nm_prefetch_ct(next, wave * 2, lane, n0f, n1f);
-        pre.s[0].a[0] = n0f.a[0]; pre.s[0].b[0] = n0f.b[0];
-        pre.s[1].a[0] = n1f.a[0]; pre.s[1].b[0] = n1f.b[0];
-    }
-    if (!LAST) __syncthreads();  // every wave has finished reading the input tile
-    nm_phase_stamp(stamp_slot);
-    _Float16* d0 = tile + li * NM_H_STRIDE + n0 + 16 * h;
-    _Float16* d1 = tile + (32 + li) * NM_H_STRIDE + n0 + 16 * h;
-    if (!LAST) {
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            *reinterpret_cast<uint4*>(d0 + 8 * hf) = p1[0][hf];
-            *reinterpret_cast<uint4*>(d0 + NM_H_PLANE + 8 * hf) = p2[0][hf];
-            *reinterpret_cast<uint4*>(d1 + 8 * hf) = p1[1][hf];
-            *reinterpret_cast<uint4*>(d1 + NM_H_PLANE + 8 * hf) = p2[1][hf];
-        }
-    }
-    {   // column tile 1: its epilogue has nothing left to hide behind
-        uint4 s1[2][2], s2[2][2];
-        float z1[2][16];
-        nm_h2_combine_ct(c1, z1);
-        NmEpiCt<ACT, TANGENT, LAST, NOUT> e = {z1, s1, s2, head_w + n0 + 32 + 16 * h, so, mx};
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) e.chunk(4 * hf + e4);
-            if (!LAST) {
-                *reinterpret_cast<uint4*>(d0 + 32 + 8 * hf) = s1[0][hf];
-                *reinterpret_cast<uint4*>(d0 + NM_H_PLANE + 32 + 8 * hf) = s2[0][hf];
-                *reinterpret_cast<uint4*>(d1 + 32 + 8 * hf) = s1[1][hf];
-                *reinterpret_cast<uint4*>(d1 + NM_H_PLANE + 32 + 8 * hf) = s2[1][hf];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (!LAST) {
-        __syncthreads();
-    } else {
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o) {  // the two half-waves hold the same points, different columns
-            so[0][o] += __shfl_xor(so[0][o], 32);
-            so[1][o] += __shfl_xor(so[1][o], 32);
-        }
-        if (h == 0) {
-#pragma unroll
-            for (int o = 0; o < NOUT; ++o) {
-                red[(wave * NM_ROWS + li) * NOUT + o] = so[0][o];
-                red[(wave * NM_ROWS + 32 + li) * NOUT + o] = so[1][o];
-            }
-        }
-        __syncthreads();
-    }
-    nm_phase_stamp(stamp_slot + 1);
-}
-
-// layer dispatch of the kernels: SPLIT (reference-configuration kernels, NM_H2_CTSPLIT) takes the column-tile-split form
-// for straight-line layers
-template <bool SPLIT, int ACT, bool TANGENT, bool LAST, int NOUT, int CT, int KSF, int KT0F, int DEPTH>
-__device__ __forceinline__ void nm_layer_h2(_Float16* tile, const NmLayerH L, const int kt0, const bool has_next, const NmLayerH next,
-                                            NmBPre<CT>& pre, const float* cst, const int bias_row, const float* head_w,
-                                            float* red, float& mx, int stamp_slot) {
-    if constexpr (SPLIT && KSF > 0 && CT == 2) nm_mlp_layer_h2s<ACT, TANGENT, LAST, NOUT, KSF, KT0F>(tile, L, has_next, next, pre, cst, bias_row, head_w, red, mx, stamp_slot);
-    else nm_mlp_layer_h2<ACT, TANGENT, LAST, NOUT, CT, KSF, KT0F, DEPTH>(tile, L, kt0, has_next, next, pre, cst, bias_row, head_w, red, mx, stamp_slot);
-}
-
 __device__ __forceinline__ void nm_h2_raise(int* overflow, float mx) {
     if (overflow && !(mx < NM_H2_FP16_MAX)) *overflow = 1;  // (benign race: every writer stores 1)
 }
@@ -934,14 +639,14 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
     constexpr int KS0 = FIXED ? 12 : 0, KT0 = (FIXED && NABLA) ? 10 : 0;
     const float* head = cst + NM_H2_BIAS_LAYERS * NM_W;
     if (prm.D == 1) {
-        nm_layer_h2<(FIXED && NM_H2_CTSPLIT), 0, NABLA, true, 1, NM_H_CT, KS0, KT0, DEPTH0>(tile, prm.layer[0], kt0, false, prm.layer[0], pre, cst, 0, head, red, mx, 2);
+        nm_mlp_layer_h2<0, NABLA, true, 1, NM_H_CT, KS0, KT0, DEPTH0>(tile, prm.layer[0], kt0, false, prm.layer[0], pre, cst, 0, head, red, mx, 2);
     } else {
-        nm_layer_h2<(FIXED && NM_H2_CTSPLIT), 0, NABLA, false, 1, NM_H_CT, KS0, KT0, DEPTH0>(tile, prm.layer[0], kt0, true, prm.layer[1], pre, cst, 0, nullptr, red, mx, 2);
+        nm_mlp_layer_h2<0, NABLA, false, 1, NM_H_CT, KS0, KT0, DEPTH0>(tile, prm.layer[0], kt0, true, prm.layer[1], pre, cst, 0, nullptr, red, mx, 2);
         for (int l = 1; l + 1 < prm.D; ++l)
-            nm_layer_h2<(FIXED && NM_H2_CTSPLIT), 0, NABLA, false, 1, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre,
+            nm_mlp_layer_h2<0, NABLA, false, 1, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre,
                                                                     cst, l < NM_H2_BIAS_LAYERS ? l : -1, nullptr, red, mx, 2 + 2 * l);
         const int l = prm.D - 1;
-        nm_layer_h2<(FIXED && NM_H2_CTSPLIT), 0, NABLA, true, 1, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, false, prm.layer[l], pre,
+        nm_mlp_layer_h2<0, NABLA, true, 1, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, false, prm.layer[l], pre,
                                                                cst, l < NM_H2_BIAS_LAYERS ? l : -1, head, red, mx, 2 + 2 * l);
     }
     if (threadIdx.x < PTS) {
@@ -1071,14 +776,14 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
     constexpr int KS0 = FIXED ? 13 : 0;
     const float* head = cst + NM_H2_BIAS_LAYERS * NM_W;
     if (prm.D == 1) {
-        nm_layer_h2<(FIXED && NM_H2_CTSPLIT), 1, false, true, 3, NM_H_CT, KS0, 0, 2>(tile, prm.layer[0], 0, false, prm.layer[0], pre, cst, 0, head, red, mx, 2);
+        nm_mlp_layer_h2<1, false, true, 3, NM_H_CT, KS0, 0, 2>(tile, prm.layer[0], 0, false, prm.layer[0], pre, cst, 0, head, red, mx, 2);
     } else {
-        nm_layer_h2<(FIXED && NM_H2_CTSPLIT), 1, false, false, 3, NM_H_CT, KS0, 0, 2>(tile, prm.layer[0], 0, true, prm.layer[1], pre, cst, 0, nullptr, red, mx, 2);
+        nm_mlp_layer_h2<1, false, false, 3, NM_H_CT, KS0, 0, 2>(tile, prm.layer[0], 0, true, prm.layer[1], pre, cst, 0, nullptr, red, mx, 2);
         for (int l = 1; l + 1 < prm.D; ++l)
-            nm_layer_h2<(FIXED && NM_H2_CTSPLIT), 1, false, false, 3, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre,
+            nm_mlp_layer_h2<1, false, false, 3, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre,
                                                                     cst, l < NM_H2_BIAS_LAYERS ? l : -1, nullptr, red, mx, 2 + 2 * l);
         const int l = prm.D - 1;
-        nm_layer_h2<(FIXED && NM_H2_CTSPLIT), 1, false, true, 3, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, false, prm.layer[l], pre,
+        nm_mlp_layer_h2<1, false, true, 3, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, false, prm.layer[l], pre,
                                                                cst, l < NM_H2_BIAS_LAYERS ? l : -1, head, red, mx, 2 + 2 * l);
     }
     if (threadIdx.x < NM_ROWS) {  // one thread per point: its three channels are one 12-byte store
