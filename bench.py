@@ -118,7 +118,9 @@ def cpu_baseline(mesh, model, H, W, n_rays, rays0, samples=128, white_bkgd=False
         import tempfile
         from oracle import cpu_pool
         workers = max(1, min(os.cpu_count() or 1, 256))
-        per = max(16, int(min(256, round(res["value"] / 4.0 * 15.0))))   # ~15 s per worker if one thread does a quarter of the all-thread rate
+        # rays per worker for ~15-20 s: measured on the 256-core box, the processes together do only ~2x the one-process
+        # all-threads rate (the oracle is memory-bound and the box's cores share their caches), i.e. ~value * 2 / workers each
+        per = max(8, int(min(256, round(res["value"] * 2.0 / workers * 16.0))))
         with tempfile.TemporaryDirectory() as td:
             path = os.path.join(td, "scene.npz")
             np.savez(path, vertices=mesh.vertices, rays_o=o, rays_d=d, H=H, W=W, samples=samples, white_bkgd=white_bkgd, calc_normal=calc_normal,
