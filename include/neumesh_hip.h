@@ -114,7 +114,9 @@ typedef struct nm_field_desc {
     int32_t mlp_precision;     /* 0: fp32 MFMA (reference numerics); 2: split-half f16 MFMA -- every
                                   value carried as two fp16 halves (22 bits), 3 f16 MFMAs per product,
                                   fp32 accumulation; |activations| must stay < 65504 (nm_field_overflow
-                                  reports a violation); 1: the first split-half kernels (A/B only) */
+                                  reports a violation); 1: the first split-half kernels (A/B only);
+                                  3: mode 2's weights and arithmetic on the pipelined 128-row kernels of
+                                  nm_mlp_h3.h where the configuration allows (A/B only, not faster) */
     const float* geo_weight[8];   /* device; layer 0: [W, in_geo], others [W,W] */
     const float* geo_bias[8];     /* device [W] */
     const float* density_weight;  /* device [1,W] */
