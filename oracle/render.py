@@ -141,6 +141,8 @@ class RenderConfig:
     bounded_near_far: bool = True
     calc_normal: bool = True
     white_bkgd: bool = False
+    near_bypass: float | None = None   # models/renderer.py:171-174: replace every ray's near / far
+    far_bypass: float | None = None
 
 
 def upsample_step(d, sdf, it: int, n_new: int, u=None):
@@ -173,6 +175,10 @@ def render_rays(field, rays_o, rays_d, cfg: RenderConfig = RenderConfig(), detai
         near, far, probe_ds = compute_bounded_near_far(field, rays_o, rays_d, near, far)
         if detailed:
             out["probe_ds"] = probe_ds
+    if cfg.near_bypass is not None:                                          # :171-172
+        near = (F32(cfg.near_bypass) * np.ones_like(near)).astype(F32)
+    if cfg.far_bypass is not None:                                           # :173-174
+        far = (F32(cfg.far_bypass) * np.ones_like(far)).astype(F32)
     out["near"], out["far"] = near, far
 
     t = torch_linspace01(cfg.N_samples)

@@ -292,6 +292,49 @@ def test_render_matches_reference_fixture(small, cuda_device, torch_mod, tag, pr
     model.mlp_precision = "f16x2"
 
 
+def test_render_edge_sizes_against_oracle(small, cuda_device, torch_mod):
+    """Edge cases of the render call: no ray, one ray, ray counts around the 64-ray workgroup / list-group size, the
+    largest sample count the kernels accept (N_samples + N_importance = 256; 257 is refused), near / far bypass.  Every
+    case against the CPU oracle on the same rays (RGB within 1e-4) and against a different chunking (bit-equal)."""
+    torch = torch_mod
+    from neumesh_amd._lib import NeuMeshHipError
+    from neumesh_amd.renderer import volume_render
+    from oracle import render as orender
+    mesh, state, model = small
+    orc = common.make_oracle(mesh, state)
+    rf = common.golden("render_v3000_dtu")
+    ro_all, rd_all = rf["rays_o"], rf["rays_d"]
+    with torch.no_grad():
+        rgb, depth, ex = volume_render(_t(ro_all[:0], cuda_device), _t(rd_all[:0], cuda_device), model, calc_normal=True, perturb=False, detailed_output=False)
+    assert tuple(rgb.shape) == (0, 3) and tuple(depth.shape) == (0,)
+    for n in (1, 63, 65):
+        ro, rd = ro_all[:n], rd_all[:n]
+        want = orender.render_rays(orc, ro, rd, orender.RenderConfig(calc_normal=True))
+        with torch.no_grad():
+            rgb, depth, ex = volume_render(_t(ro, cuda_device), _t(rd, cuda_device), model, calc_normal=True, perturb=False, detailed_output=False, rayschunk=4096)
+            rgb_b, depth_b, _ = volume_render(_t(ro, cuda_device), _t(rd, cuda_device), model, calc_normal=True, perturb=False, detailed_output=False, rayschunk=5)
+        assert torch.equal(rgb, rgb_b) and torch.equal(depth, depth_b)
+        np.testing.assert_allclose(rgb.cpu().numpy(), want["rgb"], atol=1e-4)
+        np.testing.assert_allclose(ex["normals_volume"].cpu().numpy(), want["normals_volume"], atol=1e-4)
+    ro, rd = ro_all[:9], rd_all[:9]
+    # the largest sample count: 128 + 128 (4 up-sampling iterations of 32)
+    want = orender.render_rays(orc, ro, rd, orender.RenderConfig(calc_normal=False, N_samples=128, N_importance=128))
+    with torch.no_grad():
+        rgb, depth, ex = volume_render(_t(ro, cuda_device), _t(rd, cuda_device), model, calc_normal=False, perturb=False, detailed_output=False,
+                                       N_samples=128, N_importance=128)
+    np.testing.assert_allclose(rgb.cpu().numpy(), want["rgb"], atol=1e-4)
+    with pytest.raises(NeuMeshHipError):
+        with torch.no_grad():
+            volume_render(_t(ro, cuda_device), _t(rd, cuda_device), model, calc_normal=False, perturb=False, detailed_output=False, N_samples=129, N_importance=128)
+    # near / far bypass (renderer.py:172-175)
+    want = orender.render_rays(orc, ro, rd, orender.RenderConfig(calc_normal=False, near_bypass=0.6, far_bypass=2.4))
+    with torch.no_grad():
+        rgb, depth, ex = volume_render(_t(ro, cuda_device), _t(rd, cuda_device), model, calc_normal=False, perturb=False, detailed_output=False,
+                                       near_bypass=0.6, far_bypass=2.4)
+    np.testing.assert_allclose(rgb.cpu().numpy(), want["rgb"], atol=1e-4)
+    np.testing.assert_allclose(depth.cpu().numpy(), want["depth_volume"], atol=1e-4)
+
+
 def test_wrapper_model_renders_through_staged_path(small, cuda_device, torch_mod):
     """A model that only EXPOSES the five field methods (like the editing tools' wrapper,
     editing/texture_neumesh/texture_neumesh.py:41-51) goes through the staged renderer (per-ray HIP
