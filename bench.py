@@ -121,6 +121,81 @@ def _psnr(a, b):
     return 200.0 if mse == 0 else -10.0 * np.log10(mse)
 
 
+def consumer_rows(mesh, model, dev, H, W):
+    """Timings of the rows SURVEY 8f marks "next" on the bench scene (reported under `extra`; each is pinned for parity by
+    tests/test_gpu_parity.py): one training step through Trainer.forward + backward + Adam (models/trainer.py:50-117,
+    train.py:176), the surface renderer (models/ray_casting.py:228-320), a frame through the texture-editing wrapper
+    (editing/texture_neumesh/texture_neumesh.py:53-122)."""
+    import torch
+    from neumesh_amd import ray_casting as rc, synthetic
+    from neumesh_amd.editing import TextureEditableNeuMesh
+    from neumesh_amd.renderer import volume_render
+    from neumesh_amd.trainer import Trainer
+    out = {}
+
+    def timed(fn, steps, warmup=1):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / steps
+
+    pose, K = synthetic.orbit_pose(0), synthetic.pinhole_intrinsics(H, W)
+    try:   # ---- training step: 512 random pixels of one view (the reference config's data.N_rays), eikonal + mask + regulariser on
+        lw = {"img": 1.0, "eikonal": 0.1, "mask": 0.1, "indicator_reg": 0.1, "distill_density": 0.0, "distill_color": 0.0}
+        trainer = Trainer(model, loss_weights=lw, teacher_model=None, device_ids=[dev.index or 0])
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+        model_input = {"intrinsics": torch.from_numpy(np.asarray(K, np.float32))[None], "c2w": torch.from_numpy(np.asarray(pose, np.float32))[None],
+                       "object_mask": torch.ones(1, H * W, dtype=torch.bool)}
+        gt = {"rgb": torch.full((1, H * W, 3), 0.5)}
+        kw = dict(N_nograd_samples=2048, N_upsample_iters=4, obj_bounding_radius=1.0, batched=True, perturb=True, white_bkgd=False,
+                  bounded_near_far=True, calc_normal=True, H=H, W=W, N_samples=64, N_importance=64, rayschunk=4096)
+        was_training = model.training
+        saved = {k: v.detach().clone() for k, v in model.state_dict().items()}   # the steps below move the weights: put them back afterwards
+        model.train()
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            ret = trainer.forward({"data": {"N_rays": 512}}, None, model_input, gt, kw, 0, device=dev)
+            ret["losses"]["total"].backward()
+            opt.step()
+        dt = timed(step, 5, 2)
+        model.load_state_dict(saved)
+        model.train(was_training)
+        for p_ in model.parameters():
+            p_.grad = None
+        out["train_step (512 rays x 128 samples of one view, img + eikonal + mask + indicator losses, forward + backward + Adam)"] = {
+            "ms_per_step": dt * 1e3, "value": 512 / dt, "unit": "rays/s", "steps": 5}
+    except Exception as ex:
+        out["train_step"] = {"error": str(ex)[-300:]}
+    o, d = frame_rays(0, H, W)
+    ro, rd = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    try:   # ---- surface renderer: first hit by 256 proposals + 8 secant steps, colour / normal at the hit
+        with torch.no_grad():
+            dt = timed(lambda: rc.surface_render(ro[None], rd[None], model, calc_normal=True, batched=True, rayschunk=1 << 17, ray_casting_algo="root_finding",
+                                                 ray_casting_cfgs=dict(near=0.5, far=3.5, logit_tau=0.0, fill_inf=False)), 2)
+        out["surface_render (root finding: 256 proposals + 8 secant steps per ray, colour + normal at the hit)"] = {
+            "ms_per_frame": dt * 1e3, "value": H * W / dt, "unit": "rays/s", "steps": 2}
+    except Exception as ex:
+        out["surface_render"] = {"error": str(ex)[-300:]}
+    try:   # ---- texture editing: a tenth of the vertices painted from a second colour table, rendered by the staged renderer
+        V = mesh.vertices.shape[0]
+        g = torch.Generator().manual_seed(5)
+        masks = (torch.rand(1, V, generator=g) < 0.1).to(dev)
+        feats = (0.1 * torch.randn(V, model.color_features.shape[1], generator=g)).to(dev)
+        edit = TextureEditableNeuMesh(model, [model], masks, feats)
+        with torch.no_grad():
+            dt = timed(lambda: volume_render(ro, rd, edit, calc_normal=False, perturb=False, detailed_output=False, rayschunk=1 << 17), 2)
+        out["texture_editing_render (staged renderer through TextureEditableNeuMesh.forward, 10 % of the vertices painted)"] = {
+            "ms_per_frame": dt * 1e3, "value": H * W / dt, "unit": "rays/s", "steps": 2}
+    except Exception as ex:
+        out["texture_editing_render"] = {"error": str(ex)[-300:]}
+    return out
+
+
 def parity_blocks(gpu_rgb_frame0, H, W, V, oracle_rgb, sel):
     """(a) vs the committed REFERENCE output of the very same rays (fixture, 1536 rays of frame 0);
     (b) vs the oracle sample rendered for the CPU baseline."""
@@ -451,6 +526,7 @@ def main():
             short("config3_shape (64 samples/ray, white background)", samples=64, white=True)
             short("config4_shape (1600x1200 rays/frame in chunks of one 800x800 frame, 64+64 samples)", hw=(1200, 1600))
             model.mlp_precision = args.mlp_precision
+            extra.update(consumer_rows(mesh, model, dev, args.H, args.W))
         if world == 1 and args.cpu_rays > 0:
             try:
                 r0 = (rays0[0].cpu().numpy(), rays0[1].cpu().numpy())
