@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 5
+#define NM_ABI_VERSION 6
 #define NM_MAX_K 32
 
 typedef struct nm_grid_s* nm_grid_t;    /* spatial index over the mesh vertices */
@@ -181,7 +181,20 @@ typedef struct nm_render_cfg {
                                     sums, i.e. never evaluated: rgb and normals move by less than (N-1) * weight_eps,
                                     depth and acc not at all (their weights come from the sample SDFs).  The one
                                     setting that is NOT bit-identical to evaluating everything. */
+    /* Texture editing (editing/texture_neumesh/texture_neumesh.py:53-122: TextureEditableNeuMesh.forward), optional.
+       n_edit reference models: where a mid-point's interpolation weight sits on vertices painted from reference i
+       (edit_mask[i][v] != 0), the colour is blended, in the order i = 0, 1, ..:
+           a = sum_k w_k [painted], colour = colour * (1 - share) + colour_i * share   with share = a / sum_k w_k,
+       colour_i = reference i's colour MLP on edit_color_features interpolated with the painted neighbours' renormalised
+       weights (same ds, view direction and nabla: no rigid transform between the models).  Geometry, depth, acc and
+       normals are the main model's. */
+    int32_t n_edit;              /* 0 = plain model; at most NM_MAX_EDIT */
+    int32_t edit_reserved;
+    nm_field_t edit_field[4];    /* reference models: their colour MLPs (same color_dim / embedders as the main model) */
+    const uint8_t* edit_mask[4]; /* device [V] */
+    const float* edit_color_features; /* device [V, color_dim]  (main_editing_colorfeats) */
 } nm_render_cfg;
+#define NM_MAX_EDIT 4
 
 /* nm_render_cfg.flags.  None of them changes a result bit (tests compare the variants); they select
  * the evaluation strategy, mostly for A/B measurements:

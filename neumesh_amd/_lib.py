@@ -11,7 +11,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_K = 32
 
 
@@ -43,7 +43,9 @@ class RenderCfg(C.Structure):
                 ("white_bkgd", C.c_int32), ("probe_grid", C.c_int32), ("probe_thresh", C.c_float),
                 ("near_bypass", C.c_float), ("far_bypass", C.c_float),
                 ("flags", C.c_uint32), ("chain_tiles", C.c_int32), ("fine_group_rays", C.c_int32),
-                ("mid_group_rays", C.c_int32), ("weight_eps", C.c_float)]
+                ("mid_group_rays", C.c_int32), ("weight_eps", C.c_float),
+                ("n_edit", C.c_int32), ("edit_reserved", C.c_int32), ("edit_field", C.c_void_p * 4),
+                ("edit_mask", C.c_void_p * 4), ("edit_color_features", C.c_void_p)]
 
 
 # nm_render_cfg.flags (include/neumesh_hip.h)

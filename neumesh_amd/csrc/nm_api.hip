@@ -22,6 +22,7 @@
 #include "nm_mlp_f16.h"
 #include "nm_mlp_h2.h"
 #include "nm_mlp_h3.h"
+#include "nm_edit.h"
 
 // ------------------------------------------------------------------------------ error state
 static thread_local std::string g_err;
@@ -751,6 +752,7 @@ struct NmWorkspace {
     unsigned short* order;        // depth-bucket lane assignment of one up-sampling pass
     NmScratch slots;  // per-ray slot records (coarse + up-sampling passes), reused by the final pass
     NmScratch pts;    // compact records of the mid-point pass
+    float *rgb_ref, *edit_w, *edit_share;  // texture editing: reference colours [R][N][3], renormalised painted weights [pos][8], (rest, paint) shares [pos][2]
     size_t bytes;
 };
 static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) {
@@ -796,8 +798,12 @@ static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) 
     }
     w.slots = nm_carve(p + o, R * N, false);
     o += w.slots.bytes;
-    w.pts = nm_carve(p + o, mid_slots > R * N ? mid_slots : R * N, false);
+    const long long pts_n = mid_slots > R * N ? mid_slots : R * N;
+    w.pts = nm_carve(p + o, pts_n, c->n_edit > 0);   // (texture editing needs the mid-points' neighbour lists)
     o += w.pts.bytes;
+    w.rgb_ref = (float*)take(c->n_edit > 0 ? (size_t)R * N * 12 : 0);
+    w.edit_w = (float*)take(c->n_edit > 0 ? (size_t)pts_n * 32 : 0);
+    w.edit_share = (float*)take(c->n_edit > 0 ? (size_t)pts_n * 8 : 0);
     w.bytes = o;
     return w;
 }
@@ -807,6 +813,9 @@ static int nm_check_cfg(const nm_render_cfg* c) {
     if (c->N_samples < 2 || c->N_importance < 0 || c->N_samples + c->N_importance > NM_MAX_SAMPLES) return nm_fail("nm_render: N_samples=%d N_importance=%d unsupported (sum <= %d)", c->N_samples, c->N_importance, NM_MAX_SAMPLES);
     if (c->N_importance > 0 && (c->N_upsample_iters < 1 || c->N_importance % c->N_upsample_iters)) return nm_fail("nm_render: N_importance %% N_upsample_iters != 0");
     if (c->bounded_near_far && (c->probe_grid < 2 || c->probe_grid > 4096)) return nm_fail("nm_render: probe_grid=%d", c->probe_grid);
+    if (c->n_edit < 0 || c->n_edit > NM_MAX_EDIT) return nm_fail("nm_render: n_edit=%d (0..%d)", c->n_edit, NM_MAX_EDIT);
+    for (int i = 0; i < c->n_edit; ++i)
+        if (!c->edit_field[i] || !c->edit_mask[i] || !c->edit_color_features) return nm_fail("nm_render: texture editing: NULL reference field / mask / colour table");
     return 0;
 }
 
@@ -1011,10 +1020,23 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     src.out_off = 0;
     {
         const NmGather ga_mid = {t->geometry_features, f->geo.gdim, ws.pts.fg, t->color_features, f->col.cdim, ws.pts.ft};
-        if (nm_launch_distance(g, src, (long long)R * (N - 1), t->indicator_vector, t->indicator_weight, ws.pts.ds, nullptr, nullptr, nullptr, ws.pts.grad, stream, nullptr, ga_mid, skip_zero)) return 1;
+        if (nm_launch_distance(g, src, (long long)R * (N - 1), t->indicator_vector, t->indicator_weight, ws.pts.ds, c->n_edit > 0 ? ws.pts.idx : nullptr, nullptr,
+                               c->n_edit > 0 ? ws.pts.w : nullptr, ws.pts.grad, stream, nullptr, ga_mid, skip_zero)) return 1;
     }
     if (nm_launch_geo(f, ws.pts.fg, ws.pts.ds, ws.pts.grad, mid_pts, true, nullptr, 1, 1, 0, ws.nab_mid, stream, NM_COMPACT, 0, smap, skip_zero)) return 1;
     if (nm_launch_col(f, ws.pts.ft, ws.pts.ds, ws.nab_mid, ws.dirn, N - 1, mid_pts, ws.rgb_mid, stream, smap, skip_zero)) return 1;
+    // Texture editing (texture_neumesh.py:79-121): per reference model, the painted share of every mid-point's interpolation
+    // weight, the reference colour from the edited colour table under the painted neighbours' renormalised weights, the blend.
+    for (int e = 0; e < c->n_edit; ++e) {
+        nm_field_t rf = c->edit_field[e];
+        if (rf->col.cdim != f->col.cdim || rf->col.in_dim != f->col.in_dim) return nm_fail("nm_render_rays: texture editing: reference model %d has another colour configuration", e);
+        hipLaunchKernelGGL(nm_edit_prepare_kernel, dim3(nm_blocks(mid_pts, 256)), dim3(256), 0, stream, mid_pts, smap, ws.pts.idx, ws.pts.w, c->edit_mask[e],
+                           c->edit_color_features, f->col.cdim, ws.edit_w, ws.edit_share, ws.pts.fg);
+        NM_LAUNCH_CHECK();
+        if (nm_launch_col(rf, ws.pts.fg, ws.pts.ds, ws.nab_mid, ws.dirn, N - 1, mid_pts, ws.rgb_ref, stream, smap, skip_zero)) return 1;
+        hipLaunchKernelGGL(nm_edit_blend_kernel, dim3(nm_blocks(mid_pts, 256)), dim3(256), 0, stream, mid_pts, smap, N - 1, ws.edit_share, ws.rgb_ref, ws.rgb_mid);
+        NM_LAUNCH_CHECK();
+    }
     // alpha + compositing (renderer.py:278, 302-333)
     hipLaunchKernelGGL(nm_rays_composite_kernel, rgrid, rblock, 0, stream, ws.sdf, ws.d, (long long)R, cap, N, t->s, ws.rgb_mid,
                        c->calc_normal ? ws.nab_pts : (const float*)nullptr, c->white_bkgd, rgb, depth, acc, c->calc_normal ? normals : (float*)nullptr,

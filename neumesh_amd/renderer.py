@@ -135,12 +135,44 @@ def _n_lanes() -> int:
         return 2
 
 
-def render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int, detailed: bool = False,
+def fusable_edit_model(model) -> bool:
+    """A TextureEditableNeuMesh whose texture blend nm_render_rays can do itself (nm_render_cfg.n_edit): plain NeuMesh main and
+    reference models with the main model's colour configuration, no rigid transform between them, at most 4 references."""
+    from .editing import TextureEditableNeuMesh
+    if not isinstance(model, TextureEditableNeuMesh) or not isinstance(model.main_model, NeuMesh):
+        return False
+    refs = list(model.ref_models)
+    m = model.main_model
+    return (model.rot_s_m is None and 1 <= len(refs) <= 4 and all(isinstance(r, NeuMesh) for r in refs) and
+            all(r.color_features.shape[1] == m.color_features.shape[1] and r.enable_nablas_input == m.enable_nablas_input for r in refs) and
+            model.main_editing_masks.shape[0] == len(refs))
+
+
+def render_rays_fused(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int, detailed: bool = False,
                       tables=None, progress=None):
-    """rays_o / rays_d: [R,3] device tensors.  Returns dict of [R,...] tensors."""
-    out = _render_rays_fused(model, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress)
-    if not model.check_fp16_range():   # first call on a new weight set only: out of fp16 range -> fp32 kernels, once more
-        out = _render_rays_fused(model, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress)
+    """rays_o / rays_d: [R,3] device tensors.  Returns dict of [R,...] tensors.  model: a NeuMesh, or a
+    TextureEditableNeuMesh that fusable_edit_model() accepts (its blend then runs inside nm_render_rays)."""
+    main, keep = model, []
+    if not isinstance(model, NeuMesh):
+        main = model.main_model
+        refs = list(model.ref_models)
+        masks = model.main_editing_masks.to(torch.uint8).contiguous()
+        feats = model.main_editing_colorfeats.detach().float().contiguous()
+        cfg.n_edit = len(refs)
+        for i, r in enumerate(refs):
+            cfg.edit_field[i] = getattr(r.field_handle(), "value", r.field_handle())
+            cfg.edit_mask[i] = masks[i].data_ptr()
+        cfg.edit_color_features = feats.data_ptr()
+        keep = [masks, feats, refs]
+    else:
+        cfg.n_edit = 0
+    models = [main] + (keep[2] if keep else [])
+    out = _render_rays_fused(main, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress)
+    if not all([m.check_fp16_range() for m in models]):   # first call on a new weight set only: out of fp16 range -> fp32 kernels, once more
+        for i, r in enumerate(keep[2] if keep else []):
+            cfg.edit_field[i] = getattr(r.field_handle(), "value", r.field_handle())
+        out = _render_rays_fused(main, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress)
+    del keep
     return out
 
 
@@ -420,7 +452,7 @@ def volume_render(rays_o, rays_d, model, obj_bounding_radius=1.0, batched=False,
     training = torch.is_grad_enabled() or perturb   # trainer.py:75-81: autograd through the field + compositing
     # plain NeuMesh field, inference, the rays' own directions: one C call per chunk.  Per-sample outputs and random
     # colour directions (training-side options, trainer.py:70-79,139-146) go through the staged form.
-    fused = isinstance(model, NeuMesh) and not training and not samples_output and not random_color_direction
+    fused = (isinstance(model, NeuMesh) or fusable_edit_model(model)) and not training and not samples_output and not random_color_direction
     cfg = make_render_cfg(obj_bounding_radius, N_samples, N_importance, N_upsample_iters, bounded_near_far, calc_normal,
                           white_bkgd, near_bypass, far_bypass)
     progress = None

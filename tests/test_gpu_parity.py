@@ -983,6 +983,45 @@ def test_texture_editable_wrapper_forward_and_render(small, cuda_device, torch_m
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_ref", [1, 2])
+def test_texture_editing_inside_the_fused_renderer(small, cuda_device, torch_mod, n_ref):
+    """nm_render_cfg.n_edit: a TextureEditableNeuMesh without a rigid transform is rendered by nm_render_rays itself (painted
+    shares, reference colour from the edited table, blend -- editing/texture_neumesh/texture_neumesh.py:79-121) and must
+    give the staged renderer's image, which evaluates the wrapper's forward() through the model methods: colours to 2e-6
+    (the share sums are the same eight terms in another order), depth / acc / normals bit for bit; one and two references."""
+    torch = torch_mod
+    from neumesh_amd.editing import TextureEditableNeuMesh
+    from neumesh_amd.renderer import fusable_edit_model, make_render_cfg, render_rays_staged, volume_render
+    mesh, state, model = small
+    V = mesh.num_vertices
+    g = torch.Generator().manual_seed(11)
+    refs, masks = [], []
+    for i in range(n_ref):
+        st = dict(state)
+        for k in list(st):
+            if k.startswith("views_linears") or k.startswith("rgb_linear"):
+                st[k] = st[k] + 0.05 * (i + 1) * np.random.default_rng(20 + i).standard_normal(st[k].shape).astype(np.float32)
+        refs.append(common.make_model(mesh, st, cuda_device))
+        masks.append(torch.rand(V, generator=g) < (0.3 if i == 0 else 0.15))
+    feats = (0.1 * torch.randn(V, model.color_features.shape[1], generator=g)).to(cuda_device)
+    wrap = TextureEditableNeuMesh(model, refs, torch.stack(masks).to(cuda_device), feats)
+    assert fusable_edit_model(wrap)
+    rf = common.golden("render_v3000_dtu")
+    ro, rd = _t(rf["rays_o"], cuda_device), _t(rf["rays_d"], cuda_device)
+    kw = dict(calc_normal=True, perturb=False, detailed_output=False)
+    with torch.no_grad():
+        img, depth, ex = volume_render(ro, rd, wrap, rayschunk=4096, **kw)
+        img_c, depth_c, _ = volume_render(ro, rd, wrap, rayschunk=17, **kw)
+        st_out = render_rays_staged(wrap, ro, rd, make_render_cfg(calc_normal=True), 4096, 1 << 20)
+        img0, depth0, _ = volume_render(ro, rd, model, rayschunk=4096, **kw)
+    assert torch.equal(img, img_c) and torch.equal(depth, depth_c)
+    assert torch.equal(depth, st_out["depth_volume"]) and torch.equal(ex["mask_volume"], st_out["mask_volume"]) and torch.equal(depth, depth0)
+    assert torch.equal(ex["normals_volume"], st_out["normals_volume"])
+    np.testing.assert_allclose(img.cpu().numpy(), st_out["rgb"].cpu().numpy(), atol=2e-6)
+    assert float((img - img0).abs().max()) > 1e-3 and bool(torch.isfinite(img).all())
+
+
+@pytest.mark.gpu
 def test_device_octree_build_is_bit_identical_to_host_build(cuda_device, torch_mod):
     """nm_grid_create builds the index ON THE DEVICE (nm_grid_build_dev.h: Morton codes, radix sort, per-level node
     kernels); the host build of nm_grid_build.h -- the one tests/hostcheck checks against brute force on the CPU -- is
