@@ -186,13 +186,15 @@ typedef struct nm_render_cfg {
        (edit_mask[i][v] != 0), the colour is blended, in the order i = 0, 1, ..:
            a = sum_k w_k [painted], colour = colour * (1 - share) + colour_i * share   with share = a / sum_k w_k,
        colour_i = reference i's colour MLP on edit_color_features interpolated with the painted neighbours' renormalised
-       weights (same ds, view direction and nabla: no rigid transform between the models).  Geometry, depth, acc and
+       weights (same ds; view direction and nabla rotated into the reference's frame when edit_use_rot[i]).  Geometry, depth, acc and
        normals are the main model's. */
     int32_t n_edit;              /* 0 = plain model; at most NM_MAX_EDIT */
     int32_t edit_reserved;
     nm_field_t edit_field[4];    /* reference models: their colour MLPs (same color_dim / embedders as the main model) */
     const uint8_t* edit_mask[4]; /* device [V] */
     const float* edit_color_features; /* device [V, color_dim]  (main_editing_colorfeats) */
+    int32_t edit_use_rot[4];     /* != 0: reference i lives in another frame (T_r_m_list): its colour call takes the view    */
+    float edit_rot[4][9];        /* direction and the nabla rotated by this row-major 3x3 matrix (transform_direction)      */
 } nm_render_cfg;
 #define NM_MAX_EDIT 4
 

@@ -752,6 +752,7 @@ struct NmWorkspace {
     unsigned short* order;        // depth-bucket lane assignment of one up-sampling pass
     NmScratch slots;  // per-ray slot records (coarse + up-sampling passes), reused by the final pass
     NmScratch pts;    // compact records of the mid-point pass
+    float *nab_rot, *dirn_rot;             // texture editing with a rotated reference frame: nablas [pos][3], directions [R][3]
     float *rgb_ref, *edit_w, *edit_share;  // texture editing: reference colours [R][N][3], renormalised painted weights [pos][8], (rest, paint) shares [pos][2]
     size_t bytes;
 };
@@ -804,6 +805,10 @@ static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) 
     w.rgb_ref = (float*)take(c->n_edit > 0 ? (size_t)R * N * 12 : 0);
     w.edit_w = (float*)take(c->n_edit > 0 ? (size_t)pts_n * 32 : 0);
     w.edit_share = (float*)take(c->n_edit > 0 ? (size_t)pts_n * 8 : 0);
+    bool any_rot = false;
+    for (int i = 0; i < c->n_edit; ++i) any_rot = any_rot || c->edit_use_rot[i] != 0;
+    w.nab_rot = (float*)take(any_rot ? (size_t)pts_n * 12 : 0);
+    w.dirn_rot = (float*)take(any_rot ? (size_t)R * 12 : 0);
     w.bytes = o;
     return w;
 }
@@ -1030,10 +1035,17 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     for (int e = 0; e < c->n_edit; ++e) {
         nm_field_t rf = c->edit_field[e];
         if (rf->col.cdim != f->col.cdim || rf->col.in_dim != f->col.in_dim) return nm_fail("nm_render_rays: texture editing: reference model %d has another colour configuration", e);
+        const bool rot = c->edit_use_rot[e] != 0;
+        NmRot3 rm;
+        for (int i = 0; i < 9; ++i) rm.m[i] = c->edit_rot[e][i];
         hipLaunchKernelGGL(nm_edit_prepare_kernel, dim3(nm_blocks(mid_pts, 256)), dim3(256), 0, stream, mid_pts, smap, ws.pts.idx, ws.pts.w, c->edit_mask[e],
-                           c->edit_color_features, f->col.cdim, ws.edit_w, ws.edit_share, ws.pts.fg);
+                           c->edit_color_features, f->col.cdim, ws.edit_w, ws.edit_share, ws.pts.fg, rm, rot ? ws.nab_mid : (const float*)nullptr, ws.nab_rot);
         NM_LAUNCH_CHECK();
-        if (nm_launch_col(rf, ws.pts.fg, ws.pts.ds, ws.nab_mid, ws.dirn, N - 1, mid_pts, ws.rgb_ref, stream, smap, skip_zero)) return 1;
+        if (rot) {
+            hipLaunchKernelGGL(nm_rotate_rows3_kernel, dim3(nm_blocks(R, 256)), dim3(256), 0, stream, (long long)R, rm, ws.dirn, ws.dirn_rot);
+            NM_LAUNCH_CHECK();
+        }
+        if (nm_launch_col(rf, ws.pts.fg, ws.pts.ds, rot ? ws.nab_rot : ws.nab_mid, rot ? ws.dirn_rot : ws.dirn, N - 1, mid_pts, ws.rgb_ref, stream, smap, skip_zero)) return 1;
         hipLaunchKernelGGL(nm_edit_blend_kernel, dim3(nm_blocks(mid_pts, 256)), dim3(256), 0, stream, mid_pts, smap, N - 1, ws.edit_share, ws.rgb_ref, ws.rgb_mid);
         NM_LAUNCH_CHECK();
     }

@@ -11,9 +11,23 @@
 // on_paint / total; reference weights w_k painted_k / (sum + 1e-8); the edited colour table interpolated with them
 // (nm_gather_interp: the arithmetic of the K-NN kernel's own gathers).  Points outside the region get a zero row (their
 // reference colour is evaluated with the rest of the list and not used).
+struct NmRot3 {
+    float m[9];  // row-major
+};
+// transform_direction (utils/geo_util.py:78-89): rot @ v
+__device__ __forceinline__ void nm_rotate3(const NmRot3& r, float x, float y, float z, float* out) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out[i] = __fadd_rn(__fadd_rn(__fmul_rn(r.m[3 * i], x), __fmul_rn(r.m[3 * i + 1], y)), __fmul_rn(r.m[3 * i + 2], z));
+}
+__global__ __launch_bounds__(256) void nm_rotate_rows3_kernel(long long n, NmRot3 r, const float* __restrict__ in, float* __restrict__ out) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) nm_rotate3(r, in[q * 3], in[q * 3 + 1], in[q * 3 + 2], out + q * 3);
+}
+// (nab_in != nullptr: the reference model lives in a rotated frame -- nab_out[q] = rot @ nab_in[q] for its colour call)
 __global__ __launch_bounds__(256) void nm_edit_prepare_kernel(long long P, NmSlotMap smap, const int* __restrict__ idx32, const float* __restrict__ w,
                                                               const unsigned char* __restrict__ mask, const float* __restrict__ table, int cdim,
-                                                              float* __restrict__ ref_w, float* __restrict__ share, float* __restrict__ ft_ref) {
+                                                              float* __restrict__ ref_w, float* __restrict__ share, float* __restrict__ ft_ref,
+                                                              NmRot3 rot, const float* __restrict__ nab_in, float* __restrict__ nab_out) {
     const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = q < P && nm_slot_valid(smap, q);
     int bi[8];
@@ -37,6 +51,7 @@ __global__ __launch_bounds__(256) void nm_edit_prepare_kernel(long long P, NmSlo
         share[q * 2 + 1] = region ? __fdiv_rn(on_paint, total) : 0.f;
         *reinterpret_cast<float4*>(ref_w + q * 8) = make_float4(rw[0], rw[1], rw[2], rw[3]);
         *reinterpret_cast<float4*>(ref_w + q * 8 + 4) = make_float4(rw[4], rw[5], rw[6], rw[7]);
+        if (nab_in) nm_rotate3(rot, nab_in[q * 3], nab_in[q * 3 + 1], nab_in[q * 3 + 2], nab_out + q * 3);
         if (!region)
             for (int c = 0; c < cdim; c += 4) *reinterpret_cast<float4*>(ft_ref + q * cdim + c) = make_float4(0.f, 0.f, 0.f, 0.f);
     }

@@ -137,13 +137,13 @@ def _n_lanes() -> int:
 
 def fusable_edit_model(model) -> bool:
     """A TextureEditableNeuMesh whose texture blend nm_render_rays can do itself (nm_render_cfg.n_edit): plain NeuMesh main and
-    reference models with the main model's colour configuration, no rigid transform between them, at most 4 references."""
+    reference models with the main model's colour configuration, at most 4 references (their rotations, if any, go along)."""
     from .editing import TextureEditableNeuMesh
     if not isinstance(model, TextureEditableNeuMesh) or not isinstance(model.main_model, NeuMesh):
         return False
     refs = list(model.ref_models)
     m = model.main_model
-    return (model.rot_s_m is None and 1 <= len(refs) <= 4 and all(isinstance(r, NeuMesh) for r in refs) and
+    return (1 <= len(refs) <= 4 and all(isinstance(r, NeuMesh) for r in refs) and (model.rot_s_m is None or model.rot_s_m.shape[0] == len(refs)) and
             all(r.color_features.shape[1] == m.color_features.shape[1] and r.enable_nablas_input == m.enable_nablas_input for r in refs) and
             model.main_editing_masks.shape[0] == len(refs))
 
@@ -163,6 +163,12 @@ def render_rays_fused(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int
             cfg.edit_field[i] = getattr(r.field_handle(), "value", r.field_handle())
             cfg.edit_mask[i] = masks[i].data_ptr()
         cfg.edit_color_features = feats.data_ptr()
+        rots = None if model.rot_s_m is None else model.rot_s_m.detach().float().cpu().numpy()
+        for i in range(len(refs)):
+            cfg.edit_use_rot[i] = 0 if rots is None else 1
+            if rots is not None:
+                for j in range(9):
+                    cfg.edit_rot[i][j] = float(rots[i].reshape(-1)[j])
         keep = [masks, feats, refs]
     else:
         cfg.n_edit = 0

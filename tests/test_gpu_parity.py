@@ -983,12 +983,13 @@ def test_texture_editable_wrapper_forward_and_render(small, cuda_device, torch_m
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_ref", [1, 2])
-def test_texture_editing_inside_the_fused_renderer(small, cuda_device, torch_mod, n_ref):
+@pytest.mark.parametrize("n_ref,rotated", [(1, False), (2, False), (2, True)])
+def test_texture_editing_inside_the_fused_renderer(small, cuda_device, torch_mod, n_ref, rotated):
     """nm_render_cfg.n_edit: a TextureEditableNeuMesh without a rigid transform is rendered by nm_render_rays itself (painted
     shares, reference colour from the edited table, blend -- editing/texture_neumesh/texture_neumesh.py:79-121) and must
     give the staged renderer's image, which evaluates the wrapper's forward() through the model methods: colours to 2e-6
-    (the share sums are the same eight terms in another order), depth / acc / normals bit for bit; one and two references."""
+    (the share sums are the same eight terms in another order), depth / acc / normals bit for bit; one and two references,
+    with and without a rigid transform between the models (T_r_m_list: view direction and nabla rotated for the reference)."""
     torch = torch_mod
     from neumesh_amd.editing import TextureEditableNeuMesh
     from neumesh_amd.renderer import fusable_edit_model, make_render_cfg, render_rays_staged, volume_render
@@ -1004,7 +1005,16 @@ def test_texture_editing_inside_the_fused_renderer(small, cuda_device, torch_mod
         refs.append(common.make_model(mesh, st, cuda_device))
         masks.append(torch.rand(V, generator=g) < (0.3 if i == 0 else 0.15))
     feats = (0.1 * torch.randn(V, model.color_features.shape[1], generator=g)).to(cuda_device)
-    wrap = TextureEditableNeuMesh(model, refs, torch.stack(masks).to(cuda_device), feats)
+    T_list = None
+    if rotated:
+        T_list = []
+        for i in range(n_ref):
+            q, _ = np.linalg.qr(np.random.default_rng(40 + i).standard_normal((3, 3)))
+            T = np.eye(4, dtype=np.float32)
+            T[:3, :3] = q * np.sign(np.linalg.det(q))
+            T[:3, 3] = 0.1 * (i + 1)
+            T_list.append(torch.from_numpy(T).to(cuda_device))
+    wrap = TextureEditableNeuMesh(model, refs, torch.stack(masks).to(cuda_device), feats, T_list)
     assert fusable_edit_model(wrap)
     rf = common.golden("render_v3000_dtu")
     ro, rd = _t(rf["rays_o"], cuda_device), _t(rf["rays_d"], cuda_device)
