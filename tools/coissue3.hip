@@ -1,6 +1,6 @@
 // tools/coissue3.hip -- probe (GPU box): does vector-ALU work issued BETWEEN the MFMAs of one wave hide behind them?
 // The timed loop is ONE inline-assembly block on fixed physical registers (the compiler re-packs plain C++ fmas into
-// v_pk_fma_f32 and regroups them: tools/coissue.hip measured that, not the hardware).
+// v_pk_fma_f32 and regroups them: an earlier C++ probe of this question measured that, not the hardware).
 // Per loop trip: 8 x [ v_mfma_f32_32x32x16_f16 (8 independent accumulators v[0:127]) + N fillers on v[160:167] ].
 //   waves per SIMD: 1 (256-thread block, 1 block per CU) or 2 (512-thread block: both waves run the same mix)
 // hipcc --offload-arch=gfx950 -O3 tools/coissue3.hip -o tools/_build/coissue3
