@@ -299,15 +299,64 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
     Rall = rays_o.shape[0]
     Ns, Ni, iters = cfg.N_samples, cfg.N_importance, cfg.N_upsample_iters
     N = Ns + Ni
+    # Processing order: rays sorted by the Morton code of their point of closest approach to the scene centre (what
+    # nm_render_rays does on the device for the fused path), so that 16 consecutive rays are neighbours in space even when
+    # the caller hands over random pixels (training: trainer.py draws N_rays random pixels per step); per-ray outputs go
+    # back to the caller's order at the end.  (trace: diagnostics follow the caller's rays one by one -- no reordering.)
+    ray_inv = None
+    if Rall >= 32 and trace is None and not os.environ.get("NEUMESH_NO_RAY_SORT"):
+        with torch.no_grad():
+            dn = rays_d / torch.linalg.norm(rays_d, dim=-1, keepdim=True).clamp_min(1e-12)
+            pc = rays_o - (rays_o * dn).sum(-1, keepdim=True) * dn
+            qv = ((pc / max(float(cfg.obj_bounding_radius), 1e-6) * 0.5 + 0.5).clamp(0.0, 1.0) * 1023.0).to(torch.int64)
+            for sh, msk in ((16, 0x30000FF), (8, 0x300F00F), (4, 0x30C30C3), (2, 0x9249249)):   # spread 10 bits to every third position
+                qv = (qv | (qv << sh)) & msk
+            code = qv[:, 0] | (qv[:, 1] << 1) | (qv[:, 2] << 2)
+            ray_perm = torch.argsort(code, stable=True)
+            ray_inv = torch.empty_like(ray_perm)
+            ray_inv[ray_perm] = torch.arange(Rall, device=dev)
+        rays_o, rays_d = rays_o[ray_perm].contiguous(), rays_d[ray_perm].contiguous()
+
+    tile_perms = {}
+
+    def tile_perm(R, P):
+        """Order in which the points of an [R,P] block are handed to the model's point-wise methods: tiles of 16 adjacent
+        rays x 4 consecutive samples (64 consecutive points = one compact packet for the wave-cooperative K-NN search --
+        in ray-major order a wave would get 64 samples strung along ONE ray and fall back to lane-private traversals),
+        then whatever does not fill a tile.  Any order gives the same per-point results."""
+        key = (R, P)
+        if os.environ.get("NEUMESH_NO_TILE_ORDER"):
+            return None
+        if key not in tile_perms:
+            idx = torch.arange(R * P, device=dev).view(R, P)
+            R16, P4 = R // 16 * 16, P // 4 * 4
+            parts = []
+            if R16 and P4:
+                parts.append(idx[:R16, :P4].reshape(R16 // 16, 16, P4 // 4, 4).permute(0, 2, 1, 3).reshape(-1))
+                parts.append(idx[:R16, P4:].reshape(-1))
+                parts.append(idx[R16:, :].reshape(-1))
+                perm = torch.cat(parts)
+                inv = torch.empty_like(perm)
+                inv[perm] = torch.arange(R * P, device=dev)
+                tile_perms[key] = (perm, inv)
+            else:
+                tile_perms[key] = None
+        return tile_perms[key]
 
     def query(fn, pts, *extra):  # pts [R,P,3] -> tuple of [R,P,...]
         flat = pts.reshape(-1, 3)
         ex = [e.reshape(-1, e.shape[-1]) for e in extra]
+        tp = tile_perm(pts.shape[0], pts.shape[1])
+        if tp is not None:
+            flat = flat[tp[0]]
+            ex = [e[tp[0]] for e in ex]
         outs = []
         for i in range(0, flat.shape[0], max(1, int(netchunk))):
             o = fn(flat[i:i + netchunk], *[e[i:i + netchunk] for e in ex])
             outs.append(o if isinstance(o, tuple) else (o,))
         cols = [torch.cat([o[k] for o in outs], 0) for k in range(len(outs[0]))]
+        if tp is not None:
+            cols = [c[tp[1]] for c in cols]
         return [c.reshape(pts.shape[0], pts.shape[1], *c.shape[1:]) for c in cols]
 
     chunks = []
@@ -393,7 +442,10 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
                 if samples_output:
                     ret.update(xyz=pm, dirs=dirn[:, None, :].expand(R, N - 1, 3), density=sdf_mid, colors=radiance)
             chunks.append(ret)
-    return OrderedDict((k, torch.cat([c[k] for c in chunks], 0)) for k in chunks[0])
+    out = OrderedDict((k, torch.cat([c[k] for c in chunks], 0)) for k in chunks[0])
+    if ray_inv is not None:
+        out = OrderedDict((k, v[ray_inv]) for k, v in out.items())
+    return out
 
 
 def _mid_directions(dirn, pts_mid, random_color_direction: bool):
