@@ -246,12 +246,17 @@ int nm_grid_get_info(nm_grid_t g, nm_grid_info* out) {
     return 0;
 }
 
-static NmPointSrc nm_src_xyz(const float* xyz) {
+// Q: number of points of the call (0 = unknown: 64 queries per wave).  Below ~2^18 points the waves get fewer queries each
+// (NmPointSrc.lanes): the launch is bound by one wave's serial traversal, not by throughput.
+static NmPointSrc nm_src_xyz(const float* xyz, long long Q = 0) {
     NmPointSrc s;
     memset(&s, 0, sizeof(s));
     s.mode = 0;
     s.P = 1;
     s.xyz = xyz;
+    s.lanes = 64;
+    if (Q > 0)
+        while (s.lanes > 8 && Q / s.lanes < 4096) s.lanes >>= 1;   // aim at >= 4096 waves (4 per SIMD of the chip)
     return s;
 }
 
@@ -260,7 +265,7 @@ int nm_knn(nm_grid_t g, const float* q, int64_t Q, int K, int64_t* idx, float* d
     if (K < 1 || K > NM_MAX_K) return nm_fail("nm_knn: K=%d out of [1,%d]", K, NM_MAX_K);
     if (Q <= 0) return Q == 0 ? 0 : nm_fail("nm_knn: Q<0");
     if (!g || !idx || !d2 || !q) return nm_fail("nm_knn: NULL argument");
-    const NmPointSrc src = nm_src_xyz(q);
+    const NmPointSrc src = nm_src_xyz(q, Q);
     const dim3 grid(nm_query_blocks(src, Q)), block(256);
     long long* idx_ll = reinterpret_cast<long long*>(idx);
     if (K <= 8) hipLaunchKernelGGL(nm_knn_kernel<8>, grid, block, 0, stream, g->view, src, (long long)Q, K, idx_ll, d2);
@@ -302,7 +307,7 @@ int nm_compute_distance(nm_grid_t g, const float* q, int64_t Q, const float* ind
     if (!indicator) return nm_fail("nm_compute_distance: indicator is NULL");
     if (g->view.V < 8) return nm_fail("nm_compute_distance: mesh has %d < 8 vertices", g->view.V);
     if (Q < 0) return nm_fail("nm_compute_distance: Q<0");
-    return nm_launch_distance(g, nm_src_xyz(q), Q, indicator, w1, ds, nullptr, reinterpret_cast<long long*>(idx), w, dds_dx, stream);
+    return nm_launch_distance(g, nm_src_xyz(q, Q), Q, indicator, w1, ds, nullptr, reinterpret_cast<long long*>(idx), w, dds_dx, stream);
 }
 
 int nm_distance_interpolate(nm_grid_t g, const float* q, int64_t Q, const float* indicator, float w1, const float* table,
@@ -314,7 +319,7 @@ int nm_distance_interpolate(nm_grid_t g, const float* q, int64_t Q, const float*
     if (dim < 4 || dim % 4) return nm_fail("nm_distance_interpolate: dim=%d must be a positive multiple of 4", dim);
     if (g->view.V < 8) return nm_fail("nm_distance_interpolate: mesh has %d < 8 vertices", g->view.V);
     const NmGather ga = {table, dim, feat, nullptr, 0, nullptr};
-    return nm_launch_distance(g, nm_src_xyz(q), Q, indicator, w1, ds, nullptr, reinterpret_cast<long long*>(idx), w, nullptr, stream, nullptr, ga);
+    return nm_launch_distance(g, nm_src_xyz(q, Q), Q, indicator, w1, ds, nullptr, reinterpret_cast<long long*>(idx), w, nullptr, stream, nullptr, ga);
 }
 
 // =============================================================================== field
@@ -650,7 +655,7 @@ int nm_field_density(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const 
     if (P == 0) return 0;
     const NmScratch s = nm_carve(scratch, P);
     const NmGather ga = {t->geometry_features, f->geo.gdim, s.fg, nullptr, 0, nullptr};
-    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr,
+    if (nm_launch_distance(g, nm_src_xyz(xyz, P), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr,
                            nabla ? s.grad : nullptr, stream, nullptr, ga)) return 1;
     return nm_launch_geo(f, s.fg, s.ds, s.grad, P, nabla != nullptr, sdf, 1, 1, 0, nabla, stream);
 }
@@ -664,7 +669,7 @@ int nm_field_forward(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const 
     if (P == 0) return 0;
     const NmScratch s = nm_carve(scratch, P);
     const NmGather ga = {t->geometry_features, f->geo.gdim, s.fg, t->color_features, f->col.cdim, s.ft};
-    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr,
+    if (nm_launch_distance(g, nm_src_xyz(xyz, P), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr,
                            reinterpret_cast<long long*>(idx), w, s.grad, stream, nullptr, ga)) return 1;
     float* nab = nabla ? nabla : s.nabla;
     if (nm_launch_geo(f, s.fg, s.ds, s.grad, P, true, sdf, 1, 1, 0, nab, stream)) return 1;
@@ -1244,7 +1249,7 @@ int nm_time_kernel(nm_field_t f, nm_grid_t g, const nm_field_tables* t, int whic
     const NmGather ga = {t->geometry_features, f->geo.gdim, s.fg, t->color_features, f->col.cdim, s.ft};
     // inputs of the MLP kernels come from one K-NN pass
 #ifdef NM_EXP_GATHER
-    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx, nullptr, s.w, s.grad, stream, nullptr, ga)) return 1;
+    if (nm_launch_distance(g, nm_src_xyz(xyz, P), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx, nullptr, s.w, s.grad, stream, nullptr, ga)) return 1;
     {
         const int* pi = s.idx; const float* pw = s.w; const float* pt = t->geometry_features;
         NM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_nm_exp_idx), &pi, sizeof(pi), 0, hipMemcpyHostToDevice, stream));
@@ -1253,7 +1258,7 @@ int nm_time_kernel(nm_field_t f, nm_grid_t g, const nm_field_tables* t, int whic
         NM_HIP(hipStreamSynchronize(stream));
     }
 #else
-    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr, s.grad, stream, nullptr, ga)) return 1;
+    if (nm_launch_distance(g, nm_src_xyz(xyz, P), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr, s.grad, stream, nullptr, ga)) return 1;
 #endif
     if (which == 3 && nm_launch_geo(f, s.fg, s.ds, s.grad, P, true, nullptr, 1, 1, 0, s.nabla, stream)) return 1;
     hipEvent_t e0, e1;
@@ -1265,7 +1270,7 @@ int nm_time_kernel(nm_field_t f, nm_grid_t g, const nm_field_tables* t, int whic
     for (int i = -1; i < iters && !rc; ++i) {  // i = -1: untimed warm-up
         if (i == 0) hipEventRecord(e0, stream);
         switch (which) {
-            case 0: rc = nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr, s.grad, stream, nullptr, ga); break;
+            case 0: rc = nm_launch_distance(g, nm_src_xyz(xyz, P), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr, s.grad, stream, nullptr, ga); break;
             case 1: rc = nm_launch_geo(f, s.fg, s.ds, s.grad, P, false, sink, 1, 1, 0, nullptr, stream); break;
             case 2: rc = nm_launch_geo(f, s.fg, s.ds, s.grad, P, true, nullptr, 1, 1, 0, sink, stream); break;
             case 3: rc = nm_launch_col(f, s.ft, s.ds, s.nabla, view_dirs, 1, P, s.grad, stream); break;
@@ -1294,7 +1299,7 @@ int nm_selfcheck_field(nm_field_t f, nm_grid_t g, const nm_field_tables* t, cons
     if (!xyz || !view_dirs || !sdf || !nabla || !rgb || !scratch || !valu_tmp || P < 1) return nm_fail("nm_selfcheck_field: bad arguments");
     const NmScratch s = nm_carve(scratch, P);
     const NmGather ga = {t->geometry_features, f->geo.gdim, s.fg, t->color_features, f->col.cdim, s.ft};
-    if (nm_launch_distance(g, nm_src_xyz(xyz), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr, s.grad, stream, nullptr, ga)) return 1;
+    if (nm_launch_distance(g, nm_src_xyz(xyz, P), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr, s.grad, stream, nullptr, ga)) return 1;
     hipLaunchKernelGGL((nm_geo_mlp_kernel<true, true>), dim3(nm_blocks(P, 32)), dim3(256), 0, stream, f->geo, s.fg, s.ds, s.grad,
                        NM_COMPACT, (long long)P, sdf, 1, 1, 0, nabla, valu_tmp, 0, NM_NO_SLOTS);
     NM_LAUNCH_CHECK();

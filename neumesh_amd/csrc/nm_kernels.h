@@ -37,6 +37,10 @@ struct NmPointSrc {
     // mode 2 only: a wave walks `chain` consecutive 4-sample tiles of its 16 rays (0/1 = one tile) and
     // warm-starts every tile after the first from the tile before it (see nm_distance_kernel)
     int chain;
+    // mode 0 only: queries per wave (64, 32, 16 or 8; 0 = 64).  Small point-wise calls (a training step's few 10^4 points)
+    // are bound by ONE wave's serial traversal, which for scattered queries grows with the number of lanes that walk their
+    // own path: fewer queries per wave = more, shorter waves on a chip that has room for them.
+    int lanes;
 };
 
 // (r, p) = (ray, sample) of query q = r*P + p, as produced by nm_lane_query (mode 0: r = q, p = 0)
@@ -224,9 +228,10 @@ __device__ __forceinline__ bool nm_lane_query(const NmPointSrc& s, long long Q, 
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (s.mode == 0) {
-        q = r = wave * 64 + lane;
+        const int L = s.lanes > 0 ? s.lanes : 64;
+        q = r = wave * L + lane;
         p = 0;
-        return q < Q;
+        return lane < L && q < Q;
     }
     const long long R = Q / s.P;  // uniform
     if (s.order) {
@@ -250,7 +255,7 @@ __device__ __forceinline__ bool nm_lane_query(const NmPointSrc& s, long long Q, 
 }
 static inline unsigned nm_query_blocks(const NmPointSrc& s, long long Q) {
     long long waves;
-    if (s.mode == 0) waves = (Q + 63) / 64;
+    if (s.mode == 0) waves = (Q + (s.lanes > 0 ? s.lanes : 64) - 1) / (s.lanes > 0 ? s.lanes : 64);
     else if (s.order) waves = ((Q / s.P + s.order_rays - 1) / s.order_rays) * (((long long)s.order_rays * s.P + 63) / 64);
     else {
         const int chain = (s.mode == 2 && s.chain > 1) ? s.chain : 1;
