@@ -148,9 +148,10 @@ def consumer_rows(mesh, model, dev, H, W):
         lw = {"img": 1.0, "eikonal": 0.1, "mask": 0.1, "indicator_reg": 0.1, "distill_density": 0.0, "distill_color": 0.0}
         trainer = Trainer(model, loss_weights=lw, teacher_model=None, device_ids=[dev.index or 0])
         opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
-        model_input = {"intrinsics": torch.from_numpy(np.asarray(K, np.float32))[None], "c2w": torch.from_numpy(np.asarray(pose, np.float32))[None],
-                       "object_mask": torch.ones(1, H * W, dtype=torch.bool)}
-        gt = {"rgb": torch.full((1, H * W, 3), 0.5)}
+        # (the view's tensors resident on the device, like every other timed input here; train.py's data loader hands over host tensors)
+        model_input = {"intrinsics": torch.from_numpy(np.asarray(K, np.float32))[None].to(dev), "c2w": torch.from_numpy(np.asarray(pose, np.float32))[None].to(dev),
+                       "object_mask": torch.ones(1, H * W, dtype=torch.bool, device=dev)}
+        gt = {"rgb": torch.full((1, H * W, 3), 0.5, device=dev)}
         kw = dict(N_nograd_samples=2048, N_upsample_iters=4, obj_bounding_radius=1.0, batched=True, perturb=True, white_bkgd=False,
                   bounded_near_far=True, calc_normal=True, H=H, W=W, N_samples=64, N_importance=64, rayschunk=4096)
         was_training = model.training

@@ -276,9 +276,24 @@ class NeuMesh(nn.Module):
         iv = self.indicator_vector.detach().float().contiguous()
         t = _lib.FieldTables()
         t.geometry_features, t.color_features, t.indicator_vector = gf.data_ptr(), cf.data_ptr(), iv.data_ptr()
-        t.indicator_weight = float(self._w1())
-        t.s = float(self.forward_s())
+        t.indicator_weight, t.s = self._host_scalars()
         return t, (gf, cf, iv)
+
+    def _host_scalars(self):
+        """(indicator weight, s) as Python floats.  Reading a device scalar synchronises the stream, and every fused field
+        call needs the pair: cached on the parameters' version counters (an optimizer step or load_state_dict bumps them;
+        invalidate_field() covers edits through .data), so a training step pays for it once instead of once per call."""
+        ps = [self.ln_s] + ([self.indicator_weight_raw] if self.learn_indicator_weight else [])
+        key = tuple((p.data_ptr(), p._version) for p in ps) + (self._field_epoch,)
+        if getattr(self, "_scalars_key", None) != key:
+            with torch.no_grad():
+                if self.learn_indicator_weight:
+                    both = torch.stack([self.forward_indicator_weight().reshape(()), self.forward_s().reshape(())]).tolist()   # one transfer
+                    self._scalars = (float(both[0]), float(both[1]))
+                else:
+                    self._scalars = (0.1, float(self.forward_s()))
+            self._scalars_key = key
+        return self._scalars
 
     def __del__(self):
         try:

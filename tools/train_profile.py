@@ -48,3 +48,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=18, max_name_column_width=60))
 print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=12, max_name_column_width=60))
+print("host-synchronising operators per 3 steps:")
+for e in prof.key_averages():
+    if any(k in e.key for k in ("aten::item", "aten::nonzero", "_local_scalar_dense", "aten::_to_copy", "hipMemcpy", "hipStreamSynchronize", "aten::index", "aten::masked_select")):
+        print(f"  {e.key[:50]:50s} calls {e.count:5d}  cpu {e.cpu_time_total / 1e3:8.2f} ms")
