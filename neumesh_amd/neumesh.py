@@ -304,9 +304,44 @@ class NeuMesh(nn.Module):
             pass
 
     # ------------------------------------------------------------------ fused (no-grad) paths
+    _tile_cache = {}
+
+    @classmethod
+    def _tile_order(cls, shape, device):
+        """Points that arrive as [..., rays, samples, 3] (the reference renderer's and ray caster's layout) are handed to the
+        kernels as tiles of 16 adjacent rays x 4 consecutive samples: 64 consecutive points are then a compact packet for the
+        wave-cooperative K-NN search, where ray-major order strings a wave's 64 queries along one ray.  Returns (perm, inv)
+        index tensors over the flattened points, or None (fewer than 16 rays / 4 samples, flat point lists).  Every point's
+        result is independent of the order, so this only changes speed (neumesh_amd.renderer does the same for its stages)."""
+        if len(shape) < 3 or os.environ.get("NEUMESH_NO_TILE_ORDER"):
+            return None
+        P = int(shape[-2])
+        R = 1
+        for d in shape[:-2]:
+            R *= int(d)
+        if R < 16 or P < 4:
+            return None
+        key = (R, P, str(device))
+        hit = cls._tile_cache.get(key)
+        if hit is not None:
+            return hit
+        idx = torch.arange(R * P, device=device).view(R, P)
+        R16, P4 = R // 16 * 16, P // 4 * 4
+        perm = torch.cat([idx[:R16, :P4].reshape(R16 // 16, 16, P4 // 4, 4).permute(0, 2, 1, 3).reshape(-1), idx[:R16, P4:].reshape(-1), idx[R16:, :].reshape(-1)])
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(R * P, device=device)
+        if R * P <= (1 << 22):   # (index tensors of big calls are rebuilt each time: 16 bytes per point are not worth keeping)
+            if len(cls._tile_cache) > 16:
+                cls._tile_cache.clear()
+            cls._tile_cache[key] = (perm, inv)
+        return perm, inv
+
     def _fused_density(self, xyz, want_nabla: bool):
         lib = _lib.load()
         q = xyz.detach().float().reshape(-1, 3).contiguous()
+        tile = self._tile_order(xyz.shape, q.device)
+        if tile is not None:
+            q = q[tile[0]]
         P = q.shape[0]
         sdf = torch.empty((P,), dtype=torch.float32, device=q.device)
         nab = torch.empty((P, 3), dtype=torch.float32, device=q.device) if want_nabla else None
@@ -320,12 +355,17 @@ class NeuMesh(nn.Module):
                 if self.check_fp16_range():
                     break
         del keep
+        if tile is not None:
+            sdf, nab = sdf[tile[1]], (None if nab is None else nab[tile[1]])
         return sdf.reshape(*xyz.shape[:-1], 1), (None if nab is None else nab.reshape(xyz.shape))
 
     def _fused_forward(self, xyz, view_dirs, want_ds: bool):
         lib = _lib.load()
         q = xyz.detach().float().reshape(-1, 3).contiguous()
         v = view_dirs.detach().float().expand_as(xyz).reshape(-1, 3).contiguous()
+        tile = self._tile_order(xyz.shape, q.device)
+        if tile is not None:
+            q, v = q[tile[0]], v[tile[0]]
         P, dev = q.shape[0], q.device
         sdf = torch.empty((P,), dtype=torch.float32, device=dev)
         rgb = torch.empty((P, 3), dtype=torch.float32, device=dev)
@@ -343,6 +383,10 @@ class NeuMesh(nn.Module):
                 if self.check_fp16_range():
                     break
         del keep
+        if tile is not None:
+            sdf, rgb, nab = sdf[tile[1]], rgb[tile[1]], nab[tile[1]]
+            if want_ds:
+                ds, idx, w = ds[tile[1]], idx[tile[1]], w[tile[1]]
         lead = xyz.shape[:-1]
         out = (sdf.reshape(*lead, 1), rgb.reshape(*lead, 3), nab.reshape(*lead, 3))
         if want_ds:
