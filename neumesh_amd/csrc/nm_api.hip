@@ -24,6 +24,10 @@
 #include "nm_mlp_h3.h"
 #include "nm_edit.h"
 
+#ifndef NM_PROBE_STEP
+#define NM_PROBE_STEP 8  // probes per ray and step of nm_probe_bounds_kernel: 8 = 8 rays per wave (measured: K-NN per frame 99.9 ms with 4, 97.2 with 8, 101.7 with 16)
+#endif
+
 // ------------------------------------------------------------------------------ error state
 static thread_local std::string g_err;
 static int nm_fail(const char* fmt, ...) {
@@ -873,9 +877,14 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     if (c->bounded_near_far) {  // renderer.py:66-102
         if (!(c->flags & NM_RENDER_FULL_PROBES)) {  // first / last hit only (nm_probe_bounds_kernel)
             NmProfScope prof(NM_K_DISTANCE, 0, stream, NM_CNT_PROBE);  // units = probes actually searched (device counter)
-            hipLaunchKernelGGL(nm_probe_bounds_kernel, dim3(nm_blocks((R + 15) / 16, 4)), dim3(256), 0, stream, g->view, rays_o, ws.dirn, ws.nf0,
-                               (long long)R, c->probe_grid, c->probe_thresh, g->verts, t->indicator_vector, t->indicator_weight, ws.nf,
-                               nm_prof_counter(NM_CNT_PROBE));
+            if (NM_PROBE_STEP == 8)
+                hipLaunchKernelGGL(nm_probe_bounds_kernel<8>, dim3(nm_blocks((R + 7) / 8, 4)), dim3(256), 0, stream, g->view, rays_o, ws.dirn, ws.nf0,
+                                   (long long)R, c->probe_grid, c->probe_thresh, g->verts, t->indicator_vector, t->indicator_weight, ws.nf,
+                                   nm_prof_counter(NM_CNT_PROBE));
+            else
+                hipLaunchKernelGGL(nm_probe_bounds_kernel<4>, dim3(nm_blocks((R + 15) / 16, 4)), dim3(256), 0, stream, g->view, rays_o, ws.dirn, ws.nf0,
+                                   (long long)R, c->probe_grid, c->probe_thresh, g->verts, t->indicator_vector, t->indicator_weight, ws.nf,
+                                   nm_prof_counter(NM_CNT_PROBE));
             NM_LAUNCH_CHECK();
         } else {  // every probe, then the reduction (the staged API's form; kept for A/B measurements)
             src.mode = 2;

@@ -466,11 +466,14 @@ __global__ __launch_bounds__(256, 6) void nm_distance_kernel(NmGridView g, NmPoi
 // P regular probes whose projected distance is below the threshold (min / max of the masked depths;
 // the depths increase with the probe index).  Every point inside the object has ds < 0, so for a
 // ray that crosses it most probes lie BETWEEN those two and are never evaluated here: a wave owns 16
-// rays, walks their probes forward (4 per ray per step, warm-started from the step before, as in the
+// rays (8 with S = 8), walks their probes forward (S per ray per step, warm-started from the step before, as in the
 // chained tiles above) until every ray has its first hit, then backward from the far end until every
 // ray has its last one.  Results are the reference's exactly: the same probes decide, the skipped
 // ones cannot change a min / max.  Replaces a P-probe K-NN pass + the reduction kernel + the
 // [R,P] probe array.
+// S = probes per ray and step (4: 16 rays per wave, 8: 8 rays per wave -- half as many serial steps per wave, up to 4 more probes
+// per ray and walk; nm_render_rays picks)
+template <int S>
 __global__ __launch_bounds__(256, 6) void nm_probe_bounds_kernel(NmGridView g, const float* __restrict__ rays_o,
                                                                  const float* __restrict__ dirn, const float* __restrict__ nearfar0,
                                                                  long long R, int P, float thresh, const float* __restrict__ verts,
@@ -478,8 +481,10 @@ __global__ __launch_bounds__(256, 6) void nm_probe_bounds_kernel(NmGridView g, c
                                                                  float* __restrict__ nearfar,
                                                                  unsigned long long* __restrict__ searched) {
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63, sub = lane & 3, quad = lane & ~3;
-    const long long r = wave * 16 + (lane >> 2);
+    constexpr int LOG_S = S == 8 ? 3 : 2;
+    constexpr unsigned SMASK = (1u << S) - 1u;
+    const int lane = threadIdx.x & 63, sub = lane & (S - 1), quad = lane & ~(S - 1);
+    const long long r = wave * (64 / S) + (lane >> LOG_S);
     const bool valid = r < R;
     float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, n0 = 0.f, f0 = 1.f;
     if (valid) {
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(256, 6) void nm_probe_bounds_kernel(NmGridView g, c
         dx = dirn[3 * r]; dy = dirn[3 * r + 1]; dz = dirn[3 * r + 2];
         n0 = nearfar0[2 * r]; f0 = nearfar0[2 * r + 1];
     }
-    const int T = (P + 3) >> 2;
+    const int T = (P + S - 1) >> LOG_S;
     int first_idx = -1, last_idx = -1;
     unsigned n_searched = 0;  // probes this wave searched (profiling: one atomic per wave at the end)
     // one step: probe p of this lane's ray; returns ds (and the K-th-neighbour radius for the next warm start)
@@ -516,9 +521,9 @@ __global__ __launch_bounds__(256, 6) void nm_probe_bounds_kernel(NmGridView g, c
         float prev_rad = NM_INF_F, prev_dep = 0.f;
         for (int t = 0; t < T; ++t) {
             if (!__any(valid && first_idx < 0)) break;
-            const int p = 4 * t + sub;
+            const int p = S * t + sub;
             const bool act = valid && first_idx < 0 && p < P;
-            const float pr = __shfl(prev_rad, quad | 3), pd = __shfl(prev_dep, quad | 3);
+            const float pr = __shfl(prev_rad, quad | (S - 1)), pd = __shfl(prev_dep, quad | (S - 1));
             float dep, rad, init = NM_INF_F;
             // (the depth is needed for the bound before the search: same formula as inside probe())
             const float dep_here = nm_lerp_depth(n0, f0, nm_linspace01(p < P ? p : P - 1, P));
@@ -526,11 +531,11 @@ __global__ __launch_bounds__(256, 6) void nm_probe_bounds_kernel(NmGridView g, c
                 const float b = (pr + fabsf(dep_here - pd)) * 1.0001f + 1e-5f;
                 init = b * b;
             }
-            const float ds = probe(p, act, init, t > 0 ? (quad | 3) : -1, dep, rad);
+            const float ds = probe(p, act, init, t > 0 ? (quad | (S - 1)) : -1, dep, rad);
             prev_rad = rad;
             prev_dep = dep;
-            const unsigned hm = (unsigned)((__ballot(act && ds < thresh) >> quad) & 0xfull);
-            if (hm && first_idx < 0) first_idx = 4 * t + __builtin_ctz(hm);
+            const unsigned hm = (unsigned)((__ballot(act && ds < thresh) >> quad) & SMASK);
+            if (hm && first_idx < 0) first_idx = S * t + __builtin_ctz(hm);
         }
     }
     // ---- backward: last hit (strictly after the first one; none => the first one is also the last)
@@ -538,9 +543,9 @@ __global__ __launch_bounds__(256, 6) void nm_probe_bounds_kernel(NmGridView g, c
         float prev_rad = NM_INF_F, prev_dep = 0.f;
         bool started = false;
         for (int t = T - 1; t >= 0; --t) {
-            if (first_idx >= 0 && last_idx < 0 && 4 * t + 3 <= first_idx) last_idx = first_idx;  // nothing left above the first hit
+            if (first_idx >= 0 && last_idx < 0 && S * t + (S - 1) <= first_idx) last_idx = first_idx;  // nothing left above the first hit
             if (!__any(valid && first_idx >= 0 && last_idx < 0)) break;
-            const int p = 4 * t + sub;
+            const int p = S * t + sub;
             const bool act = valid && first_idx >= 0 && last_idx < 0 && p < P && p > first_idx;
             const float pr = __shfl(prev_rad, quad), pd = __shfl(prev_dep, quad);
             float dep, rad, init = NM_INF_F;
@@ -553,9 +558,9 @@ __global__ __launch_bounds__(256, 6) void nm_probe_bounds_kernel(NmGridView g, c
             prev_rad = rad;
             prev_dep = dep;
             started = true;
-            const unsigned hm = (unsigned)((__ballot(act && ds < thresh) >> quad) & 0xfull);
-            if (hm && first_idx >= 0 && last_idx < 0) last_idx = 4 * t + (31 - __builtin_clz(hm));
-            if (first_idx >= 0 && last_idx < 0 && 4 * t <= first_idx) last_idx = first_idx;  // this tile held the first hit
+            const unsigned hm = (unsigned)((__ballot(act && ds < thresh) >> quad) & SMASK);
+            if (hm && first_idx >= 0 && last_idx < 0) last_idx = S * t + (31 - __builtin_clz(hm));
+            if (first_idx >= 0 && last_idx < 0 && S * t <= first_idx) last_idx = first_idx;  // this tile held the first hit
         }
         if (first_idx >= 0 && last_idx < 0) last_idx = first_idx;
     }
