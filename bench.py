@@ -405,7 +405,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(steps, warmup, precision="f16x2", samples=128, normals=True, white=False, flags=0, keep_frame0=False, gather=True, hw=None, weight_eps=0.0):
+    def run(steps, warmup, precision="f16x2", samples=128, normals=True, white=False, flags=0, keep_frame0=False, gather=True, hw=None, weight_eps=0.0, chunk=None):
         """warmup + `steps` timed frames of one variant; returns (elapsed s [max over ranks], profile dict, rgb of frame 0 or None)."""
         model.mlp_precision = precision
         cfg = make_render_cfg(calc_normal=normals, N_samples=samples // 2, N_importance=samples // 2, white_bkgd=white, flags=flags, weight_eps=weight_eps)
@@ -419,7 +419,7 @@ def main():
         gathered = torch.empty((world * H * W, 8 if normals else 5), dtype=torch.float32, device=dev) if (world > 1 and gather) else None
 
         def step(i):
-            ret = render_rays_fused(model, rays[i][0], rays[i][1], cfg, args.rayschunk or n_rays, tables=tables)   # hw frames: chunks of one headline frame
+            ret = render_rays_fused(model, rays[i][0], rays[i][1], cfg, chunk or args.rayschunk or n_rays, tables=tables)   # hw frames: chunks of one headline frame
             if gathered is not None:
                 packed, _ = pack_outputs(ret)
                 dist.all_gather_into_tensor(gathered, packed)   # the path's only collective: final pixels
@@ -525,6 +525,9 @@ def main():
                   flags=_lib.RENDER_FULL_PROBES | _lib.RENDER_NO_ZERO_SKIP)
             short("mlp_precision_fp32 (fp32-input MFMA)", precision="fp32")
             short("calc_normal_false", normals=False)
+            short("two_half_frame_chunks_on_two_streams (rayschunk = half a frame: the low-occupancy per-ray kernels of one chunk run beside the other chunk's "
+                  "kernels; identical pixels; the per-kernel event times of this run overlap, so the roofline figures are taken from the one-stream headline run)",
+                  chunk=(n_rays + 1) // 2, keep_frame0=True)
             short("weight_eps_1e-10 (mid-points of visibility weight < 1e-10 not evaluated: the one variant that is not bit-identical; "
                   "rgb / normals move by < 127e-10, depth / acc not at all)", weight_eps=1e-10, keep_frame0=True)
             short("config3_shape (64 samples/ray, white background)", samples=64, white=True)
