@@ -184,7 +184,8 @@ typedef struct nm_render_cfg {
     /* Texture editing (editing/texture_neumesh/texture_neumesh.py:53-122: TextureEditableNeuMesh.forward), optional.
        n_edit reference models: where a mid-point's interpolation weight sits on vertices painted from reference i
        (edit_mask[i][v] != 0), the colour is blended, in the order i = 0, 1, ..:
-           a = sum_k w_k [painted], colour = colour * (1 - share) + colour_i * share   with share = a / sum_k w_k,
+           paint = sum_k w_k [painted_k], rest = sum_k w_k [not painted_k]; where paint > 0:
+           colour = colour * (rest / (paint + rest)) + colour_i * (paint / (paint + rest)),
        colour_i = reference i's colour MLP on edit_color_features interpolated with the painted neighbours' renormalised
        weights (same ds; view direction and nabla rotated into the reference's frame when edit_use_rot[i]).  Geometry, depth, acc and
        normals are the main model's. */
