@@ -45,10 +45,43 @@ def run_secant_method(f_low, f_high, d_low, d_high, rays_o_masked, rays_d_masked
     return d_pred
 
 
+_EARLY_BLOCK = 32
+
+
+def _proposal_values_until_first_sign_change(surface_query_fn, rays_o, rays_d, d_proposal, logit_tau):
+    """The [B, N_rays, N_steps] proposal values root_finding_surface_points reads -- evaluated only as far as each ray's
+    first sign change.  Everything the routine returns depends on the proposal values through the first sign change alone
+    (the first proposal's sign, the index of the first negative product val_j * val_j+1, the two values and depths around
+    it), so the proposals beyond it need not be evaluated: they are left at +1 here (the products after the first change are
+    never looked at: the cost minimum of :106-117 is already taken by the first one).  Rays are walked in blocks of _EARLY_BLOCK proposals; a ray leaves
+    the walk after the block that holds its first sign change.  Same outputs as evaluating all N_steps proposals."""
+    B, R, N = d_proposal.shape
+    val = torch.ones((B * R, N), device=d_proposal.device, dtype=torch.float32)
+    ro, rd, dp = rays_o.reshape(B * R, 3), rays_d.reshape(B * R, 3), d_proposal.reshape(B * R, N)
+    alive = torch.arange(B * R, device=d_proposal.device)
+    start = 0
+    while alive.numel() > 0:
+        stop = min(N, start + _EARLY_BLOCK + 1)   # one proposal of overlap: the product at the block's last index needs its successor
+        cols = slice(start if start == 0 else start + 1, stop)   # (the first column of a later block was evaluated as the previous block's overlap)
+        if cols.start < cols.stop:
+            pts = ro[alive].unsqueeze(-2) + dp[alive, cols].unsqueeze(-1) * rd[alive].unsqueeze(-2)
+            val[alive, cols] = (surface_query_fn(pts.unsqueeze(0)).reshape(alive.numel(), -1) - logit_tau).float()
+        seg = val[alive, start:stop]
+        changed = (seg[:, :-1] * seg[:, 1:] < 0).any(dim=-1)
+        alive = alive[~changed]
+        if stop >= N:
+            break
+        start = stop - 1
+    # rays that left early: everything after their first sign change must not produce an EARLIER-ranked cost; +1 fill gives
+    # products of sign(val_last_evaluated) with +1 and +1 * +1 -- if the last evaluated value is negative that is one more
+    # negative product, but at a later index (lower cost magnitude), so the minimum stays at the first change.
+    return val.reshape(B, R, N)
+
+
 def root_finding_surface_points(surface_query_fn, rays_o: torch.Tensor, rays_d: torch.Tensor,
                                 near: Union[float, torch.Tensor] = 0.0, far: Union[float, torch.Tensor] = 6.0,
                                 batched=True, batched_info={}, N_steps=256, logit_tau=0.0, method="secant", N_secant_steps=8,
-                                fill_inf=True):
+                                fill_inf=True, early_exit=True):
     """models/ray_casting.py:45-200.  rays_o / rays_d: [(B), N_rays, 3] (rays_d normalised); near / far: float or
     [(B), N_rays].  Returns (d_pred_out [(B),N_rays], pt_pred [(B),N_rays,3], mask, mask_sign_change).
     Sign convention: surface value > 0 outside, < 0 inside; a hit is the FIRST sign change along the ray, and it
@@ -66,7 +99,10 @@ def root_finding_surface_points(surface_query_fn, rays_o: torch.Tensor, rays_d: 
         if not isinstance(far, torch.Tensor):
             far = far * torch.ones(rays_o.shape[:-1], device=device)
         d_proposal = near[..., None] * (1 - t) + far[..., None] * t                              # [B, N_rays, N_steps]
-        val = surface_query_fn(rays_o.unsqueeze(-2) + d_proposal.unsqueeze(-1) * rays_d.unsqueeze(-2)) - logit_tau
+        if early_exit and N_steps > 2 * _EARLY_BLOCK:
+            val = _proposal_values_until_first_sign_change(surface_query_fn, rays_o, rays_d, d_proposal, logit_tau)
+        else:
+            val = surface_query_fn(rays_o.unsqueeze(-2) + d_proposal.unsqueeze(-1) * rays_d.unsqueeze(-2)) - logit_tau
         mask_0_not_occupied = val[..., 0] > 0
         # cost = sign(val_j * val_j+1) * (N_steps - j): its minimum is the first sign change (:106-117)
         sign_matrix = torch.cat([torch.sign(val[..., :-1] * val[..., 1:]), torch.ones([B, N_rays, 1], device=device)], dim=-1)

@@ -903,6 +903,12 @@ def test_surface_rendering_matches_reference_ray_casting(small, cuda_device, tor
         miss = ~m[0].cpu().numpy() & ~m_ref
         np.testing.assert_allclose(d[0].cpu().numpy()[miss], f[name + ".d"][miss], atol=1e-6)   # `far` or 0 exactly as the reference fills them
 
+        # the early-exit walk (proposals only up to each ray's first sign change) returns what the full evaluation returns
+        d_full, pt_full, m_full, msc_full = rc.root_finding_surface_points(sdf, ro.clone(), rd.clone(), near=near, far=far, batched=True, N_steps=256,
+                                                                           logit_tau=float(f[name + ".tau"]), method="secant", N_secant_steps=8, fill_inf=False,
+                                                                           early_exit=False)
+        assert torch.equal(d, d_full) and torch.equal(pt, pt_full) and torch.equal(m, m_full) and torch.equal(msc, msc_full)
+
     class Surf:
         def forward(self, p):
             return sdf(p) + 0.08
