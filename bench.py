@@ -147,7 +147,7 @@ def consumer_rows(mesh, model, dev, H, W):
     try:   # ---- training step: 512 random pixels of one view (the reference config's data.N_rays), eikonal + mask + regulariser on
         lw = {"img": 1.0, "eikonal": 0.1, "mask": 0.1, "indicator_reg": 0.1, "distill_density": 0.0, "distill_color": 0.0}
         trainer = Trainer(model, loss_weights=lw, teacher_model=None, device_ids=[dev.index or 0])
-        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+        opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.0)   # (the full update runs; a zero step keeps the timed steps on one and the same field)
         # (the view's tensors resident on the device, like every other timed input here; train.py's data loader hands over host tensors)
         model_input = {"intrinsics": torch.from_numpy(np.asarray(K, np.float32))[None].to(dev), "c2w": torch.from_numpy(np.asarray(pose, np.float32))[None].to(dev),
                        "object_mask": torch.ones(1, H * W, dtype=torch.bool, device=dev)}
