@@ -31,6 +31,13 @@ torch.cuda.synchronize()
 parts = []
 for _ in range(5): step(parts)
 print("forward / backward / optimizer ms:", (np.mean(parts, 0) * 1e3).round(2))
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(8): step()
+torch.cuda.synchronize(); print("8 steps without intermediate synchronisation: ms per step", round((time.perf_counter() - t0) / 8 * 1e3, 2), flush=True)
+t0 = time.perf_counter()
+for _ in range(8):
+    step(); torch.cuda.synchronize()
+print("8 steps, one synchronisation after each step: ms per step", round((time.perf_counter() - t0) / 8 * 1e3, 2), flush=True)
 if os.environ.get("NM_TRAIN_AB"):
     for tag, env in (("baseline", {"NEUMESH_NO_TILE_ORDER": "1", "NEUMESH_NO_RAY_SORT": "1"}), ("tile order", {"NEUMESH_NO_RAY_SORT": "1"}), ("tile order + ray sort", {}),
                      ("baseline", {"NEUMESH_NO_TILE_ORDER": "1", "NEUMESH_NO_RAY_SORT": "1"})):
