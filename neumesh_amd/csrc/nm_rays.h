@@ -22,6 +22,20 @@
 #include "nm_distance.h"
 
 #define NM_MAX_SAMPLES 256  // N_samples + N_importance upper bound
+// The per-ray loops carry only a cheap serial chain (cumprod / running sums); the expensive part of an iteration (two
+// sigmoids, correctly rounded divisions) is independent from one interval to the next.  Unrolled by four, the scheduler
+// interleaves those chains (one lane per ray, two waves per CU: the kernels are bound by instruction latency).  The
+// arithmetic and its order are unchanged.
+#ifndef NM_RAY_UNROLL
+#define NM_RAY_UNROLL 4
+#endif
+#define NM_STR2(x) #x
+#define NM_STR(x) NM_STR2(x)
+#if defined(__HIPCC__)
+#define NM_UNROLL_RAY _Pragma(NM_STR(unroll NM_RAY_UNROLL))
+#else
+#define NM_UNROLL_RAY
+#endif
 
 NM_HD float nm_exp(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -111,6 +125,7 @@ NM_HD void nm_ray_upsample(const float* d, const float* sdf, int n, int it, int 
     double T = 1.0;      // cumprod accumulator (float64, rounded to fp32 per element like torch CPU)
     double wsum = 0.0;
     float d_j = d[0], s_j = sdf[0];
+    NM_UNROLL_RAY
     for (int j = 0; j + 1 < n; ++j) {
         const float d_n = d[j + 1], s_n = sdf[j + 1];
         const float dist = nm_sub(d_n, d_j);
@@ -134,6 +149,7 @@ NM_HD void nm_ray_upsample(const float* d, const float* sdf, int n, int it, int 
     double c = 0.0;
     float w_j = n > 1 ? w[0] : 0.f;
     cdf[0] = 0.f;
+    NM_UNROLL_RAY
     for (int j = 0; j + 1 < n; ++j) {
         const float w_next = (j + 2 < n) ? w[j + 1] : 0.f;  // read before cdf[j + 1] may overwrite it
         c += (double)nm_div(w_j, sum);
@@ -195,6 +211,7 @@ NM_HD void nm_ray_merge(float* d, float* sdf, int n, int m, SlotT* slot = nullpt
 NM_HD void nm_ray_weights(const float* sdf, int N, float s, float* w) {
     double T = 1.0;  // cumprod accumulator (float64, rounded to fp32 per element like torch CPU)
     float cdf_j = nm_sigmoid(nm_mul(sdf[0], s));
+    NM_UNROLL_RAY
     for (int j = 0; j + 1 < N; ++j) {
         const float cdf_n = nm_sigmoid(nm_mul(sdf[j + 1], s));
         const float alpha = fmaxf(nm_div(nm_sub(cdf_j, cdf_n), nm_add(cdf_j, 1e-10f)), 0.0f);
@@ -217,6 +234,7 @@ NM_HD void nm_ray_composite(const float* sdf, const float* d, int N, float s, co
     // and "not read" the same set by construction)
     nm_ray_weights(sdf, N, s, w_scratch);
     float r = 0.f, g = 0.f, b = 0.f, wsum = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+    NM_UNROLL_RAY
     for (int j = 0; j + 1 < N; ++j) {
         const float w = w_scratch[j];
         if ((evaluated_w ? evaluated_w[j] : w) != 0.0f) {
@@ -237,6 +255,7 @@ NM_HD void nm_ray_composite(const float* sdf, const float* d, int N, float s, co
     }
     const float den = nm_add(wsum, 1e-10f);
     float dep = 0.f;
+    NM_UNROLL_RAY
     for (int j = 0; j + 1 < N; ++j) {
         const float dm = nm_mul(0.5f, nm_add(d[j + 1], d[j]));
         dep = nm_add(dep, nm_mul(nm_div(w_scratch[j], den), dm));
