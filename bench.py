@@ -64,7 +64,7 @@ class _Mesh:
         return self
 
 
-def build_scene(V, device, seed=0, s_value=200.0):
+def build_scene(V, device, seed=0, s_value=None, scene="surf"):
     """Scene S-DTU.  MLP weights: the set shared by every golden fixture
     (tests/golden/model_seed0.npz = the reference constructor under torch.manual_seed(0)), so that the
     benchmark scene is exactly the scene of tests/golden/render_v140k_dtu.npz; torch default init under
@@ -75,10 +75,17 @@ def build_scene(V, device, seed=0, s_value=200.0):
     torch.manual_seed(seed)
     model = NeuMesh(MeshGrid(_Mesh(mesh), device), **MODEL_CFG)
     wpath = os.path.join(ROOT, "tests", "golden", "model_seed0.npz")
+    if s_value is None:
+        s_value = 400.0 if scene == "surf" else 200.0
     if os.path.exists(wpath):
-        sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in np.load(wpath).items()}
+        sd = dict(np.load(wpath).items())
+        if scene == "surf":   # scene with a surface (sdf = ds + bump): tests/golden/render_v140k_surf.npz is the reference's render of it
+            sd = synthetic.surface_mlp_state(sd, s_value=s_value)
+        sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
         res = model.load_state_dict(sd, strict=False)
         assert not res.unexpected_keys, res.unexpected_keys
+    elif scene == "surf":
+        raise SystemExit("scene 'surf' is derived from tests/golden/model_seed0.npz, which is missing")
     with torch.no_grad():
         model.geometry_features.copy_(torch.from_numpy(synthetic.random_codes(V, 32, 1)))
         model.color_features.copy_(torch.from_numpy(synthetic.random_codes(V, 32, 2)))
@@ -207,11 +214,12 @@ def consumer_rows(mesh, model, dev, H, W):
     return out
 
 
-def parity_blocks(gpu_rgb_frame0, H, W, V, oracle_rgb, sel):
+def parity_blocks(gpu_rgb_frame0, H, W, V, oracle_rgb, sel, scene="surf"):
     """(a) vs the committed REFERENCE output of the very same rays (fixture, 1536 rays of frame 0);
     (b) vs the oracle sample rendered for the CPU baseline."""
     out = {}
-    fpath = os.path.join(ROOT, "tests", "golden", "render_v140k_dtu.npz")
+    fname = "render_v140k_surf.npz" if scene == "surf" else "render_v140k_dtu.npz"
+    fpath = os.path.join(ROOT, "tests", "golden", fname)
     if gpu_rgb_frame0 is not None and os.path.exists(fpath):
         f = np.load(fpath)
         if int(f["V"]) == V and int(f["H"]) == H and int(f["W"]) == W:
@@ -219,7 +227,7 @@ def parity_blocks(gpu_rgb_frame0, H, W, V, oracle_rgb, sel):
             err = np.abs(g - f["rgb"]).max(-1)
             se = f["self_err_1ulp"]
             out["parity_vs_reference"] = {
-                "source": "tests/golden/render_v140k_dtu.npz: the imported reference (CPU torch + declared-arithmetic K-NN) on these rays",
+                "source": f"tests/golden/{fname}: the imported reference (CPU torch + declared-arithmetic K-NN) on these rays",
                 "rays": int(len(err)), "psnr_db": _psnr(g, f["rgb"]), "max_abs_rgb": float(err.max()),
                 "median_abs_rgb": float(np.median(err)), "frac_rays_within_1e-4": float((err <= 1e-4).mean()),
                 "reference_self_sensitivity_1ulp": {"max_abs_rgb": float(se.max()), "frac_rays_within_1e-4": float((se <= 1e-4).mean())}}
@@ -350,6 +358,9 @@ def main():
     ap.add_argument("--workload", choices=["frame", "stress5"], default="frame",
                     help="frame = BASELINE configs[1], the headline 800x800x128 render (default); stress5 = BASELINE configs[4], "
                          "the HBM-bound K-NN + 256-d gather stress (a second roofline, not the headline metric)")
+    ap.add_argument("--scene", choices=["surf", "noise"], default="surf",
+                    help="surf = MLP weights with a surface (synthetic.surface_mlp_state: sdf = ds + code-driven bump, s = 400; rays miss / graze / "
+                         "hit); noise = the default-initialised weights of rounds 1-2 (every ray opaque, s = 200)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -400,7 +411,7 @@ def main():
 
     if args.samples < 8 or args.samples % 8:
         raise SystemExit("--samples must be a multiple of 8 (two halves, four up-sampling iterations)")
-    mesh, model = build_scene(args.V, dev)
+    mesh, model = build_scene(args.V, dev, scene=args.scene)
     from neumesh_amd import synthetic
     from neumesh_amd.rays import make_rays
     n_rays = args.H * args.W
@@ -480,7 +491,7 @@ def main():
         strategy = ("every probe and every mid-point evaluated (data-independent work, as the reference)" if args.data_independent else
                     "probes between the first and last hit and mid-points of weight 0 are not evaluated (bit-identical results, scene-dependent work)")
         out = {
-            "metric": f"rays/sec at {args.H}x{args.W}x{args.samples} samples (DTU scan63 shape, synthetic scene S-DTU)",
+            "metric": f"rays/sec at {args.H}x{args.W}x{args.samples} samples (DTU scan63 shape, synthetic scene S-DTU, {'with a surface' if args.scene == 'surf' else 'default-init noise field'})",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_frame": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -548,11 +559,11 @@ def main():
                                                white_bkgd=args.white_bkgd, calc_normal=not args.no_normals)
                 out["cpu_baseline"] = base
                 out["speedup_vs_cpu_baseline"] = value / base["value"]
-                out.update(parity_blocks(rgb0, args.H, args.W, args.V, orgb, sel))
+                out.update(parity_blocks(rgb0, args.H, args.W, args.V, orgb, sel, args.scene))
             except Exception as e:  # the baseline must never sink the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         elif world == 1:
-            out.update(parity_blocks(rgb0, args.H, args.W, args.V, None, None))
+            out.update(parity_blocks(rgb0, args.H, args.W, args.V, None, None, args.scene))
         if world == 1 and not args.no_extras and extra:
             try:   # BASELINE config 5 (HBM-stress of the K-NN + gather kernel), 2 steps
                 del model

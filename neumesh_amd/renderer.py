@@ -413,39 +413,87 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
             if differentiable:
                 chunks.append(_composite_autograd(model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf, samples_output, random_color_direction))
                 continue
-            nablas = None
-            if cfg.calc_normal:
-                s_all, nablas = query(model.forward_with_nablas, pts)
-                nablas = nablas.float().contiguous()
-            else:
-                s_all = query(model.forward_density_only, pts)[0]
-            sdf = s_all.reshape(R, N).float().contiguous()
-            pm = torch.empty((R, N - 1, 3), **f32)
-            _lib.check(lib.nm_rays_points(_lib.ptr(ro), _lib.ptr(dirn), R, N - 1, 1, None, _lib.ptr(dmid), N, 0, None, _lib.ptr(pm), st), "nm_rays_points")
-            view = _mid_directions(dirn, pm, random_color_direction)
-            sdf_mid, radiance = query(lambda x, v: model.forward(x, v)[:2], pm, view)
-            radiance = radiance.float().contiguous()
-            rgb, depth, acc = torch.empty((R, 3), **f32), torch.empty((R,), **f32), torch.empty((R,), **f32)
-            normals = torch.empty((R, 3), **f32) if cfg.calc_normal else None
-            s_val = float(model.forward_s())
-            _lib.check(lib.nm_rays_composite(_lib.ptr(sdf), _lib.ptr(d), R, N, N, s_val, _lib.ptr(radiance), _lib.ptr(nablas), cfg.white_bkgd,
-                                             _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc), _lib.ptr(normals), st), "nm_rays_composite")
-            ret = OrderedDict(rgb=rgb, depth_volume=depth, mask_volume=acc)
-            if cfg.calc_normal:
-                ret["normals_volume"] = normals
-            if detailed:
-                cdf, alpha = sdf_to_alpha(sdf, s_val)
-                if cfg.calc_normal:
-                    ret["implicit_nablas"] = nablas
-                ret.update(implicit_surface=sdf, radiance=radiance, alpha=alpha, cdf=cdf, visibility_weights=alpha_to_w(alpha),
-                           d_final=0.5 * (d[:, 1:] + d[:, :-1]), d_all=d, near_far=nf)
-                if samples_output:
-                    ret.update(xyz=pm, dirs=dirn[:, None, :].expand(R, N - 1, 3), density=sdf_mid, colors=radiance)
+            ret = _staged_tail(lib, st, model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf, samples_output, random_color_direction)
             chunks.append(ret)
     out = OrderedDict((k, torch.cat([c[k] for c in chunks], 0)) for k in chunks[0])
     if ray_inv is not None:
         out = OrderedDict((k, v[ray_inv]) for k, v in out.items())
     return out
+
+
+def _staged_tail(lib, st, model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf, samples_output=False, random_color_direction=False):
+    """renderer.py:264-348 on given sorted depths d [R,N] (mid-point depths dmid, sample points pts): field + nablas at
+    the samples, radiance at the mid-points through the model's own methods, nm_rays_composite."""
+    R, N = d.shape
+    dev = d.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    nablas = None
+    if cfg.calc_normal:
+        s_all, nablas = query(model.forward_with_nablas, pts)
+        nablas = nablas.float().contiguous()
+    else:
+        s_all = query(model.forward_density_only, pts)[0]
+    sdf = s_all.reshape(R, N).float().contiguous()
+    pm = torch.empty((R, N - 1, 3), **f32)
+    _lib.check(lib.nm_rays_points(_lib.ptr(ro), _lib.ptr(dirn), R, N - 1, 1, None, _lib.ptr(dmid), N, 0, None, _lib.ptr(pm), st), "nm_rays_points")
+    view = _mid_directions(dirn, pm, random_color_direction)
+    sdf_mid, radiance = query(lambda x, v: model.forward(x, v)[:2], pm, view)
+    radiance = radiance.float().contiguous()
+    rgb, depth, acc = torch.empty((R, 3), **f32), torch.empty((R,), **f32), torch.empty((R,), **f32)
+    normals = torch.empty((R, 3), **f32) if cfg.calc_normal else None
+    s_val = float(model.forward_s())
+    _lib.check(lib.nm_rays_composite(_lib.ptr(sdf), _lib.ptr(d), R, N, N, s_val, _lib.ptr(radiance), _lib.ptr(nablas), cfg.white_bkgd,
+                                     _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc), _lib.ptr(normals), st), "nm_rays_composite")
+    ret = OrderedDict(rgb=rgb, depth_volume=depth, mask_volume=acc)
+    if cfg.calc_normal:
+        ret["normals_volume"] = normals
+    if detailed:
+        cdf, alpha = sdf_to_alpha(sdf, s_val)
+        if cfg.calc_normal:
+            ret["implicit_nablas"] = nablas
+        ret.update(implicit_surface=sdf, radiance=radiance, alpha=alpha, cdf=cdf, visibility_weights=alpha_to_w(alpha),
+                   d_final=0.5 * (d[:, 1:] + d[:, :-1]), d_all=d, near_far=nf)
+        if samples_output:
+            ret.update(xyz=pm, dirs=dirn[:, None, :].expand(R, N - 1, 3), density=sdf_mid, colors=radiance)
+    return ret
+
+
+def render_at_depths(model, rays_o, rays_d, d_all, cfg: _lib.RenderCfg, netchunk: int = 1 << 20, detailed: bool = False):
+    """The part of render_rayschunk after the sample placement (models/renderer.py:264-333) on GIVEN sorted sample
+    depths d_all [R,N] (N = cfg.N_samples + cfg.N_importance): SDF (+ nablas) at the samples, radiance at the mid-points,
+    alpha / visibility weights / compositing on the HIP kernels.  With another implementation's depths this compares
+    everything behind the sampler ray by ray, without the sampler's sensitivity to the last bit of an SDF value."""
+    lib = _lib.load()
+    dev = rays_o.device
+    if dev.type != "cuda":
+        raise _lib.NeuMeshHipError("rays must be on a HIP device (no CPU fallback)")
+    ro = rays_o.detach().float().reshape(-1, 3).contiguous()
+    rd = rays_d.detach().float().reshape(-1, 3).contiguous()
+    d = d_all.detach().float().contiguous()
+    R, N = d.shape
+    if R != ro.shape[0] or N != cfg.N_samples + cfg.N_importance:
+        raise ValueError(f"d_all must be [{ro.shape[0]}, {cfg.N_samples + cfg.N_importance}], got {tuple(d.shape)}")
+    f32 = dict(dtype=torch.float32, device=dev)
+
+    def query(fn, pts, *extra):
+        flat = pts.reshape(-1, 3)
+        ex = [e.reshape(-1, e.shape[-1]) for e in extra]
+        outs = []
+        for i in range(0, flat.shape[0], max(1, int(netchunk))):
+            o = fn(flat[i:i + netchunk], *[e[i:i + netchunk] for e in ex])
+            outs.append(o if isinstance(o, tuple) else (o,))
+        cols = [torch.cat([o[k] for o in outs], 0) for k in range(len(outs[0]))]
+        return [c.reshape(pts.shape[0], pts.shape[1], *c.shape[1:]) for c in cols]
+
+    with torch.cuda.device(dev), torch.no_grad():
+        st = _lib.current_stream(dev)
+        dirn, nf0 = torch.empty((R, 3), **f32), torch.empty((R, 2), **f32)
+        _lib.check(lib.nm_rays_setup(_lib.ptr(ro), _lib.ptr(rd), R, cfg.obj_bounding_radius, _lib.ptr(dirn), _lib.ptr(nf0), st), "nm_rays_setup")
+        dmid = torch.zeros((R, N), **f32)
+        dmid[:, :N - 1] = 0.5 * (d[:, 1:] + d[:, :-1])
+        pts = torch.empty((R, N, 3), **f32)
+        _lib.check(lib.nm_rays_points(_lib.ptr(ro), _lib.ptr(dirn), R, N, 1, None, _lib.ptr(d), N, 0, None, _lib.ptr(pts), st), "nm_rays_points")
+        return _staged_tail(lib, st, model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf0)
 
 
 def _mid_directions(dirn, pts_mid, random_color_direction: bool):

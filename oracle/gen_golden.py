@@ -227,7 +227,7 @@ def gen_grad_fixture(tag, render_tag, V, mlp_state):
                         rgb=rgb[0].detach().numpy(), **grads)
 
 
-def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=800, mlp_state=None):
+def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=800, mlp_state=None, s_value=200.0):
     """Headline-scale pin (BASELINE configs[1] shape, SURVEY 8d scene S-DTU): `n_rays` strided rays of
     frame 0 of the 800x800 orbit rendered by the IMPORTED REFERENCE at V = 140 000, with the stages a
     diverging ray can be traced through (near/far, coarse SDF, sorted depths after every up-sampling
@@ -242,7 +242,7 @@ def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=8
     from oracle import knn as oknn
     print(f"[{tag}] V={V} rays={n_rays} of {H}x{W}")
     mesh = synthetic.fibonacci_blob(V)
-    model, kw, renderer, _ = harness.build_reference(mesh, seed=0, mlp_state=mlp_state)
+    model, kw, renderer, _ = harness.build_reference(mesh, seed=0, mlp_state=mlp_state, s_value=s_value)
     import frnn as frnn_stub                 # oracle/refimport/stubs/frnn.py
     import models.renderer as ref_renderer   # reference
     tree = cKDTree(mesh.vertices.astype(np.float64))
@@ -310,6 +310,13 @@ def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=8
     print(f"    reference render: {t_ref:.1f} s ({n_rays / t_ref:.0f} rays/s on {os.cpu_count()} cores, torch threads {torch.get_num_threads()})")
     d_all = trace["d_iter4"]
     assert d_all.shape == (n_rays, 128)
+    acc = ref["mask_volume"]
+    stats = {"rays_acc_eq_0": int((acc == 0).sum()), "rays_acc_lt_1e-3": int((acc < 1e-3).sum()),
+             "rays_partial(1e-3..0.999)": int(((acc >= 1e-3) & (acc <= 0.999)).sum()), "rays_acc_gt_0.999": int((acc > 0.999).sum()),
+             "rgb_std": float(ref["rgb"].std()), "rgb_std_opaque_rays": float(ref["rgb"][acc > 0.999].std()) if (acc > 0.999).any() else None,
+             "zero_weight_midpoint_fraction": float((ref["visibility_weights"] == 0).mean())}
+    print("    scene:", stats)
+    REPORT[f"{tag}.scene"] = stats
     # the kd-tree stand-in == the brute-force declaration on (a sample of) the queries this render issued
     qs = np.concatenate([q.reshape(-1, 3) for q in queries])
     pick = np.random.default_rng(5).choice(qs.shape[0], 40000, replace=False)
@@ -346,8 +353,19 @@ def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=8
         d_iter1=trace["d_iter1"], d_iter2=trace["d_iter2"], d_iter3=trace["d_iter3"], d_all=d_all,
         sdf_all=ref["implicit_surface"].astype(np.float32),
         rgb=ref["rgb"], depth_volume=ref["depth_volume"], mask_volume=ref["mask_volume"], normals_volume=ref["normals_volume"],
-        self_err_1ulp=self_err,
+        self_err_1ulp=self_err, s=np.float32(model.forward_s().item()), state_sha256=np.array(state_digest(mlp_state) if mlp_state is not None else ""),
     )
+
+
+def state_digest(state) -> str:
+    """sha256 over the MLP tensors of a state dict (sorted keys, raw fp32 bytes): the product side
+    re-derives the surface scene's weights and must arrive at these very bytes."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(state):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(state[k], dtype=np.float32).tobytes())
+    return h.hexdigest()
 
 
 class StubTeacher:
@@ -500,10 +518,12 @@ def gen_rays_fixture():
 
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
-    if len(sys.argv) > 1 and sys.argv[1] in ("scale", "train", "surface"):   # only one of the later fixtures (the others are unchanged)
+    if len(sys.argv) > 1 and sys.argv[1] in ("scale", "train", "surface", "surf"):   # only one of the later fixtures (the others are unchanged)
         sd = dict(np.load(os.path.join(GOLDEN, "model_seed0.npz")))
         if sys.argv[1] == "scale":
             gen_scale_fixture("render_v140k_dtu", mlp_state=sd)
+        elif sys.argv[1] == "surf":   # the scene with a surface (neumesh_amd.synthetic.surface_mlp_state), s = 400
+            gen_scale_fixture("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0)
         elif sys.argv[1] == "train":
             gen_train_step_fixture("train_step_v3000", V=3000, mlp_state=sd)
         else:
@@ -527,6 +547,7 @@ def main():
     gen_train_step_fixture("train_step_v3000", V=3000, mlp_state=sd)
     gen_surface_fixture("surface_v3000", V=3000, mlp_state=sd)
     gen_scale_fixture("render_v140k_dtu", mlp_state=sd)
+    gen_scale_fixture("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0)
     with open(os.path.join(GOLDEN, "REPORT.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
     print("all oracle-vs-reference checks passed; fixtures written to", GOLDEN)

@@ -198,8 +198,22 @@ def render_rays(field, rays_o, rays_d, cfg: RenderConfig = RenderConfig(), detai
         sdf = np.take_along_axis(sdf, order, axis=-1)
         if detailed:
             out[f"d_fine_{it}"] = d_fine
-    d_all = d
-    out["d_all"] = d_all
+    out["d_all"] = d
+    out.update(render_at_depths(field, rays_o, rays_d, d, cfg, detailed, normalized=True))
+    return out
+
+
+def render_at_depths(field, rays_o, rays_d, d_all, cfg: RenderConfig = RenderConfig(), detailed: bool = False,
+                     normalized: bool = False) -> Dict[str, np.ndarray]:
+    """The tail of render_rayschunk (models/renderer.py:264-333) on GIVEN sorted sample depths d_all [R,N]:
+    field + nablas at the samples, radiance at the mid-points, alpha / weights / compositing.  (Used with the
+    reference's own depths this compares everything after the sample placement without the placement's chaos.)"""
+    rays_o = np.ascontiguousarray(rays_o, dtype=F32).reshape(-1, 3)
+    rays_d = np.ascontiguousarray(rays_d, dtype=F32).reshape(-1, 3)
+    if not normalized:
+        rays_d = normalize(rays_d)
+    d_all = np.ascontiguousarray(d_all, dtype=F32)
+    out: Dict[str, np.ndarray] = {}
 
     pts = (rays_o[:, None, :] + rays_d[:, None, :] * d_all[..., None]).astype(F32)      # :264
     d_mid = (F32(0.5) * (d_all[..., 1:] + d_all[..., :-1])).astype(F32)                 # :266

@@ -38,6 +38,24 @@ def scene_state(mesh, mlp_seed_file: str = "model_seed0") -> dict:
     return sd
 
 
+def surface_state(mesh) -> dict:
+    """The scene WITH a surface (tests/golden/render_v140k_surf.npz): the fixture weights re-shaped by
+    synthetic.surface_mlp_state (unit 0 of the geometry layers carries ds, sdf = ds + a code-driven bump), s = 400."""
+    sd = scene_state(mesh)
+    sd.update(synthetic.surface_mlp_state({k: v for k, v in golden("model_seed0").items()}))
+    return sd
+
+
+def state_digest(state) -> str:
+    """sha256 over the MLP tensors (sorted keys, fp32 bytes) -- as oracle/gen_golden.py:state_digest."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(state):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(state[k], dtype=np.float32).tobytes())
+    return h.hexdigest()
+
+
 class MeshObj:
     """Duck-type of the open3d mesh the reference passes to MeshGrid."""
 

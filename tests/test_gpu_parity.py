@@ -552,6 +552,75 @@ def test_render_headline_scale_matches_reference_fixture(dtu_scale, cuda_device,
     assert np.abs(nf - f["near_far"]).max() <= 2e-6
 
 
+@pytest.fixture(scope="module")
+def surf_scale(cuda_device):
+    mesh = common.scene_mesh(140000)
+    state = common.surface_state(mesh)
+    return mesh, state, common.make_model(mesh, state, cuda_device)
+
+
+def test_render_surface_scene_matches_reference_fixture(surf_scale, cuda_device, torch_mod):
+    """The headline shape on a scene WITH A SURFACE: tests/golden/render_v140k_surf.npz = 1536 strided
+    rays of frame 0 rendered by the imported reference on the weights of synthetic.surface_mlp_state (sdf = ds + bump,
+    s = 400): 356 rays with acc == 0 (they miss: near/far fall back to the bounding sphere), 130 partially covered, 911
+    opaque, rgb std 0.25.  A sharp crossing makes the reference's sample placement sensitive to the last bit (its own
+    render with directions nudged by 1 ulp moves 18 rays by > 1e-4, one by 1.6e-3), so the gates are
+      (1) everything behind the sampler, on the REFERENCE'S OWN 128 depths per ray (render_at_depths): rgb / acc /
+          normals <= 1e-4 and depth <= 2e-4 on EVERY ray;
+      (2) end to end: median <= 1e-6, rays beyond 1e-4 no more than the reference's own 1-ulp share + 1 %, near/far <= 2e-6,
+          coverage classes (acc == 0 / partial / opaque) of every ray equal to the reference's;
+      (3) production call (ray sort, first/last-hit probe walk, zero-weight skip) == detailed call, bit for bit;
+      (4) the field on the reference's own sample points: |sdf| <= 3e-6."""
+    torch = torch_mod
+    from neumesh_amd.renderer import make_render_cfg, render_at_depths, volume_render
+    mesh, state, model = surf_scale
+    f = common.golden("render_v140k_surf")
+    assert int(f["V"]) == mesh.num_vertices and str(f["state_sha256"]) == common.state_digest(
+        {k: v for k, v in state.items() if k not in ("geometry_features", "color_features", "indicator_vector")})
+    assert abs(float(model.forward_s()) - float(f["s"])) <= 1e-3
+    ro, rd = _t(f["rays_o"], cuda_device), _t(f["rays_d"], cuda_device)
+    n = len(f["rgb"])
+    # (1) behind the sampler
+    with torch.no_grad():
+        tail = render_at_depths(model, ro, rd, _t(f["d_all"], cuda_device), make_render_cfg(calc_normal=True), detailed=True)
+    t = {k: v.cpu().numpy() for k, v in tail.items()}
+    worst = {}
+    for key, tol in (("rgb", 1e-4), ("mask_volume", 1e-4), ("normals_volume", 1e-4), ("depth_volume", 2e-4)):
+        e = np.abs(t[key] - f[key]).reshape(n, -1).max(-1)
+        worst[key] = float(e.max())
+        assert e.max() <= tol, (key, float(e.max()), int(e.argmax()))
+    sdf_err = float(np.abs(t["implicit_surface"] - f["sdf_all"]).max())
+    print(f"surface scene, on the reference's own depths ({n} rays): max errors {worst}, |sdf| {sdf_err:.2e}")
+    assert sdf_err <= 3e-6
+    # (2), (3) end to end
+    kw = dict(calc_normal=True, N_samples=64, N_importance=64, perturb=False, rayschunk=65536)
+    with torch.no_grad():
+        rgb, depth, ex = volume_render(ro, rd, model, detailed_output=True, **kw)
+        rgb_p, depth_p, ex_p = volume_render(ro, rd, model, detailed_output=False, **kw)
+    assert torch.equal(rgb, rgb_p) and torch.equal(depth, depth_p) and torch.equal(ex["mask_volume"], ex_p["mask_volume"])
+    assert torch.equal(ex["normals_volume"], ex_p["normals_volume"])
+    g = {k: v.cpu().numpy() for k, v in ex.items()}
+    err = np.abs(g["rgb"] - f["rgb"]).max(-1)
+    self_err = f["self_err_1ulp"]
+    acc_r, acc_g = f["mask_volume"], g["mask_volume"]
+    print(f"surface scene end to end: median {np.median(err):.1e}, max {err.max():.2e}, PSNR {compare.psnr(g['rgb'], f['rgb']):.1f} dB, "
+          f"rays > 1e-4: {int((err > 1e-4).sum())} (reference vs itself + 1 ulp: {int((self_err > 1e-4).sum())}, max {self_err.max():.2e}); "
+          f"acc == 0: {int((acc_g == 0).sum())}, partial: {int(((acc_g >= 1e-3) & (acc_g <= 0.999)).sum())}, opaque: {int((acc_g > 0.999).sum())}")
+    assert int((acc_r == 0).sum()) >= 300 and int(((acc_r >= 1e-3) & (acc_r <= 0.999)).sum()) >= 100 and int((acc_r > 0.999).sum()) >= 800
+    assert float(f["rgb"].std()) > 0.1
+    assert np.array_equal(acc_g == 0, acc_r == 0)
+    assert np.abs(g["near_far"] - f["near_far"]).max() <= 2e-6
+    assert np.median(err) <= 1e-6
+    assert (err > 1e-4).mean() <= (self_err > 1e-4).mean() + 0.01
+    for key, tol in (("depth_volume", 2e-4), ("mask_volume", 1e-4), ("normals_volume", 1e-4)):
+        e = np.abs(g[key] - f[key]).reshape(n, -1).max(-1)
+        assert np.median(e) <= 1e-6, key
+        assert (e > tol).mean() <= (self_err > 1e-4).mean() + 0.01, key
+    # rays the reference itself holds still under the 1-ulp nudge and whose samples we place where it does: tight
+    calm = (self_err <= 1e-6) & (np.abs(g["d_all"] - f["d_all"]).max(-1) <= 2e-6)
+    assert calm.sum() >= 300 and err[calm].max() <= 1e-4, (int(calm.sum()), float(err[calm].max()))
+
+
 @pytest.mark.gpu
 def test_weight_eps_drops_only_negligible_terms(dtu_scale, cuda_device, torch_mod):
     """nm_render_cfg.weight_eps (the one setting that is not bit-identical): mid-points whose visibility weight is below it
