@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 6
+#define NM_ABI_VERSION 7
 #define NM_MAX_K 32
 
 typedef struct nm_grid_s* nm_grid_t;    /* spatial index over the mesh vertices */
@@ -277,6 +277,11 @@ typedef struct nm_camera {
 } nm_camera;
 int nm_make_rays(const nm_camera* cam, int64_t first_pixel, int64_t count, float* rays_o,
                  float* rays_d, nm_stream_t stream);
+/* The same for a LIST of row-major pixel indices (device pointer, int64; entries outside the frame are clamped):
+ * the pixels of a rank's interleaved tiles in a ray-sharded frame (neumesh_amd/sharded.py), or the random pixel
+ * selection of a training step (rend_util.get_rays with N_rays > 0, utils/rend_util.py:150-160). */
+int nm_make_rays_indexed(const nm_camera* cam, const int64_t* pixels, int64_t count, float* rays_o,
+                         float* rays_d, nm_stream_t stream);
 
 /* ----------------------------------------------------------------------------- image assembly
  * What render.py:219-249 does on the host with the three outputs of a frame, per pixel, on the device

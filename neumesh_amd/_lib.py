@@ -11,7 +11,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_K = 32
 
 
@@ -93,6 +93,7 @@ SIGNATURES = {
     "nm_rays_finalize": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P]),
     "nm_rays_composite": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
     "nm_make_rays": (C.c_int, [C.POINTER(Camera), C.c_int64, C.c_int64, _P, _P, _P]),
+    "nm_make_rays_indexed": (C.c_int, [C.POINTER(Camera), _P, C.c_int64, _P, _P, _P]),
     "nm_assemble_frame": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P]),
     "nm_profile_enable": (C.c_int, [C.c_int]),
     "nm_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

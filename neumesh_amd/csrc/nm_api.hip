@@ -19,9 +19,7 @@
 #include "nm_grid_build_dev.h"
 #include "nm_kernels.h"
 #include "nm_mlp.h"
-#include "nm_mlp_f16.h"
 #include "nm_mlp_h2.h"
-#include "nm_mlp_h3.h"
 #include "nm_edit.h"
 
 #ifndef NM_PROBE_STEP
@@ -115,10 +113,8 @@ struct nm_field_s {
     NmColParams col;
     float* blob = nullptr;  // packed weights
     size_t blob_floats = 0;
-    int precision = 0;       // 0 fp32, 1 split-half f16 (first layout), 2 split-half f16 (nm_mlp_h2.h); mlp_precision 3 = 2 + use_h3
-    bool use_h3 = false;     // reference configuration with >= 2 layers: the pipelined kernels of nm_mlp_h3.h (same weights / numerics as mode 2)
-    NmGeoParamsH geo_h;
-    NmColParamsH col_h;
+    int precision = 0;       // 0 fp32 MFMA (nm_mlp.h), 2 f16 MFMA (nm_mlp_h2.h); mlp_precision 4 = 2 + single
+    bool single = false;     // f16 MFMA with ONE product per fp32 product (plain fp16 operands): error-quantified mode, never the default
     NmGeoParamsH2 geo_h2;
     NmColParamsH2 col_h2;
     bool geo_fixed = false, col_fixed = false;  // reference configuration: kernels with constant embedding trip counts
@@ -338,7 +334,8 @@ static int nm_field_validate(const nm_field_desc* d) {
     if (d->multires_d < 0 || d->multires_fg < 0 || d->multires_ft < 0 || d->multires_view < 0) return nm_fail("nm_field: negative multires (identity embedders) unsupported");
     if (d->multires_d > 16 || d->multires_view > 16) return nm_fail("nm_field: multires too large");
     if (!d->use_view_dirs) return nm_fail("nm_field: use_view_dirs=0 unsupported");
-    if (d->mlp_precision < 0 || d->mlp_precision > 3) return nm_fail("nm_field: mlp_precision=%d (0 = fp32, 1 = split-half f16 first layout, 2 = split-half f16, 3 = split-half f16 with pipelined epilogues)", d->mlp_precision);
+    if (d->mlp_precision != 0 && d->mlp_precision != 2 && d->mlp_precision != 4)
+        return nm_fail("nm_field: mlp_precision=%d (0 = fp32 MFMA, 2 = split-half f16 MFMA [default], 4 = single-product f16 MFMA)", d->mlp_precision);
     const int in_geo = 1 + 2 * d->multires_d + d->geometry_dim * (1 + 2 * d->multires_fg);
     const int in_col = (d->enable_nablas_input ? 3 : 0) + 1 + 2 * d->multires_d + 3 * (1 + 2 * d->multires_view) + d->color_dim * (1 + 2 * d->multires_ft);
     if (in_geo > 256 || in_col > 256) return nm_fail("nm_field: MLP input width %d/%d exceeds the 256-column LDS tile", in_geo, in_col);
@@ -408,8 +405,8 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
     f->col.d_emb = 1 + 2 * d->multires_d;
     f->col.in_dim = in_col;
     f->desc = *d;
-    f->precision = d->mlp_precision == 3 ? 2 : d->mlp_precision;
-    f->use_h3 = d->mlp_precision == 3;
+    f->precision = d->mlp_precision == 4 ? 2 : d->mlp_precision;
+    f->single = d->mlp_precision == 4;
     if (d->mlp_precision >= 1) {
         size_t need_h = 0;
         for (int l = 0; l < d->D_density; ++l) need_h += (size_t)NM_W * nm_round16(l == 0 ? in_geo : NM_W) * 2;
@@ -425,29 +422,6 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
             NM_HIP(hipMalloc((void**)&f->overflow, sizeof(int)));
             NM_HIP(hipMemsetAsync(f->overflow, 0, sizeof(int), stream));
         }
-    }
-    if (d->mlp_precision == 1) {
-        _Float16* ph = f->blob_h;
-        memset(&f->geo_h, 0, sizeof(f->geo_h));
-        memset(&f->col_h, 0, sizeof(f->col_h));
-        auto pack_h = [&](const float* src, int in_dim, NmLayerH& L, const float* packed_bias) {
-            L.Kpad = nm_round16(in_dim);
-            L.W = ph;
-            L.b = packed_bias;
-            hipLaunchKernelGGL(nm_pack_weight_h_kernel, dim3(nm_blocks((long long)NM_W * L.Kpad, 256)), dim3(256), 0, stream, src, in_dim, L.Kpad, ph);
-            ph += (size_t)NM_W * L.Kpad * 2;
-        };
-        for (int l = 0; l < d->D_density; ++l) pack_h(d->geo_weight[l], l == 0 ? in_geo : NM_W, f->geo_h.layer[l], f->geo.layer[l].b);
-        for (int l = 0; l < d->D_color; ++l) pack_h(d->col_weight[l], l == 0 ? in_col : NM_W, f->col_h.layer[l], f->col.layer[l].b);
-        NM_LAUNCH_CHECK();
-        NM_HIP(hipStreamSynchronize(stream));
-        f->geo_h.D = f->geo.D; f->geo_h.wd = f->geo.wd; f->geo_h.bd = f->geo.bd;
-        f->geo_h.multires_d = f->geo.multires_d; f->geo_h.multires_fg = f->geo.multires_fg; f->geo_h.gdim = f->geo.gdim;
-        f->geo_h.d_emb = f->geo.d_emb; f->geo_h.in_dim = f->geo.in_dim;
-        f->col_h.D = f->col.D; f->col_h.wrgb = f->col.wrgb;
-        f->col_h.brgb[0] = f->col.brgb[0]; f->col_h.brgb[1] = f->col.brgb[1]; f->col_h.brgb[2] = f->col.brgb[2];
-        f->col_h.multires_d = f->col.multires_d; f->col_h.multires_ft = f->col.multires_ft; f->col_h.multires_view = f->col.multires_view;
-        f->col_h.cdim = f->col.cdim; f->col_h.use_nabla = f->col.use_nabla; f->col_h.d_emb = f->col.d_emb; f->col_h.in_dim = f->col.in_dim;
     }
     if (f->precision == 2) {
         _Float16* ph = f->blob_h;
@@ -592,25 +566,21 @@ static int nm_launch_geo(nm_field_t f, const float* fg, const float* ds, const f
                          NmRecMap rmap = NM_COMPACT, int nabla_slotted = 0, NmSlotMap smap = NM_NO_SLOTS, bool counted = false) {
     if (P <= 0) return 0;
     NmProfScope prof(nabla ? NM_K_GEO_NABLA : NM_K_GEO, counted ? 0 : P, stream, counted ? NM_CNT_MID : NM_CNT_NONE);
-    if (f->precision == 2 && f->use_h3 && f->geo_fixed && f->geo_h2.D >= 2) {
-        const dim3 gr(nm_blocks(P, nabla ? 64 : 128)), bl(NM_H3_THREADS);
-        if (nabla) hipLaunchKernelGGL((nm_geo_mlp_h3_kernel<true>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow);
-        else hipLaunchKernelGGL((nm_geo_mlp_h3_kernel<false>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow);
-        NM_LAUNCH_CHECK();
-        return 0;
-    }
     if (f->precision == 2) {
         const dim3 gr(nm_blocks(P, nabla ? 32 : 64)), bl(NM_H_THREADS);
-        if (nabla && f->geo_fixed) hipLaunchKernelGGL((nm_geo_mlp_h2_kernel<true, true>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow);
-        else if (nabla) hipLaunchKernelGGL((nm_geo_mlp_h2_kernel<true, false>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow);
-        else if (f->geo_fixed) hipLaunchKernelGGL((nm_geo_mlp_h2_kernel<false, true>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow);
-        else hipLaunchKernelGGL((nm_geo_mlp_h2_kernel<false, false>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow);
-        NM_LAUNCH_CHECK();
-        return 0;
-    }
-    if (f->precision == 1) {
-        if (nabla) hipLaunchKernelGGL((nm_geo_mlp_h_kernel<true>), dim3(nm_blocks(P, 32)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap);
-        else hipLaunchKernelGGL((nm_geo_mlp_h_kernel<false>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->geo_h, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap);
+#define NM_GEO_H2(NB, FX, NP) hipLaunchKernelGGL((nm_geo_mlp_h2_kernel<NB, FX, NP>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow)
+        if (!f->single) {
+            if (nabla && f->geo_fixed) NM_GEO_H2(true, true, 3);
+            else if (nabla) NM_GEO_H2(true, false, 3);
+            else if (f->geo_fixed) NM_GEO_H2(false, true, 3);
+            else NM_GEO_H2(false, false, 3);
+        } else {
+            if (nabla && f->geo_fixed) NM_GEO_H2(true, true, 1);
+            else if (nabla) NM_GEO_H2(true, false, 1);
+            else if (f->geo_fixed) NM_GEO_H2(false, true, 1);
+            else NM_GEO_H2(false, false, 1);
+        }
+#undef NM_GEO_H2
         NM_LAUNCH_CHECK();
         return 0;
     }
@@ -629,19 +599,16 @@ static int nm_launch_col(nm_field_t f, const float* ft, const float* ds, const f
                          long long P, float* rgb, hipStream_t stream, NmSlotMap smap = NM_NO_SLOTS, bool counted = false) {
     if (P <= 0) return 0;
     NmProfScope prof(NM_K_COLOR, counted ? 0 : P, stream, counted ? NM_CNT_MID : NM_CNT_NONE);
-    if (f->precision == 2 && f->use_h3 && f->col_fixed && f->col_h2.D >= 2) {
-        hipLaunchKernelGGL(nm_col_mlp_h3_kernel, dim3(nm_blocks(P, NM_H3_ROWS)), dim3(NM_H3_THREADS), 0, stream, f->col_h2, ft, ds, nabla, dirs, dir_div, P, rgb, smap, f->overflow);
-        NM_LAUNCH_CHECK();
-        return 0;
-    }
     if (f->precision == 2) {
-        if (f->col_fixed) hipLaunchKernelGGL((nm_col_mlp_h2_kernel<true>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h2, ft, ds, nabla, dirs, dir_div, P, rgb, smap, f->overflow);
-        else hipLaunchKernelGGL((nm_col_mlp_h2_kernel<false>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h2, ft, ds, nabla, dirs, dir_div, P, rgb, smap, f->overflow);
-        NM_LAUNCH_CHECK();
-        return 0;
-    }
-    if (f->precision == 1) {
-        hipLaunchKernelGGL(nm_col_mlp_h_kernel, dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h, ft, ds, nabla, dirs, dir_div, P, rgb, smap);
+#define NM_COL_H2(FX, NP) hipLaunchKernelGGL((nm_col_mlp_h2_kernel<FX, NP>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h2, ft, ds, nabla, dirs, dir_div, P, rgb, smap, f->overflow)
+        if (!f->single) {
+            if (f->col_fixed) NM_COL_H2(true, 3);
+            else NM_COL_H2(false, 3);
+        } else {
+            if (f->col_fixed) NM_COL_H2(true, 1);
+            else NM_COL_H2(false, 1);
+        }
+#undef NM_COL_H2
         NM_LAUNCH_CHECK();
         return 0;
     }
@@ -1168,18 +1135,36 @@ int nm_assemble_frame(const float* rgb, const float* depth, const float* normals
     return 0;
 }
 
-int nm_make_rays(const nm_camera* cam, int64_t first_pixel, int64_t count, float* rays_o, float* rays_d, nm_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!cam) return nm_fail("nm_make_rays: cam is NULL");
-    if (cam->H < 1 || cam->W < 1 || first_pixel < 0 || count < 0 || first_pixel + count > (int64_t)cam->H * cam->W)
-        return nm_fail("nm_make_rays: pixel range [%lld,+%lld) outside %dx%d", (long long)first_pixel, (long long)count, cam->H, cam->W);
-    if (count == 0) return 0;
-    if (!rays_o || !rays_d) return nm_fail("nm_make_rays: NULL output");
-    NmCamera c;
+static int nm_camera_convert(const nm_camera* cam, NmCamera& c, const char* who) {
+    if (!cam) return nm_fail("%s: cam is NULL", who);
+    if (cam->H < 1 || cam->W < 1) return nm_fail("%s: image size %dx%d", who, cam->H, cam->W);
     for (int i = 0; i < 12; ++i) c.r[i] = cam->c2w[i];
     c.fx = cam->fx; c.fy = cam->fy; c.cx = cam->cx; c.cy = cam->cy; c.sk = cam->sk;
     c.H = cam->H; c.W = cam->W;
+    return 0;
+}
+
+int nm_make_rays(const nm_camera* cam, int64_t first_pixel, int64_t count, float* rays_o, float* rays_d, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NmCamera c;
+    if (int rc = nm_camera_convert(cam, c, "nm_make_rays")) return rc;
+    if (first_pixel < 0 || count < 0 || first_pixel + count > (int64_t)cam->H * cam->W)
+        return nm_fail("nm_make_rays: pixel range [%lld,+%lld) outside %dx%d", (long long)first_pixel, (long long)count, cam->H, cam->W);
+    if (count == 0) return 0;
+    if (!rays_o || !rays_d) return nm_fail("nm_make_rays: NULL output");
     hipLaunchKernelGGL(nm_make_rays_kernel, dim3(nm_blocks(count, 256)), dim3(256), 0, stream, c, (long long)first_pixel, (long long)count, rays_o, rays_d);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_make_rays_indexed(const nm_camera* cam, const int64_t* pixels, int64_t count, float* rays_o, float* rays_d, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NmCamera c;
+    if (int rc = nm_camera_convert(cam, c, "nm_make_rays_indexed")) return rc;
+    if (count < 0) return nm_fail("nm_make_rays_indexed: count %lld", (long long)count);
+    if (count == 0) return 0;
+    if (!pixels || !rays_o || !rays_d) return nm_fail("nm_make_rays_indexed: NULL pointer");
+    hipLaunchKernelGGL(nm_make_rays_indexed_kernel, dim3(nm_blocks(count, 256)), dim3(256), 0, stream, c, (const long long*)pixels, (long long)count, rays_o, rays_d);
     NM_LAUNCH_CHECK();
     return 0;
 }

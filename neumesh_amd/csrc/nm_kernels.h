@@ -967,11 +967,7 @@ struct NmCamera {
     float fx, fy, cx, cy, sk;
     int H, W;
 };
-__global__ void nm_make_rays_kernel(NmCamera cam, long long first, long long count, float* __restrict__ rays_o,
-                                    float* __restrict__ rays_d) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const long long p = first + i;
+__device__ __forceinline__ void nm_make_ray(const NmCamera& cam, long long p, long long i, float* __restrict__ rays_o, float* __restrict__ rays_d) {
     const float y = (float)(p / cam.W), x = (float)(p - (p / cam.W) * cam.W);
     // x_lift = (x - cx + cy*sk/fy - sk*y/fy) / fx * z,  y_lift = (y - cy) / fy * z,  z = 1
     const float xl = nm_div(nm_sub(nm_add(nm_sub(x, cam.cx), nm_div(nm_mul(cam.cy, cam.sk), cam.fy)), nm_div(nm_mul(cam.sk, y), cam.fy)), cam.fx);
@@ -983,6 +979,22 @@ __global__ void nm_make_rays_kernel(NmCamera cam, long long first, long long cou
         rays_d[3 * i + a] = nm_add(nm_add(nm_mul(cam.r[4 * a], dx), nm_mul(cam.r[4 * a + 1], dy)), nm_mul(cam.r[4 * a + 2], dz));
         rays_o[3 * i + a] = cam.r[4 * a + 3];
     }
+}
+__global__ void nm_make_rays_kernel(NmCamera cam, long long first, long long count, float* __restrict__ rays_o,
+                                    float* __restrict__ rays_d) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    nm_make_ray(cam, first + i, i, rays_o, rays_d);
+}
+// pixel list instead of a pixel range (a rank's interleaved tiles of a sharded frame, a training step's random pixels)
+__global__ void nm_make_rays_indexed_kernel(NmCamera cam, const long long* __restrict__ pixels, long long count, float* __restrict__ rays_o,
+                                            float* __restrict__ rays_d) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    long long p = pixels[i];
+    const long long np = (long long)cam.H * cam.W;
+    p = p < 0 ? 0 : (p >= np ? np - 1 : p);   // (the host checks nothing on the device: out-of-frame entries are clamped)
+    nm_make_ray(cam, p, i, rays_o, rays_d);
 }
 
 // ------------------------------------------------------------------------------- image assembly (render.py:183-184, 219-249)

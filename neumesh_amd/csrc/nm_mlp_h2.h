@@ -1,9 +1,23 @@
-// nm_mlp_h2.h -- fused embed + MLP kernels on the f16 matrix pipe with split-half operands
-// (precision mode 2, the default).  Same arithmetic model as nm_mlp_f16.h (every fp32 value carried
-// as h1 + h2 * 2^-11, three f16 MFMAs per fp32 product, fp32 accumulation) with the data flow
-// re-cut around what the phase stamps of that kernel showed (matrix pipe 46 % busy,
-// the rest spent in 2-byte LDS stores, a 14 k-cycle input phase and a separate output projection):
+// nm_mlp_h2.h -- fused embed + MLP kernels on the f16 matrix pipe (v_mfma_f32_32x32x16_f16).
 //
+// Why not the fp32 MFMA: on gfx950 the fp32-input MFMA executes at the vector-FMA rate and does not overlap
+// VALU work (measured: 91-124 TFLOP/s of the 157), the f16 MFMA has 16x the rate and its own pipe.
+//
+// Split-half operands (NP = 3 products, the default, mlp_precision 2): every fp32 value a is carried as two
+// halves  a = h1 + h2 * 2^-11,  h1 = rne16(a), h2 = rne16((a - h1) * 2^11)  -- 22 significant bits, error
+// <= 2^-22 |a| (fp32: 2^-24) -- and a product as  a*b = h1a*h1b + 2^-11 (h1a*h2b + h2a*h1b)  (+ h2a*h2b*2^-22,
+// dropped): 3 f16 MFMAs with fp32 accumulation in two accumulators (main / 2^11-scaled), recombined in the
+// epilogue.  The two halves occupy exactly the 4 bytes of the fp32 value, so the LDS tile (64 rows x 256
+// columns) and the packed weights keep their size; activations are split ONCE, by the epilogue that produces them.
+// Range: |values| must stay below 65504 (fp16); fp16 subnormals are exact on the matrix pipe (tools/mfma_denorm.hip).
+//
+// Single product (NP = 1, mlp_precision 4, never the default): only h1a*h1b -- plain fp16 operands (11 significant
+// bits) with fp32 accumulation, one MFMA per product.  This is the "bf16 MLP"-class mode BASELINE configs[1] names
+// (fp16 keeps 3 more mantissa bits than bf16 at the same matrix rate); it does NOT meet the 1e-4 RGB bound and is
+// reported with its measured error beside the default (bench.py `f16_single`).
+//
+// Data flow (v2; what the phase stamps of the first layout showed -- matrix pipe 46 % busy, the rest in 2-byte LDS
+// stores, a 14 k-cycle input phase and a separate output projection):
 //  * The MFMA operands are swapped: D = W_tile (32 output columns x 16 k) * A^T (16 k x 32 points).
 //    The 32x32 result layout then gives a lane ONE point and 16 output columns, and the weight rows
 //    of a column tile are packed in the order that makes those 16 columns CONSECUTIVE
@@ -30,10 +44,49 @@
 // Reference semantics: models/frameworks/neumesh/neumesh.py:204-260, models/base.py:52-70 (see nm_mlp.h).
 #pragma once
 
-#include "nm_mlp_f16.h"
+#include "nm_mlp.h"
 
+typedef _Float16 nm_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 nm_h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 nm_h2 __attribute__((ext_vector_type(2)));
+
+#define NM_H_STRIDE 264  // halves per tile row: 528 B = 33 16-byte slots -> conflict-free ds_read_b128
+#define NM_H_PLANE (NM_ROWS * NM_H_STRIDE)
+#ifndef NM_EXP_LDS_PAD
+#define NM_EXP_LDS_PAD 0  // experiments: extra LDS halves per workgroup (forces 1 workgroup per CU)
+#endif
+
+struct NmLayerH {
+    const _Float16* W;  // packed fragments: [col tile 8][k-step Kpad/16][plane 2][lane 64][8 halves]
+    const float* b;     // [256] fp32
+    int Kpad;
+};
+
+// a -> (h1, h2): a ~= h1 + h2 / 2048.  fp16 subnormals are fine on both sides: v_cvt_f16_f32 produces
+// them and the matrix pipe consumes them exactly (probe: tools/mfma_denorm.hip on gfx950).
+__device__ __forceinline__ void nm_split_half(float a, _Float16* h1, _Float16* h2) {
+    const _Float16 p = (_Float16)a;
+    *h1 = p;
+    *h2 = (_Float16)((a - (float)p) * 2048.0f);
+}
+
+// Work split inside a workgroup (64 activation rows x 256 output columns per layer): a wave owns all
+// 64 rows of CT 32-column tiles, so there are 8/CT waves.  CT = 2: 256 threads, two workgroups per CU
+// = 2 waves per SIMD.  CT = 1 (512 threads, 4 waves per SIMD, half the accumulators per wave) was
+// measured slower (every wave re-reads the whole A tile from LDS, four waves share one matrix pipe).
+#define NM_H_CT 2
+#define NM_H_THREADS (64 * 8 / NM_H_CT)
+#define NM_H_WAVES_PER_SIMD (4 / NM_H_CT)  // two workgroups per CU (LDS: 2 x 68 KiB)
+
+// B operand (weights) of one k-step for the CT column tiles of a wave: 2*CT x 16 bytes per lane.
+template <int CT>
+struct NmBFrag {
+    nm_h8 a[CT], b[CT];  // plane h1, plane h2
+};
+template <int CT>
+struct NmAccH {  // 2 row tiles x CT column tiles of a wave, main and 2^11-scaled accumulators
+    nm_f32x16 hi[2][CT], lo[2][CT];
+};
 
 #ifndef NM_H2_DEPTH0
 #define NM_H2_DEPTH0 2   // layer-0 B-fragment prefetch distance of the tangent kernel (<= NM_H2_PRE)
@@ -161,6 +214,16 @@ __device__ __forceinline__ void nm_h2_store8(_Float16* p, const float (&v)[8], f
     *reinterpret_cast<uint4*>(p) = a;
     *reinterpret_cast<uint4*>(p + PLANE) = b;
 }
+__device__ __forceinline__ void nm_h1_store8(_Float16* p, const float (&v)[8], float& mx) {  // main plane only (single-product mode)
+    uint4 a;
+    a.x = __builtin_bit_cast(unsigned, nm_h2{(_Float16)v[0], (_Float16)v[1]});
+    a.y = __builtin_bit_cast(unsigned, nm_h2{(_Float16)v[2], (_Float16)v[3]});
+    a.z = __builtin_bit_cast(unsigned, nm_h2{(_Float16)v[4], (_Float16)v[5]});
+    a.w = __builtin_bit_cast(unsigned, nm_h2{(_Float16)v[6], (_Float16)v[7]});
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) mx = fmaxf(fmaxf(mx, fabsf(v[e])), fabsf(v[e + 1]));
+    *reinterpret_cast<uint4*>(p) = a;
+}
 // zero columns [c0, c1) of a tile row, both planes (c0 a multiple of 8: 16-byte stores, then singles)
 template <int PLANE = NM_H_PLANE>
 __device__ __forceinline__ void nm_h2_zero_cols(_Float16* row, int c0, int c1, int j) {
@@ -241,10 +304,12 @@ __device__ __forceinline__ float nm_softplus_l2(float zp, float* grad) {
 #define NM_H2_MFMAS(A, F, R1)                                                                             \
     _Pragma("unroll") for (int rt_ = 0; rt_ < (R1); ++rt_) _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_)  \
         c.hi[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[c_], A[rt_][0], c.hi[rt_][c_], 0, 0, 0);   \
+    if (NP == 3) {                                                                                                \
     _Pragma("unroll") for (int rt_ = 0; rt_ < (R1); ++rt_) _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_)  \
         c.lo[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.b[c_], A[rt_][0], c.lo[rt_][c_], 0, 0, 0);   \
     _Pragma("unroll") for (int rt_ = 0; rt_ < (R1); ++rt_) _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_)  \
-        c.lo[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[c_], A[rt_][1], c.lo[rt_][c_], 0, 0, 0);
+        c.lo[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[c_], A[rt_][1], c.lo[rt_][c_], 0, 0, 0);   \
+    }
 
 // B (weight) fragments are fetched with raw buffer loads: the (layer, column tile) block is a buffer
 // resource in 4 SGPRs, the lane contributes a constant 32-bit byte offset (lane * 16) and the k-step /
@@ -256,13 +321,14 @@ __device__ __forceinline__ nm_rsrc nm_b_rsrc(const _Float16* W, int Kpad, int ct
     const _Float16* p = W + (size_t)ctile_uniform * (Kpad >> 4) * 2 * 64 * 8;
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (Kpad >> 4) * 2048, 0x00020000);
 }
-template <int CT>
+template <int CT, int NP>
 __device__ __forceinline__ NmBFrag<CT> nm_ld_bu(const nm_rsrc (&ub)[CT], int lane, int ks) {
     NmBFrag<CT> f;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         f.a[c] = __builtin_bit_cast(nm_h8, __builtin_amdgcn_raw_buffer_load_b128(ub[c], lane * 16, ks * 2048, 0));
-        f.b[c] = __builtin_bit_cast(nm_h8, __builtin_amdgcn_raw_buffer_load_b128(ub[c], lane * 16, ks * 2048 + 1024, 0));
+        if (NP == 3) f.b[c] = __builtin_bit_cast(nm_h8, __builtin_amdgcn_raw_buffer_load_b128(ub[c], lane * 16, ks * 2048 + 1024, 0));
+        else f.b[c] = nm_h8{0, 0, 0, 0, 0, 0, 0, 0};   // (single-product mode: the residual plane is never read)
     }
     return f;
 }
@@ -274,7 +340,7 @@ struct NmBPre {
 // DEPTH: how many k-steps ahead the B fragments are requested (DEPTH + 1 rotating register sets, the first
 // DEPTH arrive pre-loaded in `pre`): 2 everywhere.  (A distance of 4 in layer 0 of the tangent kernel, whose
 // row-tile-1 accumulators only start their life at k-step KT0, was measured slower.)
-template <int KS, int CT, int KT0, int DEPTH>
+template <int KS, int CT, int KT0, int DEPTH, int NP>
 __device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16* a1p, const nm_rsrc (&bp)[CT], const int lane,
                                             const NmBPre<CT>& pre, NmAccH<CT>& c) {
     NmBFrag<CT> f[DEPTH + 1];
@@ -282,10 +348,10 @@ __device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16*
     for (int i = 0; i < DEPTH; ++i) f[i] = pre.s[i];
     nm_h8 a[2][2][2];  // [buffer][row tile][plane]
     a[0][0][0] = *reinterpret_cast<const nm_h8*>(a0p);
-    a[0][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
+    if (NP == 3) a[0][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
     if (KT0 == 0) {
         a[0][1][0] = *reinterpret_cast<const nm_h8*>(a1p);
-        a[0][1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE);
+        if (NP == 3) a[0][1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE);
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -294,14 +360,14 @@ __device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16*
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) c.hi[1][ct] = c.lo[1][ct] = nm_f32x16{0};
         }
-        if (ks + DEPTH < KS) f[(ks + DEPTH) % (DEPTH + 1)] = nm_ld_bu<CT>(bp, lane, ks + DEPTH);
+        if (ks + DEPTH < KS) f[(ks + DEPTH) % (DEPTH + 1)] = nm_ld_bu<CT, NP>(bp, lane, ks + DEPTH);
         if (ks + 1 < KS) {
             const int oa = (ks + 1) * 16;
             a[(ks + 1) & 1][0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
-            a[(ks + 1) & 1][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
+            if (NP == 3) a[(ks + 1) & 1][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
             if (ks + 1 >= KT0) {
                 a[(ks + 1) & 1][1][0] = *reinterpret_cast<const nm_h8*>(a1p + oa);
-                a[(ks + 1) & 1][1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE + oa);
+                if (NP == 3) a[(ks + 1) & 1][1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE + oa);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -313,7 +379,7 @@ __device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16*
     }
     __builtin_amdgcn_sched_barrier(0);
 }
-template <int CT>
+template <int CT, int NP>
 __device__ __forceinline__ void nm_prefetch_bn(const NmLayerH L, NmBPre<CT>& pre, int n) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     nm_rsrc bp[CT];
@@ -321,12 +387,12 @@ __device__ __forceinline__ void nm_prefetch_bn(const NmLayerH L, NmBPre<CT>& pre
     for (int c = 0; c < CT; ++c) bp[c] = nm_b_rsrc(L.W, L.Kpad, wave * CT + c);
 #pragma unroll
     for (int i = 0; i < NM_H2_PRE; ++i)
-        if (i < n) pre.s[i] = nm_ld_bu<CT>(bp, lane, i);  // (every layer has >= 2 k-steps; layer 0 of any supported configuration >= 4)
+        if (i < n) pre.s[i] = nm_ld_bu<CT, NP>(bp, lane, i);  // (every layer has >= 2 k-steps; layer 0 of any supported configuration >= 4)
 }
 
 // any other layer-0 width (run-time k-step counts): rolled loops, fragments one step ahead; k-steps
 // [0, kt0) without row tile 1, then [kt0, KS) with it
-template <int CT>
+template <int CT, int NP>
 __device__ __forceinline__ void nm_kloop_h2_generic(int KS, int kt0, const _Float16* a0p, const _Float16* a1p,
                                                     const nm_rsrc (&bp)[CT], const int lane, const NmBPre<CT>& pre, NmAccH<CT>& c) {
     NmBFrag<CT> nf = pre.s[0];
@@ -341,7 +407,7 @@ __device__ __forceinline__ void nm_kloop_h2_generic(int KS, int kt0, const _Floa
         nm_h8 A[2][2];
         A[0][0] = na[0][0]; A[0][1] = na[0][1]; A[1][0] = na[1][0]; A[1][1] = na[1][1];
         if (ks + 1 < KS) {
-            nf = nm_ld_bu<CT>(bp, lane, ks + 1);
+            nf = nm_ld_bu<CT, NP>(bp, lane, ks + 1);
             const int oa = (ks + 1) * 16;
             na[0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
             na[0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
@@ -355,7 +421,7 @@ __device__ __forceinline__ void nm_kloop_h2_generic(int KS, int kt0, const _Floa
         nm_h8 A[2][2];
         A[0][0] = na[0][0]; A[0][1] = na[0][1]; A[1][0] = na[1][0]; A[1][1] = na[1][1];
         if (ks + 1 < KS) {
-            nf = nm_ld_bu<CT>(bp, lane, ks + 1);
+            nf = nm_ld_bu<CT, NP>(bp, lane, ks + 1);
             const int oa = (ks + 1) * 16;
             na[0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
             na[0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
@@ -376,7 +442,7 @@ __device__ __forceinline__ void nm_kloop_h2_generic(int KS, int kt0, const _Floa
 //   (non-zero only in layer 0 of the tangent kernel); KSF = 0: run-time counts (L.Kpad, kt0), rolled loops.
 //   DEPTH: B-fragment prefetch distance of this layer's K loop = number of sets `pre` holds on entry; on exit
 //   `pre` holds the first two sets of `next` (requested before the epilogue so that they arrive while it runs).
-template <int ACT, bool TANGENT, bool LAST, int NOUT, int CT, int KSF, int KT0F, int DEPTH>
+template <int ACT, bool TANGENT, bool LAST, int NOUT, int CT, int KSF, int KT0F, int DEPTH, int NP>
 __device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L, const int kt0, const bool has_next, const NmLayerH next,
                                                 NmBPre<CT>& pre, const float* cst, const int bias_row, const float* head_w,
                                                 float* red, float& mx, int stamp_slot) {
@@ -415,9 +481,9 @@ __device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L
             c.lo[1][ct] = nm_f32x16{0};
         }
     }
-    if (KSF > 0) nm_kloop_h2<(KSF > 0 ? KSF : 1), CT, KT0F, DEPTH>(a0p, a1p, bp, lane, pre, c);  // one straight-line loop, no run-time dispatch
-    else nm_kloop_h2_generic<CT>(L.Kpad >> 4, kt0, a0p, a1p, bp, lane, pre, c);
-    if (has_next) nm_prefetch_bn<CT>(next, pre, 2);
+    if (KSF > 0) nm_kloop_h2<(KSF > 0 ? KSF : 1), CT, KT0F, DEPTH, NP>(a0p, a1p, bp, lane, pre, c);  // one straight-line loop, no run-time dispatch
+    else nm_kloop_h2_generic<CT, NP>(L.Kpad >> 4, kt0, a0p, a1p, bp, lane, pre, c);
+    if (has_next) nm_prefetch_bn<CT, NP>(next, pre, 2);
     if (!LAST) __syncthreads();  // every wave has finished reading the input tile
     nm_phase_stamp(stamp_slot);
     const float sc = 1.0f / 2048.0f;
@@ -432,8 +498,8 @@ __device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L
             float y0[8], y1[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                const float z0 = fmaf(c.lo[0][ct][8 * hf + r], sc, c.hi[0][ct][8 * hf + r]);  // (bias: in the accumulator)
-                const float z1 = fmaf(c.lo[1][ct][8 * hf + r], sc, c.hi[1][ct][8 * hf + r]);
+                const float z0 = NP == 3 ? fmaf(c.lo[0][ct][8 * hf + r], sc, c.hi[0][ct][8 * hf + r]) : c.hi[0][ct][8 * hf + r];  // (bias: in the accumulator)
+                const float z1 = NP == 3 ? fmaf(c.lo[1][ct][8 * hf + r], sc, c.hi[1][ct][8 * hf + r]) : c.hi[1][ct][8 * hf + r];
                 if (TANGENT) {
                     float g0;
                     if (ACT == 0) {
@@ -454,8 +520,13 @@ __device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L
                 }
             }
             if (!LAST) {
-                nm_h2_store8(tile + li * NM_H_STRIDE + col0, y0, mx);
-                nm_h2_store8(tile + (32 + li) * NM_H_STRIDE + col0, y1, mx);
+                if (NP == 3) {
+                    nm_h2_store8(tile + li * NM_H_STRIDE + col0, y0, mx);
+                    nm_h2_store8(tile + (32 + li) * NM_H_STRIDE + col0, y1, mx);
+                } else {   // single product: the main halves only
+                    nm_h1_store8(tile + li * NM_H_STRIDE + col0, y0, mx);
+                    nm_h1_store8(tile + (32 + li) * NM_H_STRIDE + col0, y1, mx);
+                }
             } else {
 #pragma unroll
                 for (int o = 0; o < NOUT; ++o) {
@@ -498,7 +569,7 @@ __device__ __forceinline__ void nm_h2_raise(int* overflow, float mx) {
 
 // ------------------------------------------------------------------ geometry MLP (split-half, v2)
 // Same contract as nm_geo_mlp_h_kernel.  FIXED: gdim = 32, multires_fg = 2, multires_d = 8 (Kpad0 = 192).
-template <bool NABLA, bool FIXED>
+template <bool NABLA, bool FIXED, int NP>
 __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_h2_kernel(
     NmGeoParamsH2 prm, const float* __restrict__ fg_rec, const float* __restrict__ ds, const float* __restrict__ grad, NmRecMap rmap,
     long long npts, float* __restrict__ sdf_out, int P, int stride, int off, float* __restrict__ nabla_out, int nabla_slotted,
@@ -532,7 +603,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
     nm_phase_stamp(0);
     constexpr int DEPTH0 = (FIXED && NABLA) ? NM_H2_DEPTH0 : 2;  // layer-0 prefetch distance (nm_kloop_h2); the rolled loops use one set
     NmBPre<NM_H_CT> pre;
-    nm_prefetch_bn<NM_H_CT>(prm.layer[0], pre, DEPTH0);  // in flight during the input phase
+    nm_prefetch_bn<NM_H_CT, NP>(prm.layer[0], pre, DEPTH0);  // in flight during the input phase
     const int gdim = FIXED ? 32 : prm.gdim, mfg = FIXED ? 2 : prm.multires_fg, md = FIXED ? 8 : prm.multires_d;
     const int FG = FIXED ? 160 : prm.fg_w, in_dim = FG + 2 * md + 1;
     const int Kpad0 = FIXED ? 192 : prm.layer[0].Kpad;
@@ -639,14 +710,14 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
     constexpr int KS0 = FIXED ? 12 : 0, KT0 = (FIXED && NABLA) ? 10 : 0;
     const float* head = cst + NM_H2_BIAS_LAYERS * NM_W;
     if (prm.D == 1) {
-        nm_mlp_layer_h2<0, NABLA, true, 1, NM_H_CT, KS0, KT0, DEPTH0>(tile, prm.layer[0], kt0, false, prm.layer[0], pre, cst, 0, head, red, mx, 2);
+        nm_mlp_layer_h2<0, NABLA, true, 1, NM_H_CT, KS0, KT0, DEPTH0, NP>(tile, prm.layer[0], kt0, false, prm.layer[0], pre, cst, 0, head, red, mx, 2);
     } else {
-        nm_mlp_layer_h2<0, NABLA, false, 1, NM_H_CT, KS0, KT0, DEPTH0>(tile, prm.layer[0], kt0, true, prm.layer[1], pre, cst, 0, nullptr, red, mx, 2);
+        nm_mlp_layer_h2<0, NABLA, false, 1, NM_H_CT, KS0, KT0, DEPTH0, NP>(tile, prm.layer[0], kt0, true, prm.layer[1], pre, cst, 0, nullptr, red, mx, 2);
         for (int l = 1; l + 1 < prm.D; ++l)
-            nm_mlp_layer_h2<0, NABLA, false, 1, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre,
+            nm_mlp_layer_h2<0, NABLA, false, 1, NM_H_CT, 16, 0, 2, NP>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre,
                                                                     cst, l < NM_H2_BIAS_LAYERS ? l : -1, nullptr, red, mx, 2 + 2 * l);
         const int l = prm.D - 1;
-        nm_mlp_layer_h2<0, NABLA, true, 1, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, false, prm.layer[l], pre,
+        nm_mlp_layer_h2<0, NABLA, true, 1, NM_H_CT, 16, 0, 2, NP>(tile, prm.layer[l], 0, false, prm.layer[l], pre,
                                                                cst, l < NM_H2_BIAS_LAYERS ? l : -1, head, red, mx, 2 + 2 * l);
     }
     if (threadIdx.x < PTS) {
@@ -673,7 +744,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
 // ------------------------------------------------------------------ colour MLP (split-half, v2)
 // Physical input columns: [ft embedding | (sin, cos) pairs of ds | view bands | view | nabla | ds].
 // FIXED: cdim = 32, multires_ft = 2, multires_d = 8, multires_view = 4, nabla input (207 -> Kpad0 = 208).
-template <bool FIXED>
+template <bool FIXED, int NP>
 __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_h2_kernel(
     NmColParamsH2 prm, const float* __restrict__ ft_rec, const float* __restrict__ ds, const float* __restrict__ nabla,
     const float* __restrict__ dirs, int dir_div, long long npts, float* __restrict__ rgb_out, NmSlotMap smap, int* __restrict__ overflow) {
@@ -687,7 +758,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
     nm_phase_stamp(0);
     constexpr int DEPTH0 = 2;
     NmBPre<NM_H_CT> pre;
-    nm_prefetch_bn<NM_H_CT>(prm.layer[0], pre, DEPTH0);  // in flight during the input phase
+    nm_prefetch_bn<NM_H_CT, NP>(prm.layer[0], pre, DEPTH0);  // in flight during the input phase
     const int cdim = FIXED ? 32 : prm.cdim, mft = FIXED ? 2 : prm.multires_ft, md = FIXED ? 8 : prm.multires_d;
     const int mv = FIXED ? 4 : prm.multires_view, use_nabla = FIXED ? 1 : prm.use_nabla;
     const int FT = FIXED ? 160 : prm.ft_w;
@@ -776,14 +847,14 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
     constexpr int KS0 = FIXED ? 13 : 0;
     const float* head = cst + NM_H2_BIAS_LAYERS * NM_W;
     if (prm.D == 1) {
-        nm_mlp_layer_h2<1, false, true, 3, NM_H_CT, KS0, 0, 2>(tile, prm.layer[0], 0, false, prm.layer[0], pre, cst, 0, head, red, mx, 2);
+        nm_mlp_layer_h2<1, false, true, 3, NM_H_CT, KS0, 0, 2, NP>(tile, prm.layer[0], 0, false, prm.layer[0], pre, cst, 0, head, red, mx, 2);
     } else {
-        nm_mlp_layer_h2<1, false, false, 3, NM_H_CT, KS0, 0, 2>(tile, prm.layer[0], 0, true, prm.layer[1], pre, cst, 0, nullptr, red, mx, 2);
+        nm_mlp_layer_h2<1, false, false, 3, NM_H_CT, KS0, 0, 2, NP>(tile, prm.layer[0], 0, true, prm.layer[1], pre, cst, 0, nullptr, red, mx, 2);
         for (int l = 1; l + 1 < prm.D; ++l)
-            nm_mlp_layer_h2<1, false, false, 3, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre,
+            nm_mlp_layer_h2<1, false, false, 3, NM_H_CT, 16, 0, 2, NP>(tile, prm.layer[l], 0, true, prm.layer[l + 1], pre,
                                                                     cst, l < NM_H2_BIAS_LAYERS ? l : -1, nullptr, red, mx, 2 + 2 * l);
         const int l = prm.D - 1;
-        nm_mlp_layer_h2<1, false, true, 3, NM_H_CT, 16, 0, 2>(tile, prm.layer[l], 0, false, prm.layer[l], pre,
+        nm_mlp_layer_h2<1, false, true, 3, NM_H_CT, 16, 0, 2, NP>(tile, prm.layer[l], 0, false, prm.layer[l], pre,
                                                                cst, l < NM_H2_BIAS_LAYERS ? l : -1, head, red, mx, 2 + 2 * l);
     }
     if (threadIdx.x < NM_ROWS) {  // one thread per point: its three channels are one 12-byte store

@@ -52,8 +52,9 @@ def get_embedder(multires: int, input_dim: int = 3):
     return e, e.out_dim
 
 
-# mlp_precision -> nm_field_desc.mlp_precision ("f16x2_v1": the first split-half kernels, kept for A/B runs)
-_PRECISION_CODES = {"fp32": 0, "f16x2_v1": 1, "f16x2": 2, "f16x2_v3": 3}
+# mlp_precision -> nm_field_desc.mlp_precision.  "f16" = ONE f16 MFMA per product (plain fp16 operands, fp32 accumulation):
+# the reduced-precision mode BASELINE configs[1] calls "bf16 MLP"; it misses the 1e-4 RGB bound and is never a default
+_PRECISION_CODES = {"fp32": 0, "f16x2": 2, "f16": 4}
 
 
 def interpolation(features, indices, weights):
@@ -150,8 +151,8 @@ class NeuMesh(nn.Module):
                          multires_view=multires_view)
         # MLP arithmetic of the fused HIP path: "f16x2" (default: split-half f16 MFMA -- every operand
         # carried as two fp16 halves = 22 bits, fp32 accumulation; measured as accurate as the fp32
-        # form against the reference, 2.1-2.4x faster; needs |activations| < 65504) or "fp32"
-        # (fp32-input MFMA).
+        # form against the reference, 2.1-2.4x faster; needs |activations| < 65504), "fp32"
+        # (fp32-input MFMA) or "f16" (single f16 product: reduced precision, error-quantified in bench.py).
         self.mlp_precision = os.environ.get("NEUMESH_MLP_PRECISION", "f16x2")
         self._field = None        # nm_field_t
         self._field_key = None    # parameter versions / device / precision the packed weights were built from

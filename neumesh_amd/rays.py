@@ -38,6 +38,22 @@ def make_rays(c2w, intrinsics, H, W, device, first_pixel=0, count=None):
     return ro, rd
 
 
+def make_rays_indexed(c2w, intrinsics, H, W, pixels: torch.Tensor):
+    """Rays of the row-major pixel indices `pixels` (int64 tensor on a HIP device) -> (rays_o [n,3], rays_d [n,3])."""
+    lib = _lib.load()
+    dev = pixels.device
+    if dev.type != "cuda":
+        raise _lib.NeuMeshHipError("make_rays_indexed: the pixel list must be on a HIP device (no CPU fallback)")
+    pix = pixels.reshape(-1).to(torch.int64).contiguous()
+    cam = _camera(torch.as_tensor(c2w), torch.as_tensor(intrinsics), H, W)
+    n = pix.shape[0]
+    ro = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    rd = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.nm_make_rays_indexed(C.byref(cam), _lib.ptr(pix), n, _lib.ptr(ro), _lib.ptr(rd), _lib.current_stream(dev)), "nm_make_rays_indexed")
+    return ro, rd
+
+
 def quat_to_rot(q):
     """utils/rend_util.py quaternion (w, x, y, z) -> rotation matrix."""
     q = torch.nn.functional.normalize(q, dim=-1)

@@ -4,10 +4,15 @@ per frame (a gather / all-gather of the final pixels) and nothing else.
 The reference has no multi-GPU inference path (its nn.DataParallel / DDP wrap training only,
 SURVEY.md section 2 rows 18-19); rays are independent (no cross-ray operation anywhere in
 models/renderer.py:162-350), so the mesh index, code tables and MLP weights (~40 MB) are
-replicated and rank g renders the contiguous pixel block [g*N/G, (g+1)*N/G).  The per-rank
-outputs rgb[3] + depth + acc (+ normals[3]) are packed into one [n, C] fp32 tensor so the
-frame costs a single RCCL all-gather of 20-32 B/ray over xGMI (point-to-point links: every peer
-is one hop, so no ring is needed).
+replicated.  A frame is cut into TILE x TILE pixel tiles dealt round-robin to the ranks
+(`tile_shard_pixels`): the cost of a ray depends on where it goes -- rays that miss the object walk
+all 256 near/far probes and then carry no mid-point work, rays through the surface the opposite --
+so contiguous bands of an image are unevenly loaded while every rank's share of interleaved 32 x 32
+tiles sees the same mix.  (`render_sharded`, for caller-supplied ray lists whose layout is unknown,
+keeps contiguous blocks.)  The per-rank outputs rgb[3] + depth + acc (+ normals[3]) are packed into one
+[n, C] fp32 tensor so the frame costs a single RCCL all-gather of 20-32 B/ray over xGMI (point-to-point
+links: every peer is one hop, so no ring is needed); every rank then scatters the rows to pixel order
+with the tile table it can compute by itself.
 """
 from __future__ import annotations
 
@@ -15,6 +20,8 @@ from typing import Callable, Dict, Tuple
 
 import torch
 import torch.distributed as dist
+
+TILE = 32   # pixels per tile edge: 625 tiles of an 800 x 800 frame, 1900 of 1600 x 1200
 
 _KEYS = (("rgb", 3), ("depth_volume", 1), ("mask_volume", 1), ("normals_volume", 3))
 
@@ -28,7 +35,7 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 
 def pack_outputs(ret: Dict[str, torch.Tensor]) -> Tuple[torch.Tensor, Tuple[str, ...]]:
     keys = tuple(k for k, _ in _KEYS if k in ret)
-    cols = [ret[k].reshape(ret[k].shape[0], -1).float() for k in keys]
+    cols = [ret[k].reshape(ret[k].shape[0], w).float() for k, w in _KEYS if k in ret]   # (explicit widths: a rank may hold 0 rays)
     return torch.cat(cols, dim=1).contiguous(), keys
 
 
@@ -79,22 +86,82 @@ def render_sharded(render_fn: Callable[[torch.Tensor, torch.Tensor], Dict[str, t
     return unpack_outputs(torch.cat(pieces, dim=0), keys)
 
 
-def render_frame_sharded(render_fn, c2w, intrinsics, H: int, W: int, device, group=None) -> Dict[str, torch.Tensor]:
-    """One frame of an H x W camera: every rank builds ONLY its own pixel block's rays on its own GPU
-    (nm_make_rays, no host->device ray traffic), renders it and all-gathers the pixels."""
-    from .rays import make_rays
+def tile_shard_pixels(H: int, W: int, rank: int, world: int, tile: int = TILE, device=None) -> torch.Tensor:
+    """Row-major pixel indices (int64) of the tiles rank `rank` owns: tiles are numbered row-major over the
+    ceil(H/tile) x ceil(W/tile) tile grid, tile t belongs to rank t % world; inside a tile pixels run row-major
+    (partial tiles at the right / bottom border simply hold fewer pixels).  The `world` lists partition range(H*W)."""
+    tiles_x, tiles_y = -(-W // tile), -(-H // tile)
+    if rank >= tiles_x * tiles_y:
+        return torch.empty((0,), dtype=torch.int64, device=device)
+    t = torch.arange(rank, tiles_x * tiles_y, world, device=device, dtype=torch.int64)
+    ty, tx = t // tiles_x, t % tiles_x
+    iy = torch.arange(tile, device=device, dtype=torch.int64)
+    py = (ty[:, None, None] * tile + iy[None, :, None]).expand(-1, tile, tile)
+    px = (tx[:, None, None] * tile + iy[None, None, :]).expand(-1, tile, tile)
+    ok = (py < H) & (px < W)
+    return (py * W + px)[ok]
+
+
+def pick_tile(H: int, W: int, world: int, tile: int = TILE) -> int:
+    """Tile edge for an H x W frame over `world` ranks: TILE, halved (down to 8 = one 64-ray wave's patch) until every rank
+    gets at least 16 tiles -- small frames would otherwise be dealt out unevenly."""
+    while tile > 8 and (-(-H // tile)) * (-(-W // tile)) < 16 * world:
+        tile //= 2
+    return tile
+
+
+_TABLES = {}
+
+
+def _frame_tables(H, W, world, tile, device):
+    """(per-rank pixel lists, padded rows per rank, scatter index of the gathered [world*per] rows -> pixel order)."""
+    key = (H, W, world, tile, str(device))
+    tab = _TABLES.get(key)
+    if tab is None:
+        lists = [tile_shard_pixels(H, W, r, world, tile, device) for r in range(world)]
+        per = max(int(p.shape[0]) for p in lists)
+        rows = torch.cat([r * per + torch.arange(p.shape[0], device=device, dtype=torch.int64) for r, p in enumerate(lists)])
+        pix = torch.cat(lists)
+        src = torch.empty(H * W, dtype=torch.int64, device=device)
+        src[pix] = rows                      # pixel p of the frame is row src[p] of the gathered buffer
+        if len(_TABLES) > 8:
+            _TABLES.clear()
+        tab = _TABLES[key] = (lists, per, src)
+    return tab
+
+
+def render_frame_sharded(render_fn, c2w, intrinsics, H: int, W: int, device, group=None, tile: int = None,
+                         timings: dict = None) -> Dict[str, torch.Tensor]:
+    """One frame of an H x W camera over the ranks of `group`: every rank builds ONLY the rays of its own interleaved
+    tiles on its own GPU (nm_make_rays_indexed, no host->device ray traffic), renders them with
+    `render_fn(rays_o, rays_d) -> dict` and all ranks end with the full frame in pixel order after ONE all-gather.
+    timings (optional dict): receives "render_ms" (this rank's render, host clock around a device sync) when given."""
+    from .rays import make_rays, make_rays_indexed
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    n = H * W
-    lo, hi = shard_range(n, rank, world)
-    ro, rd = make_rays(c2w, intrinsics, H, W, device, first_pixel=lo, count=hi - lo)
-    ret = render_fn(ro, rd)
     if world == 1:
-        return ret
+        ro, rd = make_rays(c2w, intrinsics, H, W, device)
+        return render_fn(ro, rd)
+    lists, per, src = _frame_tables(H, W, world, tile or pick_tile(H, W, world), torch.device(device))
+    mine = lists[rank]
+    ro, rd = make_rays_indexed(c2w, intrinsics, H, W, mine)
+    if timings is not None:
+        import time
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+    ret = render_fn(ro, rd)
+    if timings is not None:
+        torch.cuda.synchronize(device)
+        timings["render_ms"] = (time.perf_counter() - t0) * 1e3
+        timings["rays"] = int(mine.shape[0])
+    return gather_tiles(ret, per, src, world, group)
+
+
+def gather_tiles(ret: Dict[str, torch.Tensor], per: int, src: torch.Tensor, world: int, group=None) -> Dict[str, torch.Tensor]:
+    """This rank's per-ray outputs (in the order of its tile_shard_pixels list) -> the full frame in pixel order on
+    every rank: rows padded to `per`, ONE all-gather, one index_select with the `src` table of _frame_tables."""
     packed, keys = pack_outputs(ret)
-    per = -(-n // world)
     buf = torch.zeros((per, packed.shape[1]), dtype=torch.float32, device=packed.device)
-    buf[: hi - lo] = packed
+    buf[: packed.shape[0]] = packed
     full = _all_gather_rows(buf, world, group)
-    pieces = [full[r * per: r * per + (shard_range(n, r, world)[1] - shard_range(n, r, world)[0])] for r in range(world)]
-    return unpack_outputs(torch.cat(pieces, dim=0), keys)
+    return unpack_outputs(full[src], keys)

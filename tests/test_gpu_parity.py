@@ -164,7 +164,7 @@ def test_compute_distance_matches_reference(small, cuda_device, torch_mod):
     assert torch_mod.equal(ds, ds2)
 
 
-@pytest.mark.parametrize("precision", ["f16x2", "f16x2_v3", "f16x2_v1", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x2", "fp32"])
 def test_field_methods_match_reference(small, cuda_device, torch_mod, precision):
     torch = torch_mod
     _, _, model = small
@@ -257,7 +257,7 @@ def test_get_rays_kernel_matches_reference(cuda_device, torch_mod):
 
 
 # ----------------------------------------------------------------------------- renderer
-@pytest.mark.parametrize("precision", ["f16x2", "f16x2_v3", "f16x2_v1", "fp32"])
+@pytest.mark.parametrize("precision", ["f16x2", "fp32"])
 @pytest.mark.parametrize("tag", ["render_v3000_dtu", "render_v3000_lego"])
 def test_render_matches_reference_fixture(small, cuda_device, torch_mod, tag, precision):
     torch = torch_mod
@@ -461,29 +461,33 @@ def test_render_frame_properties_dtu_scale(dtu_scale, cuda_device, torch_mod):
 
 
 
-def test_render_headline_scale_pipelined_mlp_kernels(dtu_scale, cuda_device, torch_mod):
-    """mlp_precision 'f16x2_v3' (nm_mlp_h3.h: 128-row tiles, a pair's epilogue inside the other pair's K loop; the
-    colour kernel's 128-point tiles span two groups of the mid-point lists) on the headline fixture's rays: the
-    reference fixture's gates, and the default kernels' pixels up to the rounding of the 8-wave head reduction."""
+def test_single_product_f16_mode_is_reduced_precision_and_quantified(surf_scale, cuda_device, torch_mod):
+    """mlp_precision 'f16' (one f16 MFMA per product: the "bf16 MLP"-class mode of BASELINE configs[1]) on the surface
+    scene's fixture rays: finite, the same coverage classes, PSNR >= 30 dB against the reference -- and NOT within the
+    1e-4 RGB bound (s = 400 amplifies an 11-bit SDF), which is why it is never a default.  Prints the error it has."""
     torch = torch_mod
     from neumesh_amd.renderer import volume_render
-    mesh, state, model = dtu_scale
-    f = common.golden("render_v140k_dtu")
+    mesh, state, model = surf_scale
+    f = common.golden("render_v140k_surf")
     ro, rd = _t(f["rays_o"], cuda_device), _t(f["rays_d"], cuda_device)
     kw = dict(calc_normal=True, N_samples=64, N_importance=64, perturb=False, rayschunk=65536, detailed_output=False)
     try:
+        model.mlp_precision = "f16"
         with torch.no_grad():
-            rgb2, depth2, ex2 = volume_render(ro, rd, model, **kw)
-            model.mlp_precision = "f16x2_v3"
-            rgb3, depth3, ex3 = volume_render(ro, rd, model, **kw)
+            rgb, depth, ex = volume_render(ro, rd, model, **kw)
+        assert model.mlp_precision == "f16"      # (no fp16-range fallback happened)
     finally:
         model.mlp_precision = "f16x2"
-    err = np.abs(rgb3.cpu().numpy().reshape(-1, 3) - f["rgb"].reshape(-1, 3)).max(-1)
-    assert float(np.median(err)) <= 1e-6 and float((err > 1e-4).mean()) <= float((f["self_err_1ulp"] > 1e-4).mean()) + 0.01
-    d23 = (rgb3 - rgb2).abs().amax(-1).flatten().cpu().numpy()   # (the SDFs differ in the last bit, so a few rays may place a sample elsewhere)
-    assert float(np.median(d23)) <= 1e-6 and float((d23 > 1e-4).mean()) <= 0.01
-    dn = (ex3["normals_volume"] - ex2["normals_volume"]).abs().amax(-1).flatten().cpu().numpy()
-    assert float(np.median(dn)) <= 1e-5 and float((dn > 1e-3).mean()) <= 0.01
+    g = rgb.cpu().numpy().reshape(-1, 3)
+    assert np.isfinite(g).all()
+    err = np.abs(g - f["rgb"]).max(-1)
+    psnr = compare.psnr(g, f["rgb"])
+    print(f"single-product f16 MLP vs the reference: max |rgb| error {err.max():.2e}, median {np.median(err):.1e}, "
+          f"rays within 1e-4: {100 * (err <= 1e-4).mean():.1f} %, PSNR {psnr:.1f} dB")
+    assert psnr >= 30.0 and np.median(err) <= 2e-2
+    assert (err > 1e-4).mean() > 0.05, "the single-product mode unexpectedly meets the fp32 bound: report it as such"
+    acc = ex["mask_volume"].cpu().numpy().reshape(-1)
+    assert ((acc < 1e-3) == (f["mask_volume"] < 1e-3)).mean() >= 0.98
 
 
 def test_render_headline_scale_matches_reference_fixture(dtu_scale, cuda_device, torch_mod):

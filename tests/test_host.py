@@ -97,6 +97,17 @@ def fake_render(ro, rd):   # deterministic per-ray function standing in for the 
 full = render_sharded(fake_render, o, d)
 want = fake_render(o, d)
 ok = all(torch.equal(full[k], want[k]) for k in want)
+# tile-interleaved frame sharding (render_frame_sharded without the device ray set-up): each rank "renders" the pixels of
+# its own tiles, one all-gather, every rank ends with the frame in pixel order
+from neumesh_amd.sharded import _frame_tables, gather_tiles, pick_tile, tile_shard_pixels
+for (H, W) in ((37, 53), (64, 96), (5, 3)):
+    lists, per, src = _frame_tables(H, W, 2, pick_tile(H, W, 2), torch.device("cpu"))
+    mine = lists[dist.get_rank()]
+    assert torch.equal(torch.sort(torch.cat(lists))[0], torch.arange(H * W))
+    frame = gather_tiles(fake_render(o[mine % o.shape[0]] + mine[:, None], d[mine % o.shape[0]]), per, src, 2)
+    allp = torch.arange(H * W)
+    want_f = fake_render(o[allp % o.shape[0]] + allp[:, None], d[allp % o.shape[0]])
+    ok = ok and all(torch.equal(frame[k], want_f[k]) for k in want_f)
 print("RANK", dist.get_rank(), "OK" if ok else "MISMATCH", flush=True)
 dist.destroy_process_group()
 sys.exit(0 if ok else 1)

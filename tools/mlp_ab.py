@@ -30,7 +30,7 @@ names = {1: "geo_mlp (64 pts/wg)", 2: "geo_mlp+tangent (32 pts/wg)", 3: "colour_
 fx = common.golden("field_v3000")
 m3 = common.scene_mesh(3000)
 small = common.make_model(m3, common.scene_state(m3), dev)
-modes = [a for a in sys.argv[1:] if not a.startswith("--")] or ["f16x2_v1", "f16x2", "fp32"]
+modes = [a for a in sys.argv[1:] if not a.startswith("--")] or ["f16x2", "f16", "fp32"]
 for mode in modes:
     model.mlp_precision = small.mlp_precision = mode
     with torch.no_grad():

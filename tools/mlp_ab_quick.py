@@ -11,7 +11,7 @@ if os.environ.get("NM_QUICK_CHILD"):
     dev = torch.device("cuda", 0)
     lib = _lib.load()
     mesh, model = bench.build_scene(140000, dev)
-    model.mlp_precision = os.environ.get("NM_QUICK_MODE", "f16x2_v3")
+    model.mlp_precision = os.environ.get("NM_QUICK_MODE", "f16x2")
     P = 1 << 20
     rng = np.random.default_rng(0)
     x = torch.from_numpy((mesh.vertices[rng.integers(0, 140000, P)] + 0.02 * rng.standard_normal((P, 3))).astype(np.float32)).to(dev)
