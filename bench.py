@@ -9,13 +9,16 @@ uses the environment it is given.
 
 Workload (BASELINE.json configs[1], shape only -- there is no DTU data / checkpoint in the
 environment, SURVEY.md section 8d scene S-DTU): V = 140 000-vertex prior mesh, 32-d geometry /
-colour codes, W=256 MLPs (the default-init weight set of tests/golden/model_seed0.npz, i.e. the scene
-whose reference render is pinned by tests/golden/render_v140k_dtu.npz), s = 200; one STEP = one
-800x800 frame = 640 000 rays x (64 coarse + 64 importance) samples with bounded near/far (256
+colour codes, W=256 MLPs.  --scene surf (default): the weights of synthetic.surface_mlp_state -- a field
+WITH a surface (sdf = ds + a code-driven bump, s = 400; 23 % of the rays miss, 8 % graze, 59 % are opaque),
+the scene whose reference render is pinned by tests/golden/render_v140k_surf.npz; --scene noise: the
+default-initialised weights of rounds 1-2 (every ray opaque, s = 200; render_v140k_dtu.npz).  One STEP =
+one 800x800 frame = 640 000 rays x (64 coarse + 64 importance) samples with bounded near/far (256
 probes/ray) and normals, i.e. the kwargs get_model() hands render.py for
 configs/neumesh_dtu_scan63.yaml.  Rays are resident in HBM before the timed region.  With N GPUs
 every rank renders its own frame of the orbit per step (weak scaling: per-GPU work is fixed) and the
-final pixels are all-gathered over RCCL -- the only collective of the path.
+final pixels are all-gathered over RCCL -- the only collective of the path; --shard frame instead splits
+ONE frame per step over the ranks by interleaved 32x32 tiles (BASELINE configs[3]; strong scaling).
 
 Prints ONE JSON line (rank 0):
   value        rays/s of the whole job
@@ -24,8 +27,11 @@ Prints ONE JSON line (rank 0):
                pipe it runs on (frac); the issued-MFMA utilisation is a separate key
   cpu_baseline the CPU oracle (numpy + kd-tree K-NN) on a bounded ray sample of the same frame
   parity_vs_reference   the same frame's 1536 fixture rays against the imported reference's output
-  extra        short runs (2 steps each, N = 1 only) of the variants the headline does not show:
-               data-independent frame, fp32 MLP, calc_normal=False, BASELINE config 3 / 4 shapes, config 5
+  config       besides the workload: scalar results of short runs (2 steps each, N = 1 only) of the variants the
+               headline does not show -- data_independent_* (every probe and mid-point evaluated: the reference's
+               work), fp32_*, f16_single_* (one f16 MFMA per product, with its error against the reference fixture),
+               noise_scene_*, config5_* -- kept as scalars because the driver's record keeps scalars
+  extra        the same runs in full + calc_normal=False, BASELINE config 3 / 4 shapes, the SURVEY 8f consumer rows
 """
 from __future__ import annotations
 
@@ -49,7 +55,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 PEAK_HBM_GBS = 8000.0
 KNN_BYTES_PER_QUERY = 76    # 12 in + 8*4 idx + 8*4 w  
-PROFILE_TAG = "r02"         # profiles/<tag>_pmc_*.json: rocprofv3 --pmc passes of this command (tools/pmc_*.py)
+PROFILE_TAG = "r03"         # profiles/<tag>_pmc_*.json: rocprofv3 --pmc passes of this command (tools/pmc_*.py)
 
 MODEL_CFG = dict(D_density=3, D_color=4, W=256, geometry_dim=32, color_dim=32, multires_view=4, multires_d=8,
                  multires_fg=2, multires_ft=2, enable_nablas_input=True, speed_factor=10.0, learn_indicator_weight=False)
@@ -99,6 +105,36 @@ def frame_rays(frame, H, W):
     return synthetic.camera_rays(synthetic.orbit_pose(frame), synthetic.pinhole_intrinsics(H, W), H, W)
 
 
+def reference_baseline(mesh, model, H, W, n_rays, rays0, samples=128, white_bkgd=False, calc_normal=True):
+    """The REFERENCE's own CPU PyTorch path (kind "reference") on a strided sample of frame 0's rays: the imported
+    reference (oracle/refimport: /root/reference behind stub modules, FRNN replaced by the kd-tree + declared-arithmetic
+    K-NN) with this scene's weights, torch threads = host cores.  Only where the reference tree exists (the build
+    container; never on the GPU box).  Returns (baseline dict, rgb of the sample, ray indices)."""
+    import torch
+    from scipy.spatial import cKDTree
+    from oracle import knn as oknn
+    from oracle.refimport import harness
+    state = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    mlp = {k: v for k, v in state.items() if k not in ("geometry_features", "color_features", "indicator_vector")}
+    ref_model, kw, renderer, _ = harness.build_reference(mesh, seed=0, mlp_state=mlp, s_value=float(model.forward_s()))
+    import frnn as frnn_stub
+    tree = cKDTree(mesh.vertices.astype(np.float64))
+    frnn_stub.KNN_FN[0] = lambda q, v, K: oknn.knn_kdtree(q, v, K, tree=tree)
+    o, d = rays0
+    sel = np.linspace(0, H * W - 1, n_rays).astype(np.int64)
+    kw = dict(kw)
+    kw.update(rayschunk=n_rays, calc_normal=calc_normal, N_samples=samples // 2, N_importance=samples // 2, perturb=False, white_bkgd=white_bkgd)
+    with torch.no_grad():
+        renderer(torch.from_numpy(o[sel[:8]])[None], torch.from_numpy(d[sel[:8]])[None], detailed_output=False, **dict(kw, rayschunk=8))
+        t = time.perf_counter()
+        rgb, _, _ = renderer(torch.from_numpy(o[sel])[None], torch.from_numpy(d[sel])[None], detailed_output=False, **kw)
+        dt = time.perf_counter() - t
+    res = {"value": n_rays / dt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "reference",
+           "sample": f"{n_rays} rays strided over frame 0 of the same {H}x{W}x{samples} workload, {dt:.1f} s; the imported reference "
+                     f"(models/renderer.py + neumesh.py on CPU torch, {torch.get_num_threads()} threads; FRNN stand-in: scipy cKDTree + declared fp32 re-rank)"}
+    return res, rgb[0].numpy(), sel
+
+
 def cpu_baseline(mesh, model, H, W, n_rays, rays0, samples=128, white_bkgd=False, calc_normal=True):
     """Oracle (CPU restatement of the reference, kind "port") on a strided sample of frame 0's rays.
     Returns (baseline dict, oracle rgb of the sample, ray indices)."""
@@ -119,7 +155,8 @@ def cpu_baseline(mesh, model, H, W, n_rays, rays0, samples=128, white_bkgd=False
            "sample": f"{n_rays} rays strided over frame 0 of the same {H}x{W}x{samples} workload, {dt:.1f} s; numpy fp32 oracle + "
                      f"scipy cKDTree candidates re-ranked with the declared fp32 arithmetic (BLAS/OpenMP threads = all cores; the same oracle as one "
                      f"single-threaded process per core reached 298 rays/s on 256 x 256 rays and 47 rays/s on 256 x 22 rays on this box type: it does not scale, so the one-process figure stands); "
-                     f"the imported reference itself did 108 rays/s on 8 cores in the build container (oracle/gen_golden.py scale)"}
+                     f"the imported REFERENCE itself (kind 'reference', used automatically where /root/reference exists) did 103 rays/s on this scene "
+                     f"on the 8 cores of the build container (oracle/gen_golden.py surf; tests/golden/REPORT.json)"}
     return res, out["rgb"], sel
 
 
@@ -312,7 +349,7 @@ def stress5_run(args, dev, world, rank, steps, warmup):
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else torch.device("cpu"))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms, n, u = C.c_double(), C.c_int64(), C.c_int64()
@@ -369,8 +406,9 @@ def main():
     ap.add_argument("--V", type=int, default=140_000)
     ap.add_argument("--rayschunk", type=int, default=0,
                     help="rays per nm_render_rays call; 0 = the whole frame in one call (56 KB of workspace per ray: 36 GB for 800x800)")
-    ap.add_argument("--mlp-precision", choices=["f16x2", "f16x2_v1", "fp32"], default="f16x2",
-                    help="MLP arithmetic: split-half f16 MFMA (default; 22-bit operands, fp32 accumulation) or fp32 MFMA")
+    ap.add_argument("--mlp-precision", choices=["f16x2", "f16", "fp32"], default="f16x2",
+                    help="MLP arithmetic: split-half f16 MFMA (default; 22-bit operands, fp32 accumulation), single-product f16 MFMA "
+                         "(reduced precision, error-quantified) or fp32 MFMA")
     ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU-baseline sample (0 disables)")
     ap.add_argument("--samples", type=int, default=128, help="samples per ray, half coarse / half importance (BASELINE configs[2], lego: 64)")
     ap.add_argument("--white-bkgd", action="store_true", help="white background compositing (NeRF-synthetic scenes, BASELINE configs[2])")
@@ -378,7 +416,13 @@ def main():
                     help="calc_normal=False (SURVEY 8d config 2 asks for both): no nablas at the N sample points, no normals_volume")
     ap.add_argument("--data-independent", action="store_true",
                     help="evaluate every probe and every mid-point (NM_RENDER_FULL_PROBES | NM_RENDER_NO_ZERO_SKIP): the work the reference always does")
-    ap.add_argument("--no-extras", action="store_true", help="skip the short variant runs reported under `extra`")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short variant runs reported under `config` / `extra`")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N > 1: nccl = RCCL over xGMI (default); gloo = test mode for boxes with fewer GPUs than "
+                         "ranks (ranks share devices round-robin, the collectives are staged through host memory)")
+    ap.add_argument("--shard", choices=["frames", "frame"], default="frames",
+                    help="multi-GPU partition: frames = every rank renders its own frame per step (weak scaling, default); frame = ONE "
+                         "frame per step split over the ranks by interleaved 32x32 tiles (BASELINE configs[3]; strong scaling)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args)
@@ -387,18 +431,23 @@ def main():
     import torch.distributed as dist
     from neumesh_amd import _lib
     from neumesh_amd.renderer import make_render_cfg, render_rays_fused
-    from neumesh_amd.sharded import pack_outputs
+    from neumesh_amd.sharded import _all_gather_rows, pack_outputs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.backend == "gloo":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     lib = _lib.load()
 
     if args.workload == "stress5":
@@ -414,8 +463,10 @@ def main():
     mesh, model = build_scene(args.V, dev, scene=args.scene)
     from neumesh_amd import synthetic
     from neumesh_amd.rays import make_rays
+    from neumesh_amd.sharded import render_frame_sharded
     n_rays = args.H * args.W
     intr = synthetic.pinhole_intrinsics(args.H, args.W)
+    one_frame = world > 1 and args.shard == "frame"
 
     def fence():
         torch.cuda.synchronize()
@@ -423,24 +474,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(steps, warmup, precision="f16x2", samples=128, normals=True, white=False, flags=0, keep_frame0=False, gather=True, hw=None, weight_eps=0.0, chunk=None):
-        """warmup + `steps` timed frames of one variant; returns (elapsed s [max over ranks], profile dict, rgb of frame 0 or None)."""
-        model.mlp_precision = precision
+    def run(steps, warmup, precision="f16x2", samples=128, normals=True, white=False, flags=0, keep_frame0=False, gather=True, hw=None,
+            weight_eps=0.0, chunk=None, mdl=None):
+        """warmup + `steps` timed frames of one variant; returns (elapsed s [max over ranks], profile dict, rgb of frame 0 or None,
+        rays of frame 0 or None, per-rank seconds up to the end of the rank's own work)."""
+        m = mdl or model
+        m.mlp_precision = precision
         cfg = make_render_cfg(calc_normal=normals, N_samples=samples // 2, N_importance=samples // 2, white_bkgd=white, flags=flags, weight_eps=weight_eps)
         total = warmup + steps
         H, W = hw or (args.H, args.W)
         r_intr = synthetic.pinhole_intrinsics(H, W) if hw else intr
-        # every rank builds the rays of ITS frame of the orbit on ITS GPU (nm_make_rays): resident before timing
-        rays = [make_rays(synthetic.orbit_pose(s * world + rank), r_intr, H, W, dev) for s in range(total)]
-        tables = model.field_tables()
-        model.field_handle()
-        gathered = torch.empty((world * H * W, 8 if normals else 5), dtype=torch.float32, device=dev) if (world > 1 and gather) else None
+        tables = m.field_tables()
+        m.field_handle()
+        rc = chunk or args.rayschunk or n_rays
+
+        def render(ro, rd):
+            return render_rays_fused(m, ro, rd, cfg, rc, tables=tables)   # hw frames: chunks of one headline frame
+
+        if one_frame:   # ONE frame per step over all ranks: every rank builds and renders the rays of its interleaved tiles
+            poses = [synthetic.orbit_pose(s) for s in range(total)]
+            rays = None
+        else:           # every rank builds the rays of ITS frame of the orbit on ITS GPU (nm_make_rays): resident before timing
+            rays = [make_rays(synthetic.orbit_pose(s * world + rank), r_intr, H, W, dev) for s in range(total)]
+        do_gather = world > 1 and gather and not one_frame
 
         def step(i):
-            ret = render_rays_fused(model, rays[i][0], rays[i][1], cfg, chunk or args.rayschunk or n_rays, tables=tables)   # hw frames: chunks of one headline frame
-            if gathered is not None:
+            if one_frame:
+                return render_frame_sharded(render, poses[i], r_intr, H, W, dev)
+            ret = render(rays[i][0], rays[i][1])
+            if do_gather:
                 packed, _ = pack_outputs(ret)
-                dist.all_gather_into_tensor(gathered, packed)   # the path's only collective: final pixels
+                _all_gather_rows(packed, world)   # the path's only collective: final pixels ([world * H * W, 5 or 8] on every rank)
             return ret
 
         rgb0 = None
@@ -453,19 +517,26 @@ def main():
         t0 = time.perf_counter()
         for i in range(warmup, total):
             step(i)
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0     # this rank's own work (+ the collectives it took part in), before the closing barrier
         fence()
         elapsed = time.perf_counter() - t0
+        per_rank = [own]
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            tdev = dev if args.backend == "nccl" else torch.device("cpu")
+            t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+            allr = torch.zeros(world, dtype=torch.float64, device=tdev)
+            dist.all_gather_into_tensor(allr, torch.tensor([own], dtype=torch.float64, device=tdev))
+            per_rank = [float(x) for x in allr.tolist()]
         prof = read_prof(lib)
         lib.nm_profile_enable(0)
-        return elapsed, prof, rgb0, (rays[0] if keep_frame0 else None)
+        return elapsed, prof, rgb0, (rays[0] if (keep_frame0 and rays) else None), per_rank
 
     head_flags = (_lib.RENDER_FULL_PROBES | _lib.RENDER_NO_ZERO_SKIP) if args.data_independent else 0
-    elapsed, prof, rgb0, rays0 = run(args.steps, args.warmup, precision=args.mlp_precision, samples=args.samples,
-                                     normals=not args.no_normals, white=args.white_bkgd, flags=head_flags, keep_frame0=True)
+    elapsed, prof, rgb0, rays0, per_rank = run(args.steps, args.warmup, precision=args.mlp_precision, samples=args.samples,
+                                               normals=not args.no_normals, white=args.white_bkgd, flags=head_flags, keep_frame0=True)
 
     def mlp_summary(prof, precision):
         split = precision != "fp32"
@@ -476,37 +547,56 @@ def main():
         return dom, p, alg, peak, split
 
     if rank == 0:
-        value = world * n_rays * args.steps / elapsed
+        frames_per_step = 1 if one_frame else world
+        value = frames_per_step * n_rays * args.steps / elapsed
         dom, p, alg, peak, split = mlp_summary(prof, args.mlp_precision)
+        products = 3.0 if args.mlp_precision == "f16x2" else 1.0
         mlp_flop = sum(prof[k]["points"] * prof[k]["flop_per_point"] for k in ("geo_mlp", "geo_mlp_tangent", "color_mlp"))
         mlp_ms = sum(prof[k]["ms"] for k in ("geo_mlp", "geo_mlp_tangent", "color_mlp"))
         kd = prof["knn_distance"]
         traffic, tsrc = _load_profile("pmc_traffic")
         mfma_pmc, msrc = _load_profile("pmc_mfma")
         knn_pmc, ksrc = _load_profile("pmc_knn")
-        kname = ({"geo_mlp": "nm_geo_mlp_h2_kernel<false,true>", "geo_mlp_tangent": "nm_geo_mlp_h2_kernel<true,true>", "color_mlp": "nm_col_mlp_h2_kernel<true>"} if args.mlp_precision == "f16x2" else
-                 {"geo_mlp": "nm_geo_mlp_h_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_h_kernel<true>", "color_mlp": "nm_col_mlp_h_kernel"} if split else
+        nabla_k, fixed_k = {"geo_mlp": "false", "geo_mlp_tangent": "true"}, "true"
+        kname = ({"geo_mlp": "nm_geo_mlp_h2_kernel<false,true,NP>", "geo_mlp_tangent": "nm_geo_mlp_h2_kernel<true,true,NP>", "color_mlp": "nm_col_mlp_h2_kernel<true,NP>"} if split else
                  {"geo_mlp": "nm_geo_mlp_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_kernel<true>", "color_mlp": "nm_col_mlp_kernel"})[dom]
+        kname = kname.replace("NP", "3" if args.mlp_precision == "f16x2" else "1")
         searched_per_s = kd["points"] / (kd["ms"] * 1e-3) if kd["ms"] > 0 else 0.0
+        n_frames = args.steps    # frames THIS rank's profile saw (its share of each under --shard frame)
+        rays_here = (n_rays / world) if one_frame else n_rays
+        knn_ref_per_ray = 256 + 3 * args.samples - 1                    # K-NN points the reference searches per ray
+        mid_per_ray = prof["color_mlp"]["points"] / max(n_frames * rays_here, 1)
         strategy = ("every probe and every mid-point evaluated (data-independent work, as the reference)" if args.data_independent else
-                    "probes between the first and last hit and mid-points of weight 0 are not evaluated (bit-identical results, scene-dependent work)")
+                    "probes between first/last hit and zero-weight mid-points skipped (bit-identical)")
+        dtype = {"f16x2": "f16x2-split (22-bit operands, fp32 accumulate; K-NN and per-ray stages fp32)",
+                 "f16": "f16 single product (11-bit operands, fp32 accumulate): reduced precision, see config.f16_single_*", "fp32": "f32"}[args.mlp_precision]
         out = {
             "metric": f"rays/sec at {args.H}x{args.W}x{args.samples} samples (DTU scan63 shape, synthetic scene S-DTU, {'with a surface' if args.scene == 'surf' else 'default-init noise field'})",
             "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_frame": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16x2-split (22-bit operands, fp32 accumulate; K-NN and per-ray stages fp32)" if split else "f32", "data": "synthetic",
-            "config": {"workload": f"S-DTU V={args.V} {args.H}x{args.W} rays/frame/GPU, {args.samples // 2}+{args.samples // 2} samples"
-                                   f"{', white background' if args.white_bkgd else ''}, bounded_near_far (256 probes), calc_normal={not args.no_normals}; "
-                                   f"per ray {256 + 3 * args.samples - 1} K-NN points in the reference ({args.samples} of them re-addressed, not searched again), "
-                                   f"{2 * args.samples - 1} geometry-MLP evaluations + {args.samples - 1} colour-MLP; {strategy}",
-                       "rayschunk": args.rayschunk or n_rays, "parallelism": f"rays sharded: {world} GPU(s) x 1 frame per step, 1 all-gather of pixels"},
+            "higher_is_better": True, "scaling": "strong" if one_frame else "weak", "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic",
+            "config": {"workload": f"S-DTU/{args.scene} V={args.V} {args.H}x{args.W}x{args.samples // 2}+{args.samples // 2}, bounded near/far, normals={not args.no_normals}"
+                                   f"{', white bkgd' if args.white_bkgd else ''}",
+                       "scene": ("surf: sdf = ds + code-driven bump, s = 400 (synthetic.surface_mlp_state); tests/golden/render_v140k_surf.npz" if args.scene == "surf"
+                                 else "noise: default-init MLP weights, s = 200; tests/golden/render_v140k_dtu.npz"),
+                       "work_strategy": strategy,
+                       "reference_work_per_ray": f"{knn_ref_per_ray} K-NN points, {2 * args.samples - 1} geometry-MLP + {args.samples - 1} colour-MLP evaluations",
+                       "knn_points_searched_per_ray": kd["points"] / max(n_frames * rays_here, 1),
+                       "knn_points_searched_frac_of_reference": kd["points"] / max(n_frames * rays_here, 1) / knn_ref_per_ray,
+                       "midpoints_evaluated_per_ray": mid_per_ray, "midpoints_zero_weight_frac": 1.0 - mid_per_ray / (args.samples - 1),
+                       "rayschunk": args.rayschunk or n_rays,
+                       "parallelism": (f"one frame per step over {world} GPU(s): interleaved 32x32 pixel tiles, 1 all-gather of pixels" if one_frame else
+                                       f"rays sharded: {world} GPU(s) x 1 frame per step, 1 all-gather of pixels"),
+                       "world_size": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else "none",
+                       "per_rank_ms_per_step_min": min(per_rank) / args.steps * 1e3, "per_rank_ms_per_step_max": max(per_rank) / args.steps * 1e3},
             "roofline": {"bound": "mfma", "kernel": kname,
                          # achieved = ALGORITHMIC fp32 flops of the layer products / measured kernel time
                          "achieved": alg, "peak": peak, "unit": "TFLOP/s", "frac": alg / peak,
-                         "mfma_dtype": "f16 (3 MFMA products per fp32 product: split-half operands, fp32 accumulate)" if split else "f32",
+                         "mfma_dtype": ("f16 (3 MFMA products per fp32 product: split-half operands, fp32 accumulate)" if products == 3.0 else
+                                        "f16 (1 MFMA product)" if split else "f32"),
                          # what the matrix pipe actually executes (3x the algorithmic flops in split-half mode)
-                         "issued_tflops": alg * (3.0 if split else 1.0), "issued_frac_of_pipe_peak": alg * (3.0 if split else 1.0) / peak,
+                         "issued_tflops": alg * products, "issued_frac_of_pipe_peak": alg * products / peak,
                          "algorithmic_vs_fp32_mfma_peak": alg / PEAK_FP32_MFMA_TFLOPS,
                          "mfma_busy_pmc": (mfma_pmc or {}).get(dom), "mfma_busy_source": msrc,
                          "traffic": (traffic or {}).get(dom, {}).get("hbm_bytes_per_launch"), "traffic_source": tsrc,
@@ -515,20 +605,28 @@ def main():
                          "points_per_launch": p["points"] / max(p["launches"], 1),
                          "all_mlp_kernels_tflops": mlp_flop / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0,
                          "share_of_step_time": {k: prof[k]["ms"] / (elapsed * 1e3) for k in prof}},
+            "per_rank_ms_per_step": [x / args.steps * 1e3 for x in per_rank],
             "knn_kernel": {"kernels": "nm_distance_kernel<chain> + nm_probe_bounds_kernel",
                            "bound": "instruction issue + scalar-load latency (index is L2/scalar-cache resident; not HBM)",
-                           "searched_points_per_s": searched_per_s, "searched_points_per_frame": kd["points"] / max(args.steps * 1, 1),
-                           "ms_per_frame": kd["ms"] / max(args.steps, 1),
+                           "searched_points_per_s": searched_per_s, "searched_points_per_frame": kd["points"] / max(n_frames, 1),
+                           "ms_per_frame": kd["ms"] / max(n_frames, 1),
                            "algorithmic_GBs_at_76B_per_query": searched_per_s * KNN_BYTES_PER_QUERY / 1e9,
                            "hbm_frac_at_76B_per_query": searched_per_s * KNN_BYTES_PER_QUERY / 1e9 / PEAK_HBM_GBS,
                            "issue_pmc": knn_pmc, "issue_pmc_source": ksrc,
                            "traffic": (traffic or {}).get("knn_distance", {}).get("hbm_bytes_per_launch")},
         }
+        cfgd = out["config"]
         extra = {}
-        if world == 1 and not args.no_extras and not args.data_independent and args.samples == 128 and not args.no_normals and not args.white_bkgd:
+        fixture = None
+        fx_path = os.path.join(ROOT, "tests", "golden", "render_v140k_surf.npz" if args.scene == "surf" else "render_v140k_dtu.npz")
+        if os.path.exists(fx_path):
+            fixture = np.load(fx_path)
+            if not (int(fixture["V"]) == args.V and int(fixture["H"]) == args.H and int(fixture["W"]) == args.W):
+                fixture = None
+        if world == 1 and not args.no_extras and not args.data_independent and args.samples == 128 and not args.no_normals and not args.white_bkgd and args.mlp_precision == "f16x2":
             def short(name, **kw):
                 try:
-                    e, pr, img, _ = run(2, 1, **kw)
+                    e, pr, img, _, _ = run(2, 1, **kw)
                     d, pp, a, pk, sp = mlp_summary(pr, kw.get("precision", "f16x2"))
                     nr = kw["hw"][0] * kw["hw"][1] if "hw" in kw else n_rays
                     extra[name] = {"value": nr * 2 / e, "unit": "rays/s", "ms_per_frame": e / 2 * 1e3, "steps": 2,
@@ -537,11 +635,27 @@ def main():
                                    "mlp_points_per_frame": {k: pr[k]["points"] / 2 for k in ("geo_mlp", "geo_mlp_tangent", "color_mlp")}}
                     if img is not None and rgb0 is not None and img.shape == rgb0.shape:   # same frame 0 as the headline run
                         extra[name]["max_abs_rgb_vs_headline_frame"] = float(np.abs(img - rgb0).max())
+                    if img is not None and fixture is not None and "mdl" not in kw:
+                        g = img[fixture["sel"]]
+                        err = np.abs(g - fixture["rgb"]).max(-1)
+                        extra[name]["vs_reference_fixture"] = {"max_abs_rgb": float(err.max()), "median_abs_rgb": float(np.median(err)),
+                                                               "frac_rays_within_1e-4": float((err <= 1e-4).mean()), "psnr_db": _psnr(g, fixture["rgb"])}
+                    return extra[name]
                 except Exception as ex:  # a variant must never sink the headline
                     extra[name] = {"error": str(ex)}
-            short("data_independent_frame (every probe + every mid-point evaluated: the reference's work)",
-                  flags=_lib.RENDER_FULL_PROBES | _lib.RENDER_NO_ZERO_SKIP)
-            short("mlp_precision_fp32 (fp32-input MFMA)", precision="fp32")
+                    return {}
+            r = short("data_independent_frame (every probe + every mid-point evaluated: the reference's work)",
+                      flags=_lib.RENDER_FULL_PROBES | _lib.RENDER_NO_ZERO_SKIP)
+            cfgd["data_independent_rays_per_s"], cfgd["data_independent_ms_per_frame"] = r.get("value"), r.get("ms_per_frame")
+            r = short("mlp_precision_fp32 (fp32-input MFMA)", precision="fp32")
+            cfgd["fp32_rays_per_s"], cfgd["fp32_ms_per_frame"] = r.get("value"), r.get("ms_per_frame")
+            cfgd["fp32_mlp_tflops"], cfgd["fp32_frac_of_fp32_mfma_peak"] = r.get("achieved_tflops_algorithmic"), r.get("frac_of_pipe_peak")
+            r = short("mlp_precision_f16 (ONE f16 MFMA per product, 11-bit operands: the 'bf16 MLP'-class mode of BASELINE configs[1]; misses the 1e-4 bound, never a default)",
+                      precision="f16", keep_frame0=True)
+            cfgd["f16_single_rays_per_s"], cfgd["f16_single_ms_per_frame"] = r.get("value"), r.get("ms_per_frame")
+            fxr = r.get("vs_reference_fixture", {})
+            cfgd["f16_single_max_abs_rgb_vs_reference"], cfgd["f16_single_psnr_db_vs_reference"] = fxr.get("max_abs_rgb"), fxr.get("psnr_db")
+            cfgd["f16_single_frac_rays_within_1e-4"] = fxr.get("frac_rays_within_1e-4")
             short("calc_normal_false", normals=False)
             short("two_half_frame_chunks_on_two_streams (rayschunk = half a frame: the low-occupancy per-ray kernels of one chunk run beside the other chunk's "
                   "kernels; identical pixels; the per-kernel event times of this run overlap, so the roofline figures are taken from the one-stream headline run)",
@@ -550,13 +664,30 @@ def main():
                   "rgb / normals move by < 127e-10, depth / acc not at all)", weight_eps=1e-10, keep_frame0=True)
             short("config3_shape (64 samples/ray, white background)", samples=64, white=True)
             short("config4_shape (1600x1200 rays/frame in chunks of one 800x800 frame, 64+64 samples)", hw=(1200, 1600))
+            try:   # the other scene (rounds 1-2 headline: default-init noise field), same kernels
+                other = "noise" if args.scene == "surf" else "surf"
+                _, model2 = build_scene(args.V, dev, scene=other)
+                r = short(f"{other}_scene (same shape on the {'default-init noise field, s = 200: every ray opaque' if other == 'noise' else 'scene with a surface'})", mdl=model2)
+                cfgd[f"{other}_scene_rays_per_s"], cfgd[f"{other}_scene_ms_per_frame"] = r.get("value"), r.get("ms_per_frame")
+                del model2
+            except Exception as ex:
+                extra["other_scene"] = {"error": str(ex)}
             model.mlp_precision = args.mlp_precision
             extra.update(consumer_rows(mesh, model, dev, args.H, args.W))
         if world == 1 and args.cpu_rays > 0:
             try:
                 r0 = (rays0[0].cpu().numpy(), rays0[1].cpu().numpy())
-                base, orgb, sel = cpu_baseline(mesh, model, args.H, args.W, args.cpu_rays, r0, samples=args.samples,
-                                               white_bkgd=args.white_bkgd, calc_normal=not args.no_normals)
+                base = None
+                try:
+                    from oracle.refimport import harness
+                    if harness.reference_available():   # (the build container; the GPU box has no reference tree)
+                        base, orgb, sel = reference_baseline(mesh, model, args.H, args.W, min(args.cpu_rays, 512), r0, samples=args.samples,
+                                                             white_bkgd=args.white_bkgd, calc_normal=not args.no_normals)
+                except Exception:
+                    base = None
+                if base is None:
+                    base, orgb, sel = cpu_baseline(mesh, model, args.H, args.W, args.cpu_rays, r0, samples=args.samples,
+                                                   white_bkgd=args.white_bkgd, calc_normal=not args.no_normals)
                 out["cpu_baseline"] = base
                 out["speedup_vs_cpu_baseline"] = value / base["value"]
                 out.update(parity_blocks(rgb0, args.H, args.W, args.V, orgb, sel, args.scene))
@@ -564,6 +695,11 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         elif world == 1:
             out.update(parity_blocks(rgb0, args.H, args.W, args.V, None, None, args.scene))
+        if "parity_vs_reference" in out:
+            pr = out["parity_vs_reference"]
+            cfgd["parity_max_abs_rgb_vs_reference"], cfgd["parity_median_abs_rgb_vs_reference"] = pr["max_abs_rgb"], pr["median_abs_rgb"]
+            cfgd["parity_frac_rays_within_1e-4"] = pr["frac_rays_within_1e-4"]
+            cfgd["reference_self_1ulp_frac_rays_within_1e-4"] = pr["reference_self_sensitivity_1ulp"]["frac_rays_within_1e-4"]
         if world == 1 and not args.no_extras and extra:
             try:   # BASELINE config 5 (HBM-stress of the K-NN + gather kernel), 2 steps
                 del model
@@ -573,6 +709,10 @@ def main():
                 s5 = stress5_run(args, dev, 1, 0, 2, 1)
                 extra["config5_stress (V=1M, 256-d table, 4096x4096 queries/step)"] = {
                     "value": s5["value"], "unit": s5["unit"], "ms_per_step": s5["ms_per_step"], "steps": 2, "roofline": s5["roofline"]}
+                cfgd["config5_queries_per_s"] = s5["value"]
+                cfgd["config5_frac_algorithmic_of_hbm_peak"] = s5["roofline"]["frac"]
+                mh = s5["roofline"].get("measured_hbm_GBs")
+                cfgd["config5_frac_measured_hbm_of_peak"] = (mh / PEAK_HBM_GBS) if mh else None
             except Exception as ex:
                 extra["config5_stress (V=1M, 256-d table, 4096x4096 queries/step)"] = {"error": str(ex)}
         if extra:

@@ -84,6 +84,31 @@ def test_sharded_frame_world2_equals_unsharded(cuda_device, tmp_path):
     _run(tmp_path, 2, "nccl" if torch.cuda.device_count() >= 2 else "gloo")
 
 
+@pytest.mark.parametrize("shard", ["frames", "frame"])
+def test_bench_two_ranks_both_partitions(cuda_device, shard):
+    """bench.py under torch.distributed.run with 2 ranks -- over RCCL on two devices, or (one GPU visible) with --backend gloo: the
+    ranks share cuda:0 and the collectives are staged through the host; the partition, per-rank timing and JSON line are the same
+    code either way.  --shard frames: one frame per rank and step (weak); --shard frame: one frame per step over both ranks (strong)."""
+    import json
+    import torch
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    env = dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")},
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--H", "160", "--W", "160", "--V", "3000", "--cpu-rays", "0",
+           "--no-extras", "--backend", backend, "--shard", shard]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["config"]["backend"] == backend
+    assert line["scaling"] == ("weak" if shard == "frames" else "strong") and len(line["per_rank_ms_per_step"]) == 2
+    rays_per_step = 160 * 160 * (2 if shard == "frames" else 1)
+    assert abs(line["value"] - rays_per_step / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+
+
 def test_bench_self_spawns_for_multi_gpu(cuda_device):
     """`python bench.py --gpus 2` with no torch.distributed environment must launch itself (one rank per
     GPU); needs two devices -- on a single-GPU box only the re-exec command line is checked."""
