@@ -76,6 +76,10 @@ __device__ __forceinline__ void nm_fetch_point(const NmPointSrc& s, long long r,
     z = nm_add(s.rays_o[3 * r + 2], nm_mul(d, s.dirn[3 * r + 2]));
 }
 
+#ifndef NM_KNN_WAVES
+#define NM_KNN_WAVES 6   // waves per SIMD the K-NN kernels are compiled for (register budget 512 / NM_KNN_WAVES)
+#endif
+
 // ------------------------------------------------------------ wave-cooperative K-NN search
 // The 64 queries of a wave are neighbours in space (consecutive samples of adjacent rays), so
 // their K-NN searches open almost the same octree nodes.  The wave therefore runs ONE traversal:
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(256) void nm_knn_kernel(NmGridView g, NmPointSrc sr
 // bound by scalar-load latency, so waves per SIMD matter more than registers: K-NN time per frame with 4
 // waves 156 ms, 5: 141, 6: 136, 7: 155 (spills reach the traversal), 8: 540.
 template <bool CHAIN>
-__global__ __launch_bounds__(256, 6) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
+__global__ __launch_bounds__(256, NM_KNN_WAVES) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
                                                           const float* __restrict__ verts,
                                                           const float* __restrict__ indicator, float w1,
                                                           float* __restrict__ ds_out, int* __restrict__ idx32_out,
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(256, 6) void nm_distance_kernel(NmGridView g, NmPoi
 // S = probes per ray and step (4: 16 rays per wave, 8: 8 rays per wave -- half as many serial steps per wave, up to 4 more probes
 // per ray and walk; nm_render_rays picks)
 template <int S>
-__global__ __launch_bounds__(256, 6) void nm_probe_bounds_kernel(NmGridView g, const float* __restrict__ rays_o,
+__global__ __launch_bounds__(256, NM_KNN_WAVES) void nm_probe_bounds_kernel(NmGridView g, const float* __restrict__ rays_o,
                                                                  const float* __restrict__ dirn, const float* __restrict__ nearfar0,
                                                                  long long R, int P, float thresh, const float* __restrict__ verts,
                                                                  const float* __restrict__ indicator, float w1,

@@ -96,7 +96,7 @@ int hc_knn_stats(void* p, const float* q, int64_t Q, double* out) {
 // out[0] = node records tested per packet, out[1] = vertices scanned per packet.
 int hc_knn_packet(void* p, const float* q, int64_t Q, int Wd, int64_t* idx, float* d2, double* out) {
     const NmGridView g = nm_host_view(((HostGridHandle*)p)->g);
-    long long nodes_t = 0, verts_t = 0, packets = 0;
+    long long nodes_t = 0, verts_t = 0, packets = 0, insert_events = 0, deferred_rounds = 0, lane_inserts = 0, marked_sum = 0;
     std::vector<unsigned long long> kk((size_t)Wd * 8);
     for (int64_t base = 0; base < Q; base += Wd) {
         const int n = (int)std::min<int64_t>(Wd, Q - base);
@@ -137,15 +137,37 @@ int hc_knn_packet(void* p, const float* q, int64_t Q, int Wd, int64_t* idx, floa
             if (!any) continue;
             if ((crec.info & 255u) == 0u) {
                 verts_t += crec.end - crec.first;
+                // instruction-cost model of the leaf scan (out[2..4]): insert events of the one-vertex-at-a-time scan (a vertex costs the
+                // wave one list insertion when ANY lane inserts it) against the deferred scan (per 64-vertex chunk every lane first marks the
+                // vertices below its threshold at chunk entry, then the wave runs max-over-lanes(marked) insertion rounds)
+                for (uint32_t p0 = crec.first; p0 < crec.end; p0 += 64) {
+                    const uint32_t p1 = std::min<uint32_t>(crec.end, p0 + 64);
+                    int max_marked = 0;
+                    for (int l = 0; l < n; ++l) {
+                        if (!want[(size_t)l]) continue;
+                        const float* ql = q + 3 * (base + l);
+                        const unsigned long long thr = kk[(size_t)l * 8 + 7];
+                        int marked = 0;
+                        for (uint32_t pp = p0; pp < p1; ++pp) {
+                            const float4 v = g.sverts[pp];
+                            marked += nm_key(nm_dist2(ql[0], ql[1], ql[2], v.x, v.y, v.z), nm_as_int(v.w)) < thr ? 1 : 0;
+                        }
+                        max_marked = std::max(max_marked, marked);
+                        marked_sum += marked;
+                    }
+                    deferred_rounds += max_marked;
+                }
                 for (uint32_t pp = crec.first; pp < crec.end; ++pp) {
                     const float4 v = g.sverts[pp];
+                    bool any_ins = false;
                     for (int l = 0; l < n; ++l) {
                         if (!want[(size_t)l]) continue;
                         const float* ql = q + 3 * (base + l);
                         const unsigned long long key = nm_key(nm_dist2(ql[0], ql[1], ql[2], v.x, v.y, v.z), nm_as_int(v.w));
                         unsigned long long(&k8)[8] = *reinterpret_cast<unsigned long long(*)[8]>(&kk[(size_t)l * 8]);
-                        if (key < k8[7]) nm_topk_insert<8>(k8, key);
+                        if (key < k8[7]) { nm_topk_insert<8>(k8, key); any_ins = true; ++lane_inserts; }
                     }
+                    insert_events += any_ins ? 1 : 0;
                 }
             } else {
                 rec = crec;
@@ -164,6 +186,10 @@ int hc_knn_packet(void* p, const float* q, int64_t Q, int Wd, int64_t* idx, floa
     }
     out[0] = (double)nodes_t / (double)(packets ? packets : 1);
     out[1] = (double)verts_t / (double)(packets ? packets : 1);
+    out[2] = (double)insert_events / (double)(packets ? packets : 1);     // per packet: vertices at which at least one lane inserts
+    out[3] = (double)deferred_rounds / (double)(packets ? packets : 1);   // per packet: insertion rounds of the deferred (chunk-wise) scan
+    out[4] = (double)lane_inserts / (double)(Q ? Q : 1);                  // per query: list insertions
+    out[5] = (double)marked_sum / (double)(Q ? Q : 1);                    // per query: vertices below the chunk-entry threshold
     return 0;
 }
 
