@@ -76,6 +76,7 @@ __device__ __forceinline__ void nm_fetch_point(const NmPointSrc& s, long long r,
     z = nm_add(s.rays_o[3 * r + 2], nm_mul(d, s.dirn[3 * r + 2]));
 }
 
+#define NM_KNN_BLOCK 256   // threads per workgroup of every kernel that runs the K-NN traversal (the leaf stage in LDS is sized by it)
 #ifndef NM_KNN_WAVES
 #define NM_KNN_WAVES 6   // waves per SIMD the K-NN kernels are compiled for (register budget 512 / NM_KNN_WAVES)
 #endif
@@ -168,8 +169,8 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
             // scores them from LDS (same-address reads: broadcast).  A/B on the 800x800 frame, same call: scalar-path scan
             // (s_load_dwordx16 = 4 vertices per dependent load) 103.2 ms of K-NN per frame, this 100.9, vector load +
             // v_readlane broadcast 115.5; the leaf level keeps its optimum (~32 vertices per leaf: 101 vs 127-130 ms at ~120).
-            __shared__ float4 nm_leaf_lds[4][64];  // (every kernel that traverses runs 4 waves per workgroup)
-            float4* stage = nm_leaf_lds[threadIdx.x >> 6];
+            __shared__ float4 nm_leaf_lds[NM_KNN_BLOCK / 64][64];  // one stage per wave: every kernel that traverses is compiled
+            float4* stage = nm_leaf_lds[threadIdx.x >> 6];          // with __launch_bounds__(NM_KNN_BLOCK) and launched with that block size
             const uint32_t ln = threadIdx.x & 63u;
             for (uint32_t p0 = crec.first; p0 < crec.end; p0 += 64) {
                 const uint32_t cnt = crec.end - p0 < 64u ? crec.end - p0 : 64u;
@@ -346,7 +347,7 @@ __device__ __forceinline__ float nm_bound_from_neighbours(const float* __restric
 
 // ----------------------------------------------------------------------------- plain K-NN
 template <int K>
-__global__ __launch_bounds__(256) void nm_knn_kernel(NmGridView g, NmPointSrc src, long long Q, int Kout,
+__global__ __launch_bounds__(NM_KNN_BLOCK) void nm_knn_kernel(NmGridView g, NmPointSrc src, long long Q, int Kout,
                                                      long long* __restrict__ idx_out, float* __restrict__ d2_out) {
     long long q, r;
     int p;
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void nm_knn_kernel(NmGridView g, NmPointSrc sr
 // bound by scalar-load latency, so waves per SIMD matter more than registers: K-NN time per frame with 4
 // waves 156 ms, 5: 141, 6: 136, 7: 155 (spills reach the traversal), 8: 540.
 template <bool CHAIN>
-__global__ __launch_bounds__(256, NM_KNN_WAVES) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
+__global__ __launch_bounds__(NM_KNN_BLOCK, NM_KNN_WAVES) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
                                                           const float* __restrict__ verts,
                                                           const float* __restrict__ indicator, float w1,
                                                           float* __restrict__ ds_out, int* __restrict__ idx32_out,
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256, NM_KNN_WAVES) void nm_distance_kernel(NmGridVi
 // S = probes per ray and step (4: 16 rays per wave, 8: 8 rays per wave -- half as many serial steps per wave, up to 4 more probes
 // per ray and walk; nm_render_rays picks)
 template <int S>
-__global__ __launch_bounds__(256, NM_KNN_WAVES) void nm_probe_bounds_kernel(NmGridView g, const float* __restrict__ rays_o,
+__global__ __launch_bounds__(NM_KNN_BLOCK, NM_KNN_WAVES) void nm_probe_bounds_kernel(NmGridView g, const float* __restrict__ rays_o,
                                                                  const float* __restrict__ dirn, const float* __restrict__ nearfar0,
                                                                  long long R, int P, float thresh, const float* __restrict__ verts,
                                                                  const float* __restrict__ indicator, float w1,

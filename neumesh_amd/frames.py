@@ -44,10 +44,11 @@ def assemble_images(rgb: torch.Tensor, depth: torch.Tensor = None, normals: torc
         out["normal"] = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
     if (d is not None and d.numel() != n) or (nrm is not None and nrm.shape[0] != n):
         raise ValueError("assemble_images: rgb / depth / normals of different pixel counts")
-    _lib.check(lib.nm_assemble_frame(_lib.ptr(rgb), _lib.ptr(d) if d is not None else None, _lib.ptr(nrm) if nrm is not None else None,
-                                     n, int(bool(bgr)), _lib.ptr(out["rgb"]), _lib.ptr(out["depth"]) if d is not None else None,
-                                     _lib.ptr(out["normal"]) if nrm is not None else None,
-                                     _lib.ptr(scratch) if scratch is not None else None, _lib.current_stream(dev)), "nm_assemble_frame")
+    with torch.cuda.device(dev):   # (the tensors may live on another device than the current one: sharded / multi-GPU inference)
+        _lib.check(lib.nm_assemble_frame(_lib.ptr(rgb), _lib.ptr(d) if d is not None else None, _lib.ptr(nrm) if nrm is not None else None,
+                                         n, int(bool(bgr)), _lib.ptr(out["rgb"]), _lib.ptr(out["depth"]) if d is not None else None,
+                                         _lib.ptr(out["normal"]) if nrm is not None else None,
+                                         _lib.ptr(scratch) if scratch is not None else None, _lib.current_stream(dev)), "nm_assemble_frame")
     return out
 
 

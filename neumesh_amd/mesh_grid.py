@@ -102,6 +102,24 @@ class MeshGrid(MeshPrimitive):
         self.vertex_normals = torch.from_numpy(np.asarray(mesh.vertex_normals, dtype=np.float32).copy()).to(dev)
         self.grid = GridHandle(self.vertices)  # the reference caches FRNN's grid here (mesh_grid.py:64-74)
         self.distance_method = distance_method
+        self.device = dev
+        self._siblings = {}   # per-device copies for nn.DataParallel replicas (on_device)
+
+    def on_device(self, device):
+        """This mesh index on another device (own vertex copy + own octree), built once and cached: an nn.DataParallel
+        replica of a NeuMesh on cuda:k must not launch kernels against the index that lives on cuda:0."""
+        dev = _as_device(device)
+        if dev == self.device:
+            return self
+        g = self._siblings.get(dev)
+        if g is None:
+            g = MeshGrid.__new__(MeshGrid)
+            MeshPrimitive.__init__(g, self.mesh)
+            g.vertices, g.vertex_normals = self.vertices.to(dev), self.vertex_normals.to(dev)
+            g.grid = GridHandle(g.vertices)
+            g.distance_method, g.device, g._siblings = self.distance_method, dev, {}
+            self._siblings[dev] = g
+        return g
 
     def compute_distance(self, xyz, indicator_vector=None, indicator_weight=0.1, K=8):
         if self.distance_method == "frnn":

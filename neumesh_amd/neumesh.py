@@ -117,6 +117,23 @@ class _FusedField(autograd.Function):
         return (None, None, gx, None, *grads[1:])
 
 
+class FieldHandle:
+    """Owns one nm_field_t (packed MLP weights on one device).  NeuMesh keeps a reference; nn.DataParallel replicas are
+    shallow copies of the module's __dict__ and therefore share THIS object until they rebuild their own (see
+    NeuMesh._replicate_for_data_parallel): the handle is destroyed exactly once, when the last reference goes."""
+
+    def __init__(self, h, device):
+        self.h, self.device = h, device
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                _lib.load(require_device=False).nm_field_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 class NeuMesh(nn.Module):
     def __init__(self, mesh_grid, D_density: int, D_color: int, W: int, geometry_dim: int, color_dim: int,
                  multires_view: int, multires_d: int, multires_fg: int, multires_ft: int,
@@ -154,7 +171,7 @@ class NeuMesh(nn.Module):
         # form against the reference, 2.1-2.4x faster; needs |activations| < 65504), "fp32"
         # (fp32-input MFMA) or "f16" (single f16 product: reduced precision, error-quantified in bench.py).
         self.mlp_precision = os.environ.get("NEUMESH_MLP_PRECISION", "f16x2")
-        self._field = None        # nm_field_t
+        self._field = None        # FieldHandle (owner of the nm_field_t)
         self._field_key = None    # parameter versions / device / precision the packed weights were built from
         self._field_dev = None
         self._field_epoch = 0     # bumped by invalidate_field()
@@ -197,13 +214,13 @@ class NeuMesh(nn.Module):
         dev = ps[0].device
         key = tuple((p.data_ptr(), p._version) for p in ps) + (self.mlp_precision, str(dev), self._field_epoch)
         if self._field is not None and key == self._field_key:
-            return self._field
+            return self._field.h
         lib = _lib.load()
         if dev.type != "cuda":
             raise _lib.NeuMeshHipError("NeuMesh parameters must live on a HIP device (model.to('cuda')); no CPU fallback")
-        if self._field is not None and self._field_dev != dev:
-            # the packed weights live on the device they were created on: a moved model gets a new handle
-            lib.nm_field_destroy(self._field)
+        if self._field is not None and self._field.device != dev:
+            # the packed weights live on the device they were created on: a moved model gets a new handle (the old one
+            # goes with its last owner)
             self._field = None
         with torch.no_grad():
             def folded(m):  # W = g * v / ||v||_row  (torch.nn.utils.weight_norm, dim=0)
@@ -233,27 +250,49 @@ class NeuMesh(nn.Module):
             if self._field is None:
                 h = C.c_void_p()
                 _lib.check(lib.nm_field_create(C.byref(d), stream, C.byref(h)), "nm_field_create")
-                self._field = h
+                self._field = FieldHandle(h, dev)
             else:
-                _lib.check(lib.nm_field_update(self._field, C.byref(d), stream), "nm_field_update")
+                _lib.check(lib.nm_field_update(self._field.h, C.byref(d), stream), "nm_field_update")
         self._keep = (gw, gb, dw, db, cw, cb, rw, rb)  # the pack call synchronised; kept for clarity
         self._field_key = key
         self._field_dev = dev
         self._range_checked = False   # new weights: the next fused call verifies the fp16 range once
-        return self._field
+        return self._field.h
 
-    def check_fp16_range(self, force: bool = False) -> bool:
+    def _replicate_for_data_parallel(self):
+        """nn.DataParallel replica (models/trainer.py:39-42 wraps the renderer when several device_ids are given): a shallow
+        copy that must not share device state with the module it was copied from -- its packed weights are rebuilt on the
+        replica's own device at first use, and its mesh index is the per-device copy MeshGrid.on_device() keeps."""
+        replica = super()._replicate_for_data_parallel()
+        replica._field, replica._field_key, replica._field_dev = None, None, None
+        replica._scalars_key, replica._keep, replica._range_checked = None, None, False
+        replica._is_replica = True
+        return replica
+
+    def grid_for(self, device):
+        """The mesh index on `device` (the module's own grid, or its per-device copy for a DataParallel replica)."""
+        g = self.mesh_grid
+        return g if g.device == device else g.on_device(device)
+
+    def check_fp16_range(self, force: bool = False, every: int = 1) -> bool:
         """Split-half modes only: ask the library whether any launch since the last check saw a value
         outside the fp16 range (nm_field_overflow; synchronises the stream).  Called once after the
         first fused call on a new weight set; returns True if the results of those launches are valid.
         On overflow the model switches itself to mlp_precision='fp32' (with a warning) and returns False:
         the caller re-runs the call."""
-        if self.mlp_precision == "fp32" or self._field is None or (self._range_checked and not force):
+        # The flag is sticky on the device and depends on the INPUTS as well as the weights (hidden activations at other views,
+        # nabla magnitudes), so it is read after EVERY fused render call (every = 1: one stream sync per frame-sized call) and,
+        # for the point-wise field calls, after the first call on a weight set and then every `every`-th call (a training step
+        # issues a dozen of them; an overflow is then reported at most `every` calls late -- the flag does not forget).
+        if self.mlp_precision == "fp32" or self._field is None:
+            return True
+        self._range_calls = getattr(self, "_range_calls", 0) + 1
+        if self._range_checked and not force and every > 1 and self._range_calls % every:
             return True
         lib = _lib.load()
         flag = C.c_int(0)
         with torch.cuda.device(self._field_dev):
-            _lib.check(lib.nm_field_overflow(self._field, C.byref(flag), _lib.current_stream(self._field_dev)), "nm_field_overflow")
+            _lib.check(lib.nm_field_overflow(self._field.h, C.byref(flag), _lib.current_stream(self._field_dev)), "nm_field_overflow")
         self._range_checked = True
         if not flag.value:
             return True
@@ -295,14 +334,6 @@ class NeuMesh(nn.Module):
                     self._scalars = (0.1, float(self.forward_s()))
             self._scalars_key = key
         return self._scalars
-
-    def __del__(self):
-        try:
-            if getattr(self, "_field", None):
-                _lib.load(require_device=False).nm_field_destroy(self._field)
-                self._field = None
-        except Exception:
-            pass
 
     # ------------------------------------------------------------------ fused (no-grad) paths
     _tile_cache = {}
@@ -350,10 +381,10 @@ class NeuMesh(nn.Module):
         t, keep = self.field_tables()
         with torch.cuda.device(q.device):
             for _attempt in range(2):
-                _lib.check(lib.nm_field_density(self.field_handle(), self.mesh_grid.grid.handle, C.byref(t), _lib.ptr(q), P,
+                _lib.check(lib.nm_field_density(self.field_handle(), self.grid_for(q.device).grid.handle, C.byref(t), _lib.ptr(q), P,
                                                 _lib.ptr(sdf), _lib.ptr(nab), _lib.ptr(scratch), _lib.current_stream(q.device)),
                            "nm_field_density")
-                if self.check_fp16_range():
+                if self.check_fp16_range(every=64):
                     break
         del keep
         if tile is not None:
@@ -378,10 +409,10 @@ class NeuMesh(nn.Module):
         t, keep = self.field_tables()
         with torch.cuda.device(dev):
             for _attempt in range(2):
-                _lib.check(lib.nm_field_forward(self.field_handle(), self.mesh_grid.grid.handle, C.byref(t), _lib.ptr(q), _lib.ptr(v), P,
+                _lib.check(lib.nm_field_forward(self.field_handle(), self.grid_for(q.device).grid.handle, C.byref(t), _lib.ptr(q), _lib.ptr(v), P,
                                                 _lib.ptr(sdf), _lib.ptr(rgb), _lib.ptr(nab), _lib.ptr(ds), _lib.ptr(idx), _lib.ptr(w),
                                                 _lib.ptr(scratch), _lib.current_stream(dev)), "nm_field_forward")
-                if self.check_fp16_range():
+                if self.check_fp16_range(every=64):
                     break
         del keep
         if tile is not None:
@@ -397,7 +428,7 @@ class NeuMesh(nn.Module):
     # ------------------------------------------------------------------ public API (reference names)
     def compute_distance(self, xyz):
         """neumesh.py:262-273."""
-        ds, indices, weights = self.mesh_grid.compute_distance(
+        ds, indices, weights = self.grid_for(xyz.device).compute_distance(
             xyz.reshape(-1, 3), indicator_vector=self.indicator_vector, indicator_weight=self._w1())
         lead = xyz.shape[:-1]
         return ds.reshape(*lead, -1), indices.reshape(*lead, -1), weights.reshape(*lead, -1)
@@ -472,7 +503,7 @@ class NeuMesh(nn.Module):
                     _lib.check(lib.nm_field_color(self.field_handle(), _lib.ptr(cf), _lib.ptr(dd), _lib.ptr(v), _lib.ptr(ii), _lib.ptr(ww),
                                                   _lib.ptr(nn_), P, _lib.ptr(rgb), _lib.ptr(scratch), _lib.current_stream(dev)),
                                "nm_field_color")
-                    if self.check_fp16_range():
+                    if self.check_fp16_range(every=64):
                         break
             return rgb.reshape(*lead, 3)
         return self._forward_color(self.embed_fn_d(d), view_dirs, color_features, indices, weights, nabla)

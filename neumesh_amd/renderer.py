@@ -10,8 +10,10 @@ kernels on the current stream, with no per-stage tensors materialised in Python.
 """
 from __future__ import annotations
 
+import copy
 import ctypes as C
 import os
+import threading
 from collections import OrderedDict
 from typing import Optional
 
@@ -112,20 +114,28 @@ class _Workspace:
 # NEUMESH_RENDER_STREAMS=1 restores the single-stream order.
 # Workspaces and side streams belong to one (device, caller stream) pair: calls issued on the same
 # stream are ordered by it (fork/join below), calls on different streams or devices never share scratch.
-_POOLS = {}
+_POOLS = OrderedDict()      # (device, caller stream) -> two workspaces; least recently used first
+_POOLS_LOCK = threading.Lock()
+_POOLS_MAX = 4              # pools kept (each holds up to two full-chunk workspaces): callers on many short-lived streams
+                            # (nn.DataParallel worker threads, per-request streams) must not accumulate them
 
 
 def _lanes_for(device, stream_handle: int):
     key = (device.index if device.index is not None else torch.cuda.current_device(), int(stream_handle or 0))
-    pool = _POOLS.get(key)
-    if pool is None:
-        pool = _POOLS[key] = [_Workspace(), _Workspace()]
+    with _POOLS_LOCK:
+        pool = _POOLS.pop(key, None)
+        if pool is None:
+            pool = [_Workspace(), _Workspace()]
+        _POOLS[key] = pool                      # most recently used last
+        while len(_POOLS) > _POOLS_MAX:
+            _POOLS.popitem(last=False)          # (its tensors are freed once the evicted call's own references go)
     return pool
 
 
 def release_workspaces():
     """Drop every cached render workspace (they are sized for the largest chunk seen: 56 KB per ray)."""
-    _POOLS.clear()
+    with _POOLS_LOCK:
+        _POOLS.clear()
 
 
 def _n_lanes() -> int:
@@ -153,6 +163,7 @@ def render_rays_fused(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int
     """rays_o / rays_d: [R,3] device tensors.  Returns dict of [R,...] tensors.  model: a NeuMesh, or a
     TextureEditableNeuMesh that fusable_edit_model() accepts (its blend then runs inside nm_render_rays)."""
     main, keep = model, []
+    cfg = copy.copy(cfg)   # (the edit_* pointers below are only valid during this call: the caller's struct stays untouched)
     if not isinstance(model, NeuMesh):
         main = model.main_model
         refs = list(model.ref_models)
@@ -174,7 +185,7 @@ def render_rays_fused(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int
         cfg.n_edit = 0
     models = [main] + (keep[2] if keep else [])
     out = _render_rays_fused(main, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress)
-    if not all([m.check_fp16_range() for m in models]):   # first call on a new weight set only: out of fp16 range -> fp32 kernels, once more
+    if not all([m.check_fp16_range() for m in models]):   # a value left the fp16 range during this call (sticky device flag): fp32 kernels, once more
         for i, r in enumerate(keep[2] if keep else []):
             cfg.edit_field[i] = getattr(r.field_handle(), "value", r.field_handle())
         out = _render_rays_fused(main, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress)
@@ -206,7 +217,7 @@ def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed,
     if ws_bytes < 0:
         _lib.check(1, "nm_render_workspace_bytes")
     starts = list(range(0, R, chunk))
-    field, grid = model.field_handle(), model.mesh_grid.grid.handle
+    field, grid = model.field_handle(), model.grid_for(dev).grid.handle
     t, keep = tables if tables is not None else model.field_tables()
     with torch.cuda.device(dev):
         main = torch.cuda.current_stream(dev)

@@ -232,3 +232,47 @@ def test_write_png_roundtrip(tmp_path):
         assert ihdr == (w, h, 8, 2 if ch == 3 else 0, 0, 0, 0)
         rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * ch)
         assert (rows[:, 0] == 0).all() and np.array_equal(rows[:, 1:].reshape(h, w, ch), img.reshape(h, w, ch))
+
+
+def test_data_parallel_replicas_never_free_the_parents_field_handle(monkeypatch):
+    """nn.DataParallel replicas (models/trainer.py:39-42) are shallow copies of the module: they must start without device
+    state of their own (packed-weight handle, cached scalars) and the parent's nm_field_t must be destroyed exactly once,
+    by its owner object, however many replicas come and go (double free through NeuMesh.__del__)."""
+    torch = pytest.importorskip("torch")
+    import gc
+    from neumesh_amd import neumesh as nmod
+    mesh = common.scene_mesh(3000)
+
+    class FakeGrid:
+        device = torch.device("cpu")
+
+        def get_number_of_vertices(self):
+            return 3000
+
+        def get_vertex_normal_torch(self):
+            return torch.from_numpy(mesh.vertex_normals)
+
+    destroyed = []
+
+    class FakeLib:
+        def nm_field_destroy(self, h):
+            destroyed.append(h)
+            return 0
+
+    monkeypatch.setattr(nmod._lib, "load", lambda require_device=True: FakeLib())
+    m = nmod.NeuMesh(FakeGrid(), **common.MODEL_CFG)
+    m._field = nmod.FieldHandle("HANDLE-0", torch.device("cpu"))
+    m._field_key, m._scalars_key = ("k",), ("s",)
+    assert not hasattr(nmod.NeuMesh, "__del__")          # ownership lives in FieldHandle alone
+    for _ in range(3):                                    # one forward's worth of replicas, garbage-collected afterwards
+        reps = [m._replicate_for_data_parallel() for _ in range(2)]
+        for r in reps:
+            assert r._field is None and r._field_key is None and r._scalars_key is None and r._is_replica
+            r._field = nmod.FieldHandle(f"REPLICA-{id(r)}", torch.device("cpu"))   # what field_handle() would build on the replica's device
+        del reps, r
+        gc.collect()
+    assert "HANDLE-0" not in destroyed and len(destroyed) == 6     # only the replicas' own handles went
+    assert m._field.h == "HANDLE-0"
+    del m
+    gc.collect()
+    assert destroyed.count("HANDLE-0") == 1
