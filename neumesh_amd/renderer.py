@@ -10,7 +10,6 @@ kernels on the current stream, with no per-stage tensors materialised in Python.
 """
 from __future__ import annotations
 
-import copy
 import ctypes as C
 import os
 import threading
@@ -163,7 +162,9 @@ def render_rays_fused(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int
     """rays_o / rays_d: [R,3] device tensors.  Returns dict of [R,...] tensors.  model: a NeuMesh, or a
     TextureEditableNeuMesh that fusable_edit_model() accepts (its blend then runs inside nm_render_rays)."""
     main, keep = model, []
-    cfg = copy.copy(cfg)   # (the edit_* pointers below are only valid during this call: the caller's struct stays untouched)
+    mine = _lib.RenderCfg()   # (the edit_* pointers below are only valid during this call: the caller's struct stays untouched)
+    C.memmove(C.byref(mine), C.byref(cfg), C.sizeof(_lib.RenderCfg))
+    cfg = mine
     if not isinstance(model, NeuMesh):
         main = model.main_model
         refs = list(model.ref_models)
