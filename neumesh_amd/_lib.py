@@ -100,8 +100,8 @@ SIGNATURES = {
     "nm_time_kernel": (C.c_int, [_P, _P, C.POINTER(FieldTables), C.c_int, _P, _P, C.c_int64, _P, C.c_int,
                                  C.POINTER(C.c_float), _P]),
 }
-# test hook, not part of the public header
-_EXTRA = {
+# test hooks of the -DNM_TESTING build (tests/_build/libneumesh_hip_testing.so): not in the product library, not in the header
+TESTING_SIGNATURES = {
     "nm_debug_phase_log": (C.c_int, [_P]),
     "nm_grid_create_host": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.POINTER(_P)]),
     "nm_grid_debug_export": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64]),
@@ -137,10 +137,14 @@ def load(require_device: bool = True):
             lib = C.CDLL(path)
         except OSError as e:  # e.g. libamdhip64 missing
             raise NeuMeshHipError(f"cannot load {path}: {e}") from e
-        for name, (res, args) in {**SIGNATURES, **_EXTRA}.items():
+        for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get("NEUMESH_HIP_LIB"):   # a measurement tool's own build may carry the hooks
+            for name, (res, args) in TESTING_SIGNATURES.items():
+                if hasattr(lib, name):
+                    getattr(lib, name).restype, getattr(lib, name).argtypes = res, args
         if lib.nm_abi_version() != ABI_VERSION:
             raise NeuMeshHipError(f"ABI mismatch: library {lib.nm_abi_version()} != binding {ABI_VERSION}")
         _lib = lib
@@ -150,9 +154,22 @@ def load(require_device: bool = True):
     return _lib
 
 
-def check(rc: int, what: str):
+def load_testing():
+    """The -DNM_TESTING library (product exports + test hooks) as its own ctypes object: for the tests of the hooks and the
+    measurement tools.  Handles are NOT interchangeable with those of the product library (two copies of the library state)."""
+    import torch  # noqa: F401  (its libamdhip64 first, see load())
+    path = _build.build_testing()
+    lib = C.CDLL(path)
+    for name, (res, args) in {**SIGNATURES, **TESTING_SIGNATURES}.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def check(rc: int, what: str, lib=None):
     if rc != 0:
-        msg = _lib.nm_last_error().decode("utf-8", "replace") if _lib is not None else "?"
+        src = lib if lib is not None else _lib
+        msg = src.nm_last_error().decode("utf-8", "replace") if src is not None else "?"
         raise NeuMeshHipError(f"{what}: {msg}")
 
 

@@ -22,9 +22,7 @@
 #include "nm_mlp_h2.h"
 #include "nm_edit.h"
 
-#ifndef NM_PROBE_STEP
 #define NM_PROBE_STEP 8  // probes per ray and step of nm_probe_bounds_kernel: 8 = 8 rays per wave (measured: K-NN per frame 99.9 ms with 4, 97.2 with 8, 101.7 with 16)
-#endif
 
 // ------------------------------------------------------------------------------ error state
 static thread_local std::string g_err;
@@ -173,8 +171,9 @@ int nm_grid_create(const float* verts_device, int64_t V, int leaf_level, nm_stre
     return 0;
 }
 
+#ifdef NM_TESTING   // ---- test hooks: only in the separate test / measurement library (neumesh_amd/build.py: build_testing)
 // Host build (nm_grid_build.h), the reference implementation the device build is checked against: device->host copy,
-// CPU sort, upload.  Test hook, not part of the public header.
+// CPU sort, upload.
 int nm_grid_create_host(const float* verts_device, int64_t V, int leaf_level, nm_stream_t stream_, nm_grid_t* out) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!out) return nm_fail("nm_grid_create: out is NULL");
@@ -225,6 +224,7 @@ int nm_grid_debug_export(nm_grid_t g, void* nodes_host, int64_t nodes_bytes, voi
     NM_HIP(hipMemcpy(sverts_host, g->view.sverts, (size_t)sverts_bytes, hipMemcpyDeviceToHost));
     return 0;
 }
+#endif  // NM_TESTING
 
 int nm_grid_destroy(nm_grid_t g) {
     if (!g) return 0;
@@ -844,12 +844,8 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     if (c->bounded_near_far) {  // renderer.py:66-102
         if (!(c->flags & NM_RENDER_FULL_PROBES)) {  // first / last hit only (nm_probe_bounds_kernel)
             NmProfScope prof(NM_K_DISTANCE, 0, stream, NM_CNT_PROBE);  // units = probes actually searched (device counter)
-            if (NM_PROBE_STEP == 8)
-                hipLaunchKernelGGL(nm_probe_bounds_kernel<8>, dim3(nm_blocks((R + 7) / 8, 4)), dim3(256), 0, stream, g->view, rays_o, ws.dirn, ws.nf0,
-                                   (long long)R, c->probe_grid, c->probe_thresh, g->verts, t->indicator_vector, t->indicator_weight, ws.nf,
-                                   nm_prof_counter(NM_CNT_PROBE));
-            else
-                hipLaunchKernelGGL(nm_probe_bounds_kernel<4>, dim3(nm_blocks((R + 15) / 16, 4)), dim3(256), 0, stream, g->view, rays_o, ws.dirn, ws.nf0,
+            static_assert(NM_PROBE_STEP == 8, "launch geometry below is for 8 probes per ray and step");
+            hipLaunchKernelGGL(nm_probe_bounds_kernel<8>, dim3(nm_blocks((R + 7) / 8, 4)), dim3(256), 0, stream, g->view, rays_o, ws.dirn, ws.nf0,
                                    (long long)R, c->probe_grid, c->probe_thresh, g->verts, t->indicator_vector, t->indicator_weight, ws.nf,
                                    nm_prof_counter(NM_CNT_PROBE));
             NM_LAUNCH_CHECK();
@@ -1221,17 +1217,14 @@ int nm_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* unit
     return 0;
 }
 
-// debug: install (or clear, with NULL) the device buffer the MLP kernels write phase timestamps to
+#ifdef NM_TESTING
+// test library only: install (or clear, with NULL) the device buffer the MLP kernels write phase timestamps to
 int nm_debug_phase_log(void* device_buf_32x16_i64) {
-#ifdef NM_PHASE_STAMPS
     long long* p = (long long*)device_buf_32x16_i64;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_nm_phase_log), &p, sizeof(p)) != hipSuccess) return nm_fail("nm_debug_phase_log: hipMemcpyToSymbol failed");
     return 0;
-#else
-    (void)device_buf_32x16_i64;
-    return nm_fail("nm_debug_phase_log: this build has no phase stamps (build with -DNM_PHASE_STAMPS, see tools/mlp_phases.py)");
-#endif
 }
+#endif
 
 int nm_time_kernel(nm_field_t f, nm_grid_t g, const nm_field_tables* t, int which, const float* xyz, const float* view_dirs,
                    int64_t P, void* scratch, int iters, float* avg_ms, nm_stream_t stream_) {
@@ -1242,18 +1235,7 @@ int nm_time_kernel(nm_field_t f, nm_grid_t g, const nm_field_tables* t, int whic
     const NmScratch s = nm_carve(scratch, P);
     const NmGather ga = {t->geometry_features, f->geo.gdim, s.fg, t->color_features, f->col.cdim, s.ft};
     // inputs of the MLP kernels come from one K-NN pass
-#ifdef NM_EXP_GATHER
-    if (nm_launch_distance(g, nm_src_xyz(xyz, P), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx, nullptr, s.w, s.grad, stream, nullptr, ga)) return 1;
-    {
-        const int* pi = s.idx; const float* pw = s.w; const float* pt = t->geometry_features;
-        NM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_nm_exp_idx), &pi, sizeof(pi), 0, hipMemcpyHostToDevice, stream));
-        NM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_nm_exp_w), &pw, sizeof(pw), 0, hipMemcpyHostToDevice, stream));
-        NM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_nm_exp_tab), &pt, sizeof(pt), 0, hipMemcpyHostToDevice, stream));
-        NM_HIP(hipStreamSynchronize(stream));
-    }
-#else
     if (nm_launch_distance(g, nm_src_xyz(xyz, P), P, t->indicator_vector, t->indicator_weight, s.ds, nullptr, nullptr, nullptr, s.grad, stream, nullptr, ga)) return 1;
-#endif
     if (which == 3 && nm_launch_geo(f, s.fg, s.ds, s.grad, P, true, nullptr, 1, 1, 0, s.nabla, stream)) return 1;
     hipEvent_t e0, e1;
     NM_HIP(hipEventCreate(&e0));
@@ -1283,7 +1265,8 @@ int nm_time_kernel(nm_field_t f, nm_grid_t g, const nm_field_tables* t, int whic
     return rc;
 }
 
-// Device self-check hook (tests only): the geometry / colour MLP computed with the scalar-ALU
+#ifdef NM_TESTING
+// Device self-check hook (test library only): the geometry / colour MLP computed with the scalar-ALU
 // reference layer instead of the MFMA tile code, same inputs, same outputs.  valu_tmp: device
 // buffer of ceil(P/32) * 64*256 floats.
 int nm_selfcheck_field(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const float* xyz, const float* view_dirs,
@@ -1302,5 +1285,6 @@ int nm_selfcheck_field(nm_field_t f, nm_grid_t g, const nm_field_tables* t, cons
     NM_LAUNCH_CHECK();
     return 0;
 }
+#endif  // NM_TESTING
 
 }  // extern "C"

@@ -77,9 +77,8 @@ __device__ __forceinline__ void nm_fetch_point(const NmPointSrc& s, long long r,
 }
 
 #define NM_KNN_BLOCK 256   // threads per workgroup of every kernel that runs the K-NN traversal (the leaf stage in LDS is sized by it)
-#ifndef NM_KNN_WAVES
-#define NM_KNN_WAVES 6   // waves per SIMD the K-NN kernels are compiled for (register budget 512 / NM_KNN_WAVES)
-#endif
+#define NM_KNN_WAVES 6     // waves per SIMD the K-NN kernels are compiled for (register budget 512 / NM_KNN_WAVES; measured round 3: 4 and 6 tie,
+                           // 3 is 13 % slower -- the kernels are bound by vector-instruction issue, not by the scratch traffic of the 80-register budget)
 
 // ------------------------------------------------------------ wave-cooperative K-NN search
 // The 64 queries of a wave are neighbours in space (consecutive samples of adjacent rays), so

@@ -32,11 +32,11 @@
 
 typedef float nm_f32x16 __attribute__((ext_vector_type(16)));
 
-// Debug hook, compiled in only with -DNM_PHASE_STAMPS (tools/mlp_phases.py builds such a library):
+// Debug hook, compiled in only with -DNM_TESTING (the separate test / measurement library, neumesh_amd/build.py):
 // workgroups 4096..4127 of an MLP launch record the shader clock at their phase boundaries (slot 0
 // start, 1 after the prologue, then after each layer's MFMA loop and after its epilogue, last = end),
 // 16 stamps per workgroup.  The production build has no trace of it.
-#ifdef NM_PHASE_STAMPS
+#ifdef NM_TESTING
 __device__ long long* g_nm_phase_log = nullptr;
 __device__ __forceinline__ void nm_phase_stamp(int slot) {
     long long* log = g_nm_phase_log;

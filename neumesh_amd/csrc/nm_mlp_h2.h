@@ -52,9 +52,6 @@ typedef _Float16 nm_h2 __attribute__((ext_vector_type(2)));
 
 #define NM_H_STRIDE 264  // halves per tile row: 528 B = 33 16-byte slots -> conflict-free ds_read_b128
 #define NM_H_PLANE (NM_ROWS * NM_H_STRIDE)
-#ifndef NM_EXP_LDS_PAD
-#define NM_EXP_LDS_PAD 0  // experiments: extra LDS halves per workgroup (forces 1 workgroup per CU)
-#endif
 
 struct NmLayerH {
     const _Float16* W;  // packed fragments: [col tile 8][k-step Kpad/16][plane 2][lane 64][8 halves]
@@ -88,12 +85,6 @@ struct NmAccH {  // 2 row tiles x CT column tiles of a wave, main and 2^11-scale
     nm_f32x16 hi[2][CT], lo[2][CT];
 };
 
-#ifndef NM_H2_DEPTH0
-#define NM_H2_DEPTH0 2   // layer-0 B-fragment prefetch distance of the tangent kernel (<= NM_H2_PRE)
-#endif
-#ifndef NM_H2_EARLY_LOADS
-#define NM_H2_EARLY_LOADS 0  // record loads issued without waiting for the list entry (measured: no gain)
-#endif
 #define NM_H2_BIAS_LAYERS 4  // biases of the first 4 layers live in LDS (deeper layers read them from L2)
 #define NM_H2_FP16_MAX 65504.0f
 
@@ -132,12 +123,6 @@ __global__ void nm_scale_copy_kernel(const float* __restrict__ src, float scale,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i] * scale;
 }
-
-#ifdef NM_EXP_GATHER
-__device__ const int* g_nm_exp_idx = nullptr;
-__device__ const float* g_nm_exp_w = nullptr;
-__device__ const float* g_nm_exp_tab = nullptr;
-#endif
 
 struct NmGeoParamsH2 {
     NmLayerH layer[NM_MAX_LAYERS];  // log2 units (nm_softplus_l2): layer 0 weights and every bias x S
@@ -574,7 +559,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
     NmGeoParamsH2 prm, const float* __restrict__ fg_rec, const float* __restrict__ ds, const float* __restrict__ grad, NmRecMap rmap,
     long long npts, float* __restrict__ sdf_out, int P, int stride, int off, float* __restrict__ nabla_out, int nabla_slotted,
     NmSlotMap smap, int* __restrict__ overflow) {
-    __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE + NM_EXP_LDS_PAD];
+    __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE];
     __shared__ __attribute__((aligned(16))) float cst[(NM_H2_BIAS_LAYERS + 1) * NM_W];  // biases of layers 0..3 | density weights
     __shared__ float red[4 * NM_ROWS];
     constexpr int PTS = NABLA ? 32 : 64;
@@ -601,7 +586,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
         }
     };
     nm_phase_stamp(0);
-    constexpr int DEPTH0 = (FIXED && NABLA) ? NM_H2_DEPTH0 : 2;  // layer-0 prefetch distance (nm_kloop_h2); the rolled loops use one set
+    constexpr int DEPTH0 = 2;  // layer-0 prefetch distance (nm_kloop_h2); the rolled loops use one set
     NmBPre<NM_H_CT> pre;
     nm_prefetch_bn<NM_H_CT, NP>(prm.layer[0], pre, DEPTH0);  // in flight during the input phase
     const int gdim = FIXED ? 32 : prm.gdim, mfg = FIXED ? 2 : prm.multires_fg, md = FIXED ? 8 : prm.multires_d;
@@ -613,9 +598,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
     float in_ds[ROUNDS];
     float4 in_fg[ROUNDS][2];
     bool in_ok[ROUNDS];
-    // all global loads of the input phase first (both task rounds), then the constants, then the embedding work.
-    // The record loads do not wait for the list entry that says whether the position holds a point (padding
-    // positions have allocated, unused records): one memory round trip instead of two dependent ones.
+    // all global loads of the input phase first (both task rounds), then the constants, then the embedding work
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
         const int task = threadIdx.x + rd * NM_H_THREADS;
@@ -623,30 +606,12 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
         in_ds[rd] = 0.f;
         in_fg[rd][0] = in_fg[rd][1] = make_float4(0.f, 0.f, 0.f, 0.f);
         in_ok[rd] = base + p < npts && nm_slot_valid(smap, base + p);
-        if ((NM_H2_EARLY_LOADS && !by_list) ? (base + p < npts) : in_ok[rd]) {
+        if (in_ok[rd]) {
             long long rq, unused_o;
             locate(p, rq, unused_o);
             in_ds[rd] = ds[rq];
-#ifdef NM_EXP_GATHER  // A/B (tools/mlp_ab.py): the input phase gathers and interpolates the 8 code rows itself from idx / w records
-          if (g_nm_exp_idx) {
-            const int myi = g_nm_exp_idx[rq * 8 + j];
-            const float myw = g_nm_exp_w[rq * 8 + j];
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int l0 = (threadIdx.x & 63) & ~7;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int ik = __shfl(myi, l0 | k);
-                const float wk = __shfl(myw, l0 | k);
-                const float4 r = *reinterpret_cast<const float4*>(g_nm_exp_tab + (size_t)ik * gdim + 4 * j);
-                acc.x = fmaf(r.x, wk, acc.x); acc.y = fmaf(r.y, wk, acc.y); acc.z = fmaf(r.z, wk, acc.z); acc.w = fmaf(r.w, wk, acc.w);
-            }
-            in_fg[rd][0] = acc;
-          } else
-#endif
-          {
             if (j < nchunk) in_fg[rd][0] = *reinterpret_cast<const float4*>(fg_rec + rq * gdim + 4 * j);
             if (j + 8 < nchunk) in_fg[rd][1] = *reinterpret_cast<const float4*>(fg_rec + rq * gdim + 4 * (j + 8));
-          }
         }
     }
     nm_phase_stamp(10);
@@ -748,7 +713,7 @@ template <bool FIXED, int NP>
 __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_h2_kernel(
     NmColParamsH2 prm, const float* __restrict__ ft_rec, const float* __restrict__ ds, const float* __restrict__ nabla,
     const float* __restrict__ dirs, int dir_div, long long npts, float* __restrict__ rgb_out, NmSlotMap smap, int* __restrict__ overflow) {
-    __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE + NM_EXP_LDS_PAD];
+    __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE];
     __shared__ __attribute__((aligned(16))) float cst[(NM_H2_BIAS_LAYERS + 3) * NM_W];  // biases of layers 0..3 | rgb weights [3][256]
     __shared__ float red[4 * NM_ROWS * 3];
     const long long base = (long long)blockIdx.x * NM_ROWS;
@@ -771,7 +736,6 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
     float in_dv[ROUNDS][3];
     float4 in_ft[ROUNDS][2];
     bool in_ok[ROUNDS];
-    // (record loads independent of the list entry, as in the geometry kernel; only the ray's direction needs it)
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
         const int task = threadIdx.x + rd * NM_H_THREADS;
@@ -781,7 +745,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
         in_dv[rd][0] = in_dv[rd][1] = in_dv[rd][2] = 0.f;
         in_ft[rd][0] = in_ft[rd][1] = make_float4(0.f, 0.f, 0.f, 0.f);
         in_ok[rd] = q < npts && nm_slot_valid(smap, q);
-        if (NM_H2_EARLY_LOADS ? (q < npts) : in_ok[rd]) {
+        if (in_ok[rd]) {
             in_ds[rd] = ds[q];
             if (use_nabla && j >= 3 && j < 6) in_x[rd] = nabla[q * 3 + (j - 3)];
             if (j < nchunk) in_ft[rd][0] = *reinterpret_cast<const float4*>(ft_rec + q * cdim + 4 * j);

@@ -26,9 +26,7 @@
 // sigmoids, correctly rounded divisions) is independent from one interval to the next.  Unrolled by four, the scheduler
 // interleaves those chains (one lane per ray, two waves per CU: the kernels are bound by instruction latency).  The
 // arithmetic and its order are unchanged.
-#ifndef NM_RAY_UNROLL
 #define NM_RAY_UNROLL 4
-#endif
 #define NM_STR2(x) #x
 #define NM_STR(x) NM_STR2(x)
 #if defined(__HIPCC__)

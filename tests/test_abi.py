@@ -34,6 +34,19 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(_lib.SIGNATURES) == names
 
 
+def test_product_library_has_no_test_hooks():
+    """The hooks (host octree build / export, scalar-ALU self-check, phase stamps) live in the -DNM_TESTING build under
+    tests/_build/ only (VERDICT r2 hygiene): the product library exports exactly the header's symbols."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", build.build()], capture_output=True, text=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("nm_"))
+    assert exported == _declared(), set(exported) ^ set(_declared())
+    tlib = ctypes.CDLL(build.build_testing())
+    for n in _lib.TESTING_SIGNATURES:
+        assert hasattr(tlib, n) and n not in exported
+    assert "tests/_build" in build.TESTING_LIB_PATH
+
+
 def test_abi_version_and_error_string():
     lib = _lib.load(require_device=False)
     assert lib.nm_abi_version() == _lib.ABI_VERSION

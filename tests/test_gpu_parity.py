@@ -194,8 +194,8 @@ def test_mfma_tile_code_equals_scalar_alu_reference(small, cuda_device, torch_mo
     plain per-thread fmaf loop (asymmetric weights/activations => a transposed tile would fail)."""
     torch = torch_mod
     from neumesh_amd import _lib
-    lib = _lib.load()
-    _, _, model = small
+    lib = _lib.load_testing()         # nm_selfcheck_field is a test hook: only the -DNM_TESTING build of the library has it
+    _, _, model = small               # (the handles are plain structs of device pointers: the product library's work here too)
     model.mlp_precision = "fp32"      # this test is about the fp32 MFMA tile code
     fx = common.golden("field_v3000")
     q, dirs = _t(fx["q"], cuda_device), _t(fx["dirs"], cuda_device)
@@ -206,7 +206,7 @@ def test_mfma_tile_code_equals_scalar_alu_reference(small, cuda_device, torch_mo
     t, keep = model.field_tables()
     _lib.check(lib.nm_selfcheck_field(model.field_handle(), model.mesh_grid.grid.handle, C.byref(t), _lib.ptr(q), _lib.ptr(dirs), P,
                                       _lib.ptr(sdf), _lib.ptr(nab), _lib.ptr(rgb), _lib.ptr(scratch), _lib.ptr(tmp),
-                                      _lib.current_stream(cuda_device)), "nm_selfcheck_field")
+                                      _lib.current_stream(cuda_device)), "nm_selfcheck_field", lib)
     with torch.no_grad():
         sdf_m, rgb_m = model.forward(q, dirs)
         _, nab_m = model.forward_with_nablas(q)
@@ -1119,7 +1119,7 @@ def test_device_octree_build_is_bit_identical_to_host_build(cuda_device, torch_m
     two clusters far apart) and non-finite input."""
     torch = torch_mod
     from neumesh_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_testing()   # host build + export are test hooks of the -DNM_TESTING library (same sources as the product's)
     st = _lib.current_stream(cuda_device)
     rng = np.random.default_rng(3)
 

@@ -139,7 +139,7 @@ def main():
     @section("mfma_vs_valu_selfcheck")
     def t_self():
         import ctypes as C
-        lib = _lib.load()
+        lib = _lib.load_testing()   # nm_selfcheck_field: test hook of the -DNM_TESTING library
         P = q.shape[0]
         sdf = torch.empty((P,), device=dev); nab = torch.empty((P, 3), device=dev); rgb = torch.empty((P, 3), device=dev)
         scratch = torch.empty((int(lib.nm_field_scratch_bytes(P)),), dtype=torch.uint8, device=dev)

@@ -1,6 +1,6 @@
 """tools/mlp_ab.py -- GPU box: time the MLP kernels per precision mode (nm_time_kernel, 2^20 points) and
 print their field errors against the reference fixture; with --stamps also the per-phase shader-clock
-durations (builds a -DNM_PHASE_STAMPS copy of the library under tools/_build)."""
+durations (builds a -DNM_TESTING copy of the library under tools/_build)."""
 import ctypes as C, os, subprocess, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,7 @@ if stamps and "NEUMESH_HIP_LIB" not in os.environ:   # (a pre-built variant may 
     from neumesh_amd import build as nb
     out = os.path.join(ROOT, "tools", "_build", "libneumesh_hip_stamps.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    subprocess.check_call(["hipcc", *nb.FLAGS, "-DNM_PHASE_STAMPS", os.path.join(nb.CSRC, "nm_api.hip"), "-o", out])
+    subprocess.check_call(["hipcc", *nb.FLAGS, "-DNM_TESTING", os.path.join(nb.CSRC, "nm_api.hip"), "-o", out])
     os.environ["NEUMESH_HIP_LIB"] = out
 import torch
 import bench, common

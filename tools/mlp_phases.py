@@ -7,7 +7,7 @@ import torch
 import bench
 from neumesh_amd import _lib
 dev = torch.device("cuda", 0)
-lib = _lib.load()
+lib = _lib.load_testing()   # phase stamps exist in the -DNM_TESTING build only (its timed kernels write them)
 mesh, model = bench.build_scene(140000, dev)
 P = 1 << 20
 rng = np.random.default_rng(0)
