@@ -283,6 +283,32 @@ int nm_make_rays(const nm_camera* cam, int64_t first_pixel, int64_t count, float
 int nm_make_rays_indexed(const nm_camera* cam, const int64_t* pixels, int64_t count, float* rays_o,
                          float* rays_d, nm_stream_t stream);
 
+/* --------------------------------------------------------------------- first-hit surface points
+ * root_finding_surface_points of models/ray_casting.py:45-200 (with run_secant_method :12-38) for a NeuMesh field: N_steps
+ * proposals d_j = near (1 - t_j) + far t_j, t = linspace(0, 1, N_steps), val_j = sdf(o + d_j dir) - logit_tau; a ray's hit is
+ * its FIRST sign change of val, provided it goes from outside (> 0) to inside and val_0 > 0; the root is refined by
+ * n_secant_steps >= 0 regula-falsi steps (0 = the first secant estimate; -1 = the reference's behaviour for method != "secant":
+ * depth 1 at the hits).
+ *   rays_d: unit directions (surface_render normalises, :262).  near_far: [R][2] per-ray bounds, or NULL for cfg.near / cfg.far.
+ *   d_out [R]: hit depth; no hit: +inf (fill_inf) or the ray's far; 0 where the first proposal is already inside (:189-192).
+ *   pt_out [R][3]: o + d dir at the hits, (1,1,1) elsewhere (:177-180).  mask / mask_sign_change [R]: uint8.
+ * Same values as the reference (fp32, its operation order); a ray's proposals are only evaluated up to the block that holds
+ * its first sign change (nothing the routine returns depends on later ones).  The call reads the number of rays still walking
+ * back from the device after each block of 16 proposals: it SYNCHRONISES the stream (unlike every other entry point).
+ * workspace: nm_surface_workspace_bytes(field, R) bytes (rays are processed in internal chunks of 2^18). */
+typedef struct {
+    float near, far;          /* used when near_far == NULL */
+    int32_t N_steps;          /* 256 in the reference */
+    float logit_tau;
+    int32_t n_secant_steps;   /* 8 in the reference; -1: no secant method */
+    int32_t fill_inf;
+    float scene_radius;       /* only orders the rays in space (any positive value gives the same results) */
+} nm_surface_cfg;
+int64_t nm_surface_workspace_bytes(nm_field_t field, int64_t R);
+int nm_surface_hits(nm_field_t field, nm_grid_t grid, const nm_field_tables* tables, const float* rays_o, const float* rays_d,
+                    int64_t R, const float* near_far, const nm_surface_cfg* cfg, float* d_out, float* pt_out, uint8_t* mask,
+                    uint8_t* mask_sign_change, void* workspace, nm_stream_t stream);
+
 /* ----------------------------------------------------------------------------- image assembly
  * What render.py:219-249 does on the host with the three outputs of a frame, per pixel, on the device
  * (the frame then leaves the GPU as 7 bytes per pixel instead of 28):

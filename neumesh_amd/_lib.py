@@ -58,6 +58,11 @@ class Camera(C.Structure):
                 ("sk", C.c_float), ("H", C.c_int32), ("W", C.c_int32)]
 
 
+class SurfaceCfg(C.Structure):
+    _fields_ = [("near", C.c_float), ("far", C.c_float), ("N_steps", C.c_int32), ("logit_tau", C.c_float), ("n_secant_steps", C.c_int32),
+                ("fill_inf", C.c_int32), ("scene_radius", C.c_float)]
+
+
 class RenderDebug(C.Structure):
     _fields_ = [("near_far", C.c_void_p), ("d_all", C.c_void_p), ("sdf_all", C.c_void_p),
                 ("nablas_all", C.c_void_p), ("radiance", C.c_void_p), ("sdf_coarse", C.c_void_p)]
@@ -94,6 +99,8 @@ SIGNATURES = {
     "nm_rays_composite": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
     "nm_make_rays": (C.c_int, [C.POINTER(Camera), C.c_int64, C.c_int64, _P, _P, _P]),
     "nm_make_rays_indexed": (C.c_int, [C.POINTER(Camera), _P, C.c_int64, _P, _P, _P]),
+    "nm_surface_workspace_bytes": (C.c_int64, [_P, C.c_int64]),
+    "nm_surface_hits": (C.c_int, [_P, _P, C.POINTER(FieldTables), _P, _P, C.c_int64, _P, C.POINTER(SurfaceCfg), _P, _P, _P, _P, _P, _P]),
     "nm_assemble_frame": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P]),
     "nm_profile_enable": (C.c_int, [C.c_int]),
     "nm_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -5,6 +5,7 @@
 // are written explicitly (fmaf / MFMA) where they are wanted.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>  // library primitive for the one plain sort of the path (ray order)
+#include <rocprim/device/device_select.hpp>      // stable compaction of the walking-ray list (nm_surface_hits)
 
 #include <atomic>
 #include <cstdarg>
@@ -20,6 +21,7 @@
 #include "nm_kernels.h"
 #include "nm_mlp.h"
 #include "nm_mlp_h2.h"
+#include "nm_surface.h"
 #include "nm_edit.h"
 
 #define NM_PROBE_STEP 8  // probes per ray and step of nm_probe_bounds_kernel: 8 = 8 rays per wave (measured: K-NN per frame 99.9 ms with 4, 97.2 with 8, 101.7 with 16)
@@ -1041,6 +1043,154 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
         if (dbg->nablas_all && c->calc_normal) rows_out(ws.nab_pts, 3 * N, 3 * N, dbg->nablas_all);
         if (dbg->radiance) rows_out(ws.rgb_mid, 3 * (N - 1), 3 * (N - 1), dbg->radiance);
         NM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// ============================================================================ first-hit surface points
+// models/ray_casting.py:45-200 for a NeuMesh field (nm_surface.h).  The host loop below sizes every launch by the number of rays
+// still walking, which it reads back after each block of NM_SURF_BLOCK proposals: this entry point synchronises the stream
+// (N_steps / 16 times + once per chunk); everything between is stream-ordered.
+#define NM_SURF_CHUNK (1 << 18)   // rays per internal chunk (records of a walk step: 136 B per ray and proposal)
+struct NmSurfWs {
+    NmSurfState st;
+    int *ids_a, *ids_b, *count, *perm_in, *perm;
+    unsigned *key_in, *key_out;
+    unsigned char *keep, *hit;
+    float *nearfar, *ds, *fg, *val, *d_pred, *xyz;
+    void *sel_tmp, *sort_tmp;
+    size_t sel_tmp_bytes, sort_tmp_bytes, bytes;
+};
+static NmSurfWs nm_surf_carve(void* base, long long Rc, int gdim) {
+    NmSurfWs w;
+    memset(&w, 0, sizeof(w));
+    char* p = (char*)base;
+    size_t o = 0;
+    auto take = [&](size_t n) { char* q = p ? p + o : nullptr; o += nm_align(n); return (void*)q; };
+    const size_t R = (size_t)Rc;
+    w.st.idx = (int*)take(R * 4);
+    w.st.f_high = (float*)take(R * 4); w.st.f_low = (float*)take(R * 4); w.st.d_high = (float*)take(R * 4); w.st.d_low = (float*)take(R * 4);
+    w.st.val0 = (float*)take(R * 4); w.st.prev = (float*)take(R * 4);
+    w.ids_a = (int*)take(R * 4); w.ids_b = (int*)take(R * 4); w.count = (int*)take(256);
+    w.perm_in = (int*)take(R * 4); w.perm = (int*)take(R * 4); w.key_in = (unsigned*)take(R * 4); w.key_out = (unsigned*)take(R * 4);
+    w.keep = (unsigned char*)take(R); w.hit = (unsigned char*)take(R);
+    w.nearfar = (float*)take(R * 8);
+    w.ds = (float*)take(R * NM_SURF_BLOCK * 4);
+    w.fg = (float*)take(R * NM_SURF_BLOCK * (size_t)gdim * 4);
+    w.val = (float*)take(R * NM_SURF_BLOCK * 4);
+    w.d_pred = (float*)take(R * 4); w.xyz = (float*)take(R * 12);
+    (void)rocprim::select(nullptr, w.sel_tmp_bytes, (const int*)nullptr, (const unsigned char*)nullptr, (int*)nullptr, (int*)nullptr, R);
+    (void)rocprim::radix_sort_pairs(nullptr, w.sort_tmp_bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr, (int*)nullptr, R, 0, 30);
+    w.sel_tmp = take(w.sel_tmp_bytes);
+    w.sort_tmp = take(w.sort_tmp_bytes);
+    w.bytes = o;
+    return w;
+}
+__global__ void nm_surf_fill_nearfar_kernel(long long R, const float* __restrict__ src, float near_s, float far_s, float* __restrict__ dst) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    dst[2 * r] = src ? src[2 * r] : near_s;
+    dst[2 * r + 1] = src ? src[2 * r + 1] : far_s;
+}
+__global__ void nm_surf_hit_by_pos_kernel(const int* __restrict__ ids, int n, const unsigned char* __restrict__ hit_by_ray, unsigned char* __restrict__ flag) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < n) flag[a] = hit_by_ray[ids[a]];
+}
+
+static int nm_check_surface_cfg(const nm_surface_cfg* c) {
+    if (!c) return nm_fail("nm_surface: cfg is NULL");
+    if (c->N_steps < 2 || c->N_steps > 65536) return nm_fail("nm_surface: N_steps=%d out of [2,65536]", c->N_steps);
+    if (c->n_secant_steps < -1 || c->n_secant_steps > 64) return nm_fail("nm_surface: n_secant_steps=%d out of [-1,64]", c->n_secant_steps);
+    return 0;
+}
+int64_t nm_surface_workspace_bytes(nm_field_t f, int64_t R) {
+    if (!f || R < 1) return -1;
+    return (int64_t)nm_surf_carve(nullptr, std::min<long long>(R, NM_SURF_CHUNK), f->geo.gdim).bytes;
+}
+
+int nm_surface_hits(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const float* rays_o, const float* rays_d, int64_t R,
+                    const float* near_far, const nm_surface_cfg* c, float* d_out, float* pt_out, uint8_t* mask, uint8_t* mask_sign_change,
+                    void* workspace, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (nm_check_field_args(f, g, t, "nm_surface_hits") || nm_check_surface_cfg(c)) return 1;
+    if (R < 0 || (R > 0 && (!rays_o || !rays_d || !d_out || !pt_out || !mask || !mask_sign_change || !workspace))) return nm_fail("nm_surface_hits: bad arguments");
+    const int N = c->N_steps;
+    const NmGather ga_none = NM_NO_GATHER;
+    (void)ga_none;
+    for (int64_t c0 = 0; c0 < R; c0 += NM_SURF_CHUNK) {
+        const long long Rc = std::min<long long>(R - c0, NM_SURF_CHUNK);
+        const NmSurfWs ws = nm_surf_carve(workspace, std::min<long long>(R, NM_SURF_CHUNK), f->geo.gdim);
+        const float* ro = rays_o + 3 * c0;
+        const float* rd = rays_d + 3 * c0;
+        const dim3 rg(nm_blocks(Rc, 256)), rb(256);
+        hipLaunchKernelGGL(nm_surf_fill_nearfar_kernel, rg, rb, 0, stream, Rc, near_far ? near_far + 2 * c0 : (const float*)nullptr, c->near, c->far, ws.nearfar);
+        hipLaunchKernelGGL(nm_surf_init_kernel, rg, rb, 0, stream, Rc, ws.st, (int*)nullptr);
+        // walking order: rays sorted by the Morton code of their closest approach to the scene centre (as nm_render_rays), so that the
+        // 16 consecutive rays of a distance-kernel tile are neighbours in space; the stable compaction below keeps that order
+        hipLaunchKernelGGL(nm_ray_keys_kernel, rg, rb, 0, stream, ro, rd, Rc, 1.0f / fmaxf(c->scene_radius, 1e-6f), ws.key_in, ws.perm_in);
+        NM_LAUNCH_CHECK();
+        {
+            size_t tmp = ws.sort_tmp_bytes;
+            NM_HIP(rocprim::radix_sort_pairs(ws.sort_tmp, tmp, (const unsigned*)ws.key_in, ws.key_out, (const int*)ws.perm_in, ws.perm, (size_t)Rc, 0, 30, stream));
+        }
+        NM_HIP(hipMemcpyAsync(ws.ids_a, ws.perm, (size_t)Rc * 4, hipMemcpyDeviceToDevice, stream));
+        int* ids = ws.ids_a;
+        int* ids_next = ws.ids_b;
+        int nA = (int)Rc;
+        for (int k0 = 0; k0 < N && nA > 0; k0 += NM_SURF_BLOCK) {
+            const int n = std::min(NM_SURF_BLOCK, N - k0);
+            NmPointSrc src;
+            memset(&src, 0, sizeof(src));
+            src.mode = 2;
+            src.P = n;
+            src.rays_o = ro;
+            src.dirn = rd;
+            src.nearfar = ws.nearfar;
+            src.ray_index = ids;
+            src.p_off = k0;
+            src.p_total = N;
+            src.chain = 1;   // (chained, warm-started tiles measured slower here: 231 / 205 / 183 ms per frame with 4 / 2 / 1 tiles per wave --
+                             //  a block is only 16 proposals long, and four times as many short waves fill the chip better)
+            const NmGather ga = {t->geometry_features, f->geo.gdim, ws.fg, nullptr, 0, nullptr};
+            if (nm_launch_distance(g, src, (long long)nA * n, t->indicator_vector, t->indicator_weight, ws.ds, nullptr, nullptr, nullptr, nullptr, stream, nullptr, ga)) return 1;
+            if (nm_launch_geo(f, ws.fg, ws.ds, nullptr, (long long)nA * n, false, ws.val, 1, 1, 0, nullptr, stream)) return 1;
+            hipLaunchKernelGGL(nm_surf_scan_kernel, dim3(nm_blocks(nA, 256)), dim3(256), 0, stream, (const int*)ids, nA, (const float*)ws.val, n, k0, N, c->logit_tau,
+                               (const float*)ws.nearfar, 0.f, 0.f, ws.st, ws.keep);
+            NM_LAUNCH_CHECK();
+            if (k0 + n >= N) break;
+            size_t tmp = ws.sel_tmp_bytes;
+            NM_HIP(rocprim::select(ws.sel_tmp, tmp, (const int*)ids, (const unsigned char*)ws.keep, ids_next, ws.count, (size_t)nA, stream));
+            int cnt = 0;
+            NM_HIP(hipMemcpyAsync(&cnt, ws.count, sizeof(int), hipMemcpyDeviceToHost, stream));
+            NM_HIP(hipStreamSynchronize(stream));
+            nA = cnt;
+            std::swap(ids, ids_next);
+        }
+        // ---- the hits, in walking order; secant refinement on them
+        hipLaunchKernelGGL(nm_surf_hit_flags_kernel, rg, rb, 0, stream, Rc, ws.st, ws.hit, ws.perm_in);
+        hipLaunchKernelGGL(nm_surf_hit_by_pos_kernel, rg, rb, 0, stream, (const int*)ws.perm, (int)Rc, (const unsigned char*)ws.hit, ws.keep);
+        NM_LAUNCH_CHECK();
+        int nH = 0;
+        if (c->n_secant_steps > 0) {
+            size_t tmp = ws.sel_tmp_bytes;
+            NM_HIP(rocprim::select(ws.sel_tmp, tmp, (const int*)ws.perm, (const unsigned char*)ws.keep, ws.ids_a, ws.count, (size_t)Rc, stream));
+            NM_HIP(hipMemcpyAsync(&nH, ws.count, sizeof(int), hipMemcpyDeviceToHost, stream));
+            NM_HIP(hipStreamSynchronize(stream));
+        }
+        for (int it = 0; it < c->n_secant_steps && nH > 0; ++it) {
+            hipLaunchKernelGGL(nm_surf_secant_points_kernel, dim3(nm_blocks(nH, 256)), dim3(256), 0, stream, (const int*)ws.ids_a, nH, ws.st, ro, rd, ws.d_pred, ws.xyz);
+            NM_LAUNCH_CHECK();
+            const NmGather ga = {t->geometry_features, f->geo.gdim, ws.fg, nullptr, 0, nullptr};
+            if (nm_launch_distance(g, nm_src_xyz(ws.xyz, nH), nH, t->indicator_vector, t->indicator_weight, ws.ds, nullptr, nullptr, nullptr, nullptr, stream, nullptr, ga)) return 1;
+            if (nm_launch_geo(f, ws.fg, ws.ds, nullptr, nH, false, ws.val, 1, 1, 0, nullptr, stream)) return 1;
+            hipLaunchKernelGGL(nm_surf_secant_update_kernel, dim3(nm_blocks(nH, 256)), dim3(256), 0, stream, (const int*)ws.ids_a, nH, ws.st, (const float*)ws.d_pred,
+                               (const float*)ws.val, c->logit_tau);
+            NM_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(nm_surf_finish_kernel, rg, rb, 0, stream, Rc, ws.st, (const unsigned char*)ws.hit, ro, rd, (const float*)ws.nearfar, 0.f,
+                           c->n_secant_steps >= 0 ? 1 : 0, c->fill_inf, d_out + c0, pt_out + 3 * c0, mask + c0, mask_sign_change + c0);
+        NM_LAUNCH_CHECK();
+        if (c0 + NM_SURF_CHUNK < R) NM_HIP(hipStreamSynchronize(stream));   // the next chunk reuses the workspace
     }
     return 0;
 }

@@ -41,6 +41,11 @@ struct NmPointSrc {
     // are bound by ONE wave's serial traversal, which for scattered queries grows with the number of lanes that walk their
     // own path: fewer queries per wave = more, shorter waves on a chip that has room for them.
     int lanes;
+    // modes 1, 2 (optional): ray r of this launch is ray ray_index[r] of the rays_o / dirn / nearfar arrays (a compacted list of
+    // rays, nm_surface_hits); depths / bounds / outputs stay indexed by the launch's own r
+    const int* ray_index;
+    // mode 2 (optional): the P samples are proposals p_off .. p_off + P - 1 of a p_total-point linspace (0 = the P points themselves)
+    int p_off, p_total;
 };
 
 // (r, p) = (ray, sample) of query q = r*P + p, as produced by nm_lane_query (mode 0: r = q, p = 0)
@@ -65,15 +70,16 @@ __device__ __forceinline__ void nm_fetch_point(const NmPointSrc& s, long long r,
         d = 0.f;
         return;
     }
+    const long long rr = s.ray_index ? (long long)s.ray_index[r] : r;
     if (s.mode == 1) {
         d = s.depth[r * s.dstride + s.doff + p];
     } else {
-        d = nm_lerp_depth(s.nearfar[2 * r], s.nearfar[2 * r + 1], nm_linspace01(p, s.P));
+        d = nm_lerp_depth(s.nearfar[2 * rr], s.nearfar[2 * rr + 1], s.p_total > 0 ? nm_linspace01(s.p_off + p, s.p_total) : nm_linspace01(p, s.P));
         if (s.depth_out) s.depth_out[r * s.dstride + s.doff + p] = d;
     }
-    x = nm_add(s.rays_o[3 * r], nm_mul(d, s.dirn[3 * r]));
-    y = nm_add(s.rays_o[3 * r + 1], nm_mul(d, s.dirn[3 * r + 1]));
-    z = nm_add(s.rays_o[3 * r + 2], nm_mul(d, s.dirn[3 * r + 2]));
+    x = nm_add(s.rays_o[3 * rr], nm_mul(d, s.dirn[3 * rr]));
+    y = nm_add(s.rays_o[3 * rr + 1], nm_mul(d, s.dirn[3 * rr + 1]));
+    z = nm_add(s.rays_o[3 * rr + 2], nm_mul(d, s.dirn[3 * rr + 2]));
 }
 
 #define NM_KNN_BLOCK 256   // threads per workgroup of every kernel that runs the K-NN traversal (the leaf stage in LDS is sized by it)

@@ -9,14 +9,16 @@ provides).  Here it works for both kinds of model: an object with ``implicit_sur
 is used exactly as the reference does, a NeuMesh field is queried through ``forward_density_only`` (the SDF) and
 its fused ``forward`` (SDF, radiance and nabla at the hit points in one HIP call).
 
-All field queries -- 256 proposals per ray, 8 secant refinements or 20 sphere-tracing steps -- run on the fused
-HIP kernels (K-NN + distance + gather + geometry MLP); the per-ray bookkeeping between them (first sign change,
-secant update) is a handful of element-wise device ops on [R] / [R,S] tensors, written with the reference's
-own arithmetic so that depths and masks agree with it value for value.  Everything is inference
-(torch.no_grad), as in the reference.
+For a NeuMesh field the whole root finding is ONE C call, ``nm_surface_hits`` (csrc/nm_surface.h): the proposals are walked
+in blocks of 16 per ray over the compacted list of rays that have not met their first sign change yet (K-NN + distance +
+code gather, then the geometry MLP), the secant steps run on the list of hits, all bookkeeping in kernels with the
+reference's own arithmetic -- depths and masks agree with the reference value for value.  Any other ``surface_query_fn``
+(a NeuS teacher, a wrapper model) takes the torch-op form below, which queries the function it is given in the same
+blocks.  Everything is inference (torch.no_grad), as in the reference.
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Union
 
@@ -46,6 +48,43 @@ def run_secant_method(f_low, f_high, d_low, d_high, rays_o_masked, rays_d_masked
 
 
 _EARLY_BLOCK = 32
+
+
+def _native_root_finding(surface, rays_o, rays_d, near, far, N_steps, logit_tau, method, N_secant_steps, fill_inf):
+    """nm_surface_hits for a _NeuMeshSurface (flattened rays [M,3]; near / far: floats or [M] tensors)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    model = surface.model
+    dev = rays_o.device
+    ro, rd = rays_o.reshape(-1, 3).float().contiguous(), rays_d.reshape(-1, 3).float().contiguous()
+    M = ro.shape[0]
+    cfg = _lib.SurfaceCfg()
+    cfg.N_steps, cfg.logit_tau, cfg.fill_inf, cfg.scene_radius = int(N_steps), float(logit_tau), int(bool(fill_inf)), 1.0
+    cfg.n_secant_steps = int(N_secant_steps) if method == "secant" else -1
+    nf = None
+    if isinstance(near, torch.Tensor) or isinstance(far, torch.Tensor):
+        ones = torch.ones(M, device=dev)
+        nf = torch.stack([(near.reshape(-1).float() if isinstance(near, torch.Tensor) else near * ones),
+                          (far.reshape(-1).float() if isinstance(far, torch.Tensor) else far * ones)], -1).contiguous()
+    else:
+        cfg.near, cfg.far = float(near), float(far)
+    d = torch.empty(M, device=dev)
+    pt = torch.empty((M, 3), device=dev)
+    mask = torch.empty(M, dtype=torch.uint8, device=dev)
+    msc = torch.empty(M, dtype=torch.uint8, device=dev)
+    field = model.field_handle()
+    ws = torch.empty(max(int(lib.nm_surface_workspace_bytes(field, max(M, 1))), 256), dtype=torch.uint8, device=dev)
+    t, keep = model.field_tables()
+    with torch.cuda.device(dev):
+        for _attempt in range(2):
+            _lib.check(lib.nm_surface_hits(field, model.grid_for(dev).grid.handle, C.byref(t), _lib.ptr(ro), _lib.ptr(rd), M, _lib.ptr(nf), C.byref(cfg),
+                                           _lib.ptr(d), _lib.ptr(pt), _lib.ptr(mask), _lib.ptr(msc), _lib.ptr(ws), _lib.current_stream(dev)), "nm_surface_hits")
+            if model.check_fp16_range():
+                break
+            field = model.field_handle()
+    del keep
+    return d, pt, mask.bool(), msc.bool()
 
 
 def _proposal_values_until_first_sign_change(surface_query_fn, rays_o, rays_d, d_proposal, logit_tau):
@@ -93,6 +132,14 @@ def root_finding_surface_points(surface_query_fn, rays_o: torch.Tensor, rays_d: 
             near = near.unsqueeze(0) if isinstance(near, torch.Tensor) else near
             far = far.unsqueeze(0) if isinstance(far, torch.Tensor) else far
         B, N_rays = rays_o.shape[0], rays_o.shape[-2]
+        native = (early_exit and isinstance(surface_query_fn, _NeuMeshSurface) and hasattr(surface_query_fn.model, "field_handle")
+                  and rays_o.is_cuda and not os.environ.get("NEUMESH_NO_SURFACE_KERNEL"))
+        if native:   # the whole routine as one C call (nm_surface_hits); same outputs as the torch-op form below
+            d_pred_out, pt_pred, mask, mask_sign_change = (x.reshape(B, N_rays, *x.shape[1:]) for x in _native_root_finding(
+                surface_query_fn, rays_o, rays_d, near, far, N_steps, logit_tau, method, N_secant_steps, fill_inf))
+            if not batched:
+                d_pred_out, pt_pred, mask, mask_sign_change = d_pred_out[0], pt_pred[0], mask[0], mask_sign_change[0]
+            return d_pred_out, pt_pred, mask, mask_sign_change
         t = torch.linspace(0.0, 1.0, N_steps, device=device)[None, None, :]
         if not isinstance(near, torch.Tensor):
             near = near * torch.ones(rays_o.shape[:-1], device=device)

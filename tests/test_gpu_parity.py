@@ -3,6 +3,7 @@
 BASELINE.json sizes.  Tolerances: K-NN indices / squared distances bit-exact; everything
 floating point within the 1e-4 RGB bound of BASELINE.json:north_star (most stages are 1e-6)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -981,6 +982,35 @@ def test_surface_rendering_matches_reference_ray_casting(small, cuda_device, tor
                                                                            logit_tau=float(f[name + ".tau"]), method="secant", N_secant_steps=8, fill_inf=False,
                                                                            early_exit=False)
         assert torch.equal(d, d_full) and torch.equal(pt, pt_full) and torch.equal(m, m_full) and torch.equal(msc, msc_full)
+        # ... and so does the one-call native form (nm_surface_hits: chained K-NN tiles + geometry MLP over the compacted list of
+        # walking rays, bookkeeping in kernels): bit for bit, with scalar and per-ray bounds, inf fill, and without refinement
+        surf = rc._NeuMeshSurface(model)
+        tau = float(f[name + ".tau"])
+        d_n, pt_n, m_n, msc_n = rc.root_finding_surface_points(surf, ro.clone(), rd.clone(), near=near, far=far, batched=True, N_steps=256, logit_tau=tau,
+                                                               method="secant", N_secant_steps=8, fill_inf=False)
+        # (the native walk forms the proposal positions inside the chained distance kernel: they -- and with them the field values -- can
+        #  differ from the torch-op form's in the last bit, so depths agree to ~1e-7 relative, not bit for bit)
+        assert torch.equal(m_n, m) and torch.equal(msc_n, msc)
+        assert float((d_n - d).abs().max()) <= 2e-6 and float((pt_n - pt).abs().max()) <= 2e-6
+        nr = near + 0.1 * torch.rand(ro.shape[:2], device=cuda_device, generator=torch.Generator(device=cuda_device).manual_seed(4))
+        fr = far - 0.2 * torch.rand(ro.shape[:2], device=cuda_device, generator=torch.Generator(device=cuda_device).manual_seed(5))
+        for kw2 in (dict(near=nr, far=fr, fill_inf=True), dict(near=near, far=fr, fill_inf=False, method="none"), dict(near=nr[0], far=far, fill_inf=False, batched=False),
+                    dict(near=near, far=far, fill_inf=True, N_steps=100, N_secant_steps=3)):
+            kw3 = dict(dict(batched=True, N_steps=256, logit_tau=tau, method="secant", N_secant_steps=8), **kw2)
+            o_, d_ = (ro.clone(), rd.clone()) if kw3["batched"] else (ro[0].clone(), rd[0].clone())
+            a = rc.root_finding_surface_points(surf, o_.clone(), d_.clone(), **kw3)
+            os.environ["NEUMESH_NO_SURFACE_KERNEL"] = "1"
+            try:
+                b = rc.root_finding_surface_points(surf, o_.clone(), d_.clone(), **kw3)
+            finally:
+                del os.environ["NEUMESH_NO_SURFACE_KERNEL"]
+            for x, y in zip(a, b):
+                assert x.shape == y.shape, kw2
+                if x.dtype == torch.bool:
+                    assert torch.equal(x, y), kw2
+                else:
+                    fin = torch.isfinite(y)
+                    assert torch.equal(torch.isfinite(x), fin) and float((x[fin] - y[fin]).abs().max()) <= 2e-6, kw2
 
     class Surf:
         def forward(self, p):
