@@ -102,6 +102,7 @@ __device__ __forceinline__ void nm_fetch_point(const NmPointSrc& s, long long r,
 #define NM_CONSTANT __attribute__((address_space(4)))
 typedef unsigned nm_u32x4 __attribute__((ext_vector_type(4)));
 typedef float nm_f32x4 __attribute__((ext_vector_type(4)));
+typedef float nm_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ NmNode nm_ld_node(const NmNode* base, uint32_t i) {
     const nm_u32x4 NM_CONSTANT* pu = (const nm_u32x4 NM_CONSTANT*)(base + i);
     const nm_u32x4 h = pu[0], a = pu[1], b = pu[2], c = pu[3];
@@ -175,11 +176,16 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
             // (s_load_dwordx16 = 4 vertices per dependent load) 103.2 ms of K-NN per frame, this 100.9, vector load +
             // v_readlane broadcast 115.5; the leaf level keeps its optimum (~32 vertices per leaf: 101 vs 127-130 ms at ~120).
             __shared__ float4 nm_leaf_lds[NM_KNN_BLOCK / 64][64];  // one stage per wave: every kernel that traverses is compiled
-            float4* stage = nm_leaf_lds[threadIdx.x >> 6];          // with __launch_bounds__(NM_KNN_BLOCK) and launched with that block size
+            float4* stage = nm_leaf_lds[threadIdx.x >> 6];
+            const nm_f32x2 qyz = {qy, qz};          // with __launch_bounds__(NM_KNN_BLOCK) and launched with that block size
             const uint32_t ln = threadIdx.x & 63u;
             for (uint32_t p0 = crec.first; p0 < crec.end; p0 += 64) {
                 const uint32_t cnt = crec.end - p0 < 64u ? crec.end - p0 : 64u;
-                stage[ln] = g.sverts[p0 + (ln < cnt ? ln : 0u)];
+                {   // staged as {y, z, index, x}: the scan below then finds (y, z) in an aligned register pair (one packed subtract /
+                    // multiply for two axes without copies) and the index beside the register its squared distance is formed in
+                    const float4 sv = g.sverts[p0 + (ln < cnt ? ln : 0u)];
+                    stage[ln] = make_float4(sv.y, sv.z, sv.w, sv.x);
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -188,7 +194,11 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (j0 + j < cnt) {
-                            const unsigned long long key = nm_key(nm_dist2(qx, qy, qz, vv[j].x, vv[j].y, vv[j].z), nm_as_int(vv[j].w));
+                            // declared arithmetic (dx*dx + dy*dy) + dz*dz, one rounding per operation; (y, z) as packed pairs
+                            const nm_f32x2 dyz = qyz - nm_f32x2{vv[j].x, vv[j].y};
+                            const nm_f32x2 syz = dyz * dyz;
+                            const float dxv = nm_sub(qx, vv[j].w);
+                            const unsigned long long key = nm_key(nm_add(nm_add(nm_mul(dxv, dxv), syz.x), syz.y), nm_as_int(vv[j].z));
                             if (want && key < kk[K - 1]) nm_topk_insert<K>(kk, key);
                         }
                     }
