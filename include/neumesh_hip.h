@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 7
+#define NM_ABI_VERSION 8
 #define NM_MAX_K 32
 
 typedef struct nm_grid_s* nm_grid_t;    /* spatial index over the mesh vertices */
@@ -114,9 +114,8 @@ typedef struct nm_field_desc {
     int32_t mlp_precision;     /* 0: fp32 MFMA (reference numerics); 2: split-half f16 MFMA -- every
                                   value carried as two fp16 halves (22 bits), 3 f16 MFMAs per product,
                                   fp32 accumulation; |activations| must stay < 65504 (nm_field_overflow
-                                  reports a violation); 1: the first split-half kernels (A/B only);
-                                  3: mode 2's weights and arithmetic on the pipelined 128-row kernels of
-                                  nm_mlp_h3.h where the configuration allows (A/B only, not faster) */
+                                  reports a violation); 4: the same kernels with ONE f16 product per fp32
+                                  product (11-bit operands: reduced precision, never a default) */
     const float* geo_weight[8];   /* device; layer 0: [W, in_geo], others [W,W] */
     const float* geo_bias[8];     /* device [W] */
     const float* density_weight;  /* device [1,W] */
@@ -308,6 +307,42 @@ int64_t nm_surface_workspace_bytes(nm_field_t field, int64_t R);
 int nm_surface_hits(nm_field_t field, nm_grid_t grid, const nm_field_tables* tables, const float* rays_o, const float* rays_d,
                     int64_t R, const float* near_far, const nm_surface_cfg* cfg, float* d_out, float* pt_out, uint8_t* mask,
                     uint8_t* mask_sign_change, void* workspace, nm_stream_t stream);
+
+/* ----------------------------------------------------------------------------- training form of the field
+ * What one optimisation step differentiates (models/trainer.py:75-81,186-209): NeuMesh.forward_with_nablas
+ * (neumesh.py:146-153) at the samples and NeuMesh.forward (neumesh.py:113-136) at the mid-points -- sdf, nabla = d sdf / d xyz
+ * and rgb -- with the gradients of a loss on those outputs with respect to every parameter the reference trains: both MLPs,
+ * the geometry / colour code tables, the indicator vectors and the indicator weight.  The reference gets them from an
+ * autograd graph of ~60 torch ops per query and a create_graph=True gradient for nabla (neumesh.py:223-232); here
+ * nm_train_forward keeps every intermediate in `workspace` and nm_train_backward is the closed-form reverse pass (nabla is
+ * the kernel's forward-mode tangent, so a cotangent on it -- the eikonal loss -- needs no second-order machinery).
+ *
+ * `desc` carries the fp32 weights in PyTorch layout ([out, in], weight-norm already folded: the caller's autograd maps the
+ * returned gradient of a folded weight to its g / v parameters); mlp_precision is ignored (fp32 operands, fp32 matrix pipe).
+ * view_dirs == NULL: geometry only (rgb is not computed).  with_nabla == 0: sdf only (forward_density_only under autograd).
+ * nm_train_backward must follow an nm_train_forward on the same workspace, P and flags; g_sdf [P], g_nabla [P,3], g_rgb [P,3]
+ * are the cotangents (NULL = zero).  Gradients are ADDED into the non-NULL members of `out` (device pointers, shapes of the
+ * parameters; the caller zeroes them) with atomic adds: the summation order is not fixed from run to run. */
+typedef struct nm_train_grads {
+    float* geo_weight[8];      /* [W, in_geo] / [W, W] */
+    float* geo_bias[8];        /* [W] */
+    float* density_weight;     /* [1, W] */
+    float* density_bias;       /* [1] */
+    float* col_weight[8];
+    float* col_bias[8];
+    float* rgb_weight;         /* [3, W] */
+    float* rgb_bias;           /* [3] */
+    float* geometry_features;  /* [V, geometry_dim] */
+    float* color_features;     /* [V, color_dim] */
+    float* indicator_vector;   /* [V, 3] */
+    float* indicator_weight;   /* [1]: d / d w1 (the caller chains through its sigmoid) */
+} nm_train_grads;
+int64_t nm_train_workspace_bytes(const nm_field_desc* desc, int64_t P);
+int nm_train_forward(const nm_field_desc* desc, nm_grid_t g, const nm_field_tables* t, const float* xyz, const float* view_dirs,
+                     int64_t P, int with_nabla, float* sdf, float* nabla, float* rgb, void* workspace, nm_stream_t stream);
+int nm_train_backward(const nm_field_desc* desc, nm_grid_t g, const nm_field_tables* t, int64_t P, int with_nabla, int with_color,
+                      const float* g_sdf, const float* g_nabla, const float* g_rgb, void* workspace,
+                      const nm_train_grads* out, nm_stream_t stream);
 
 /* ----------------------------------------------------------------------------- image assembly
  * What render.py:219-249 does on the host with the three outputs of a frame, per pixel, on the device

@@ -11,7 +11,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_K = 32
 
 
@@ -63,6 +63,16 @@ class SurfaceCfg(C.Structure):
                 ("fill_inf", C.c_int32), ("scene_radius", C.c_float)]
 
 
+class TrainGrads(C.Structure):
+    """nm_train_grads: device pointers the backward pass ADDS into (None = that gradient is not wanted)."""
+    _fields_ = [("geo_weight", C.c_void_p * 8), ("geo_bias", C.c_void_p * 8),
+                ("density_weight", C.c_void_p), ("density_bias", C.c_void_p),
+                ("col_weight", C.c_void_p * 8), ("col_bias", C.c_void_p * 8),
+                ("rgb_weight", C.c_void_p), ("rgb_bias", C.c_void_p),
+                ("geometry_features", C.c_void_p), ("color_features", C.c_void_p),
+                ("indicator_vector", C.c_void_p), ("indicator_weight", C.c_void_p)]
+
+
 class RenderDebug(C.Structure):
     _fields_ = [("near_far", C.c_void_p), ("d_all", C.c_void_p), ("sdf_all", C.c_void_p),
                 ("nablas_all", C.c_void_p), ("radiance", C.c_void_p), ("sdf_coarse", C.c_void_p)]
@@ -99,6 +109,10 @@ SIGNATURES = {
     "nm_rays_composite": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, _P, _P, C.c_int, _P, _P, _P, _P, _P]),
     "nm_make_rays": (C.c_int, [C.POINTER(Camera), C.c_int64, C.c_int64, _P, _P, _P]),
     "nm_make_rays_indexed": (C.c_int, [C.POINTER(Camera), _P, C.c_int64, _P, _P, _P]),
+    "nm_train_workspace_bytes": (C.c_int64, [C.POINTER(FieldDesc), C.c_int64]),
+    "nm_train_forward": (C.c_int, [C.POINTER(FieldDesc), _P, C.POINTER(FieldTables), _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P]),
+    "nm_train_backward": (C.c_int, [C.POINTER(FieldDesc), _P, C.POINTER(FieldTables), C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P,
+                                    C.POINTER(TrainGrads), _P]),
     "nm_surface_workspace_bytes": (C.c_int64, [_P, C.c_int64]),
     "nm_surface_hits": (C.c_int, [_P, _P, C.POINTER(FieldTables), _P, _P, C.c_int64, _P, C.POINTER(SurfaceCfg), _P, _P, _P, _P, _P, _P]),
     "nm_assemble_frame": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P]),

@@ -23,6 +23,7 @@
 #include "nm_mlp_h2.h"
 #include "nm_surface.h"
 #include "nm_edit.h"
+#include "nm_train.h"
 
 #define NM_PROBE_STEP 8  // probes per ray and step of nm_probe_bounds_kernel: 8 = 8 rays per wave (measured: K-NN per frame 99.9 ms with 4, 97.2 with 8, 101.7 with 16)
 
@@ -663,6 +664,187 @@ int nm_field_color(nm_field_t f, const float* color_features, const float* ds, c
                        reinterpret_cast<const long long*>(idx), (const int*)nullptr, w, (long long)P, s.ft);
     NM_LAUNCH_CHECK();
     return nm_launch_col(f, s.ft, ds, nabla, view_dirs, 1, P, rgb, stream);
+}
+
+// =============================================================================== training form of the field (nm_train.h)
+static int nm_train_validate(const nm_field_desc* d, const char* who) {
+    if (!d) return nm_fail("%s: NULL descriptor", who);
+    if (d->W < 16 || d->W % 16) return nm_fail("%s: W=%d must be a positive multiple of 16", who, d->W);
+    if (d->D_density < 1 || d->D_density > 8 || d->D_color < 1 || d->D_color > 8) return nm_fail("%s: depths out of [1,8]", who);
+    if (d->geometry_dim < 4 || d->geometry_dim % 4 || d->color_dim < 4 || d->color_dim % 4) return nm_fail("%s: code widths must be multiples of 4", who);
+    if (d->multires_d > 15 || d->multires_fg > 15 || d->multires_ft > 15 || d->multires_view > 15) return nm_fail("%s: more than 15 embedder bands", who);
+    for (int l = 0; l < d->D_density; ++l)
+        if (!d->geo_weight[l] || !d->geo_bias[l]) return nm_fail("%s: NULL geometry weight", who);
+    for (int l = 0; l < d->D_color; ++l)
+        if (!d->col_weight[l] || !d->col_bias[l]) return nm_fail("%s: NULL colour weight", who);
+    if (!d->density_weight || !d->density_bias || !d->rgb_weight || !d->rgb_bias) return nm_fail("%s: NULL head weight", who);
+    return 0;
+}
+
+int64_t nm_train_workspace_bytes(const nm_field_desc* d, int64_t P) {
+    if (!d || P < 0) return -1;
+    return (int64_t)nm_train_carve(nullptr, P, nm_train_dims(d)).bytes;
+}
+
+static int nm_t_split(long long M, long long N, long long K) {   // K chunks so that a weight-gradient product fills the chip
+    const long long tiles = ((M + NM_G_BM - 1) / NM_G_BM) * ((N + NM_G_BN - 1) / NM_G_BN);
+    long long chunks = (1024 + tiles - 1) / tiles;
+    const long long most = (K + 511) / 512;
+    if (chunks > most) chunks = most;
+    return (int)(chunks < 1 ? 1 : chunks);
+}
+
+static NmGemm nm_t_gemm(const float* A, long long lda, int a_kc, const float* B, long long ldb, int b_kc, float* C, long long ldc,
+                        long long M, long long N, long long K, int accumulate = 0) {
+    NmGemm g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.a_kc = a_kc; g.B = B; g.ldb = ldb; g.b_kc = b_kc; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.atomic = accumulate;      // C += A . B (weight gradients: added to what the caller's buffer holds, whatever the split)
+    return g;
+}
+
+#define NM_T_GEMM(g, split)                                                            \
+    do {                                                                               \
+        if (nm_gemm_launch((g), (split), stream)) return nm_fail("nm_train: GEMM launch failed"); \
+    } while (0)
+
+int nm_train_forward(const nm_field_desc* d, nm_grid_t g, const nm_field_tables* t, const float* xyz, const float* view_dirs,
+                     int64_t P, int with_nabla, float* sdf, float* nabla, float* rgb, void* workspace, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (nm_train_validate(d, "nm_train_forward")) return 1;
+    if (!g || !t || !t->geometry_features || !t->color_features || !t->indicator_vector) return nm_fail("nm_train_forward: NULL handle/tables");
+    if (g->view.V < 8) return nm_fail("nm_train_forward: mesh has %d < 8 vertices", g->view.V);
+    if (P < 0 || (P > 0 && (!xyz || !sdf || !workspace))) return nm_fail("nm_train_forward: bad arguments");
+    if (P == 0) return 0;
+    const bool color = view_dirs != nullptr;
+    if (color && !rgb) return nm_fail("nm_train_forward: rgb is NULL");
+    const NmTrainDims td = nm_train_dims(d);
+    const int tangent = (with_nabla || (color && td.use_nabla)) ? 1 : 0;
+    if (with_nabla && !nabla) return nm_fail("nm_train_forward: nabla is NULL");
+    NmTrainWs s = nm_train_carve(workspace, P, td);
+    const long long W = td.W, rows = tangent ? 2 * P : P, toff = P * W;
+    NM_HIP(hipMemcpyAsync(s.xyz, xyz, (size_t)P * 12, hipMemcpyDeviceToDevice, stream));
+    const NmGather ga = {t->geometry_features, td.G, s.fg, color ? t->color_features : nullptr, color ? td.Cd : 0, color ? s.ft : nullptr};
+    if (nm_launch_distance(g, nm_src_xyz(xyz, P), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx, nullptr, s.w, s.gds, stream,
+                           nullptr, ga)) return 1;
+    hipLaunchKernelGGL(nm_t_pad_kernel, dim3((unsigned)((W * td.K0p + 255) / 256)), dim3(256), 0, stream, d->geo_weight[0], s.W0p, (int)W, td.K0, td.K0p, 0);
+    if (color)
+        hipLaunchKernelGGL(nm_t_pad_kernel, dim3((unsigned)((W * td.Kc0p + 255) / 256)), dim3(256), 0, stream, d->col_weight[0], s.Wc0p, (int)W, td.Kc0, td.Kc0p, 0);
+    hipLaunchKernelGGL(nm_t_embed_kernel, dim3((unsigned)((P + 7) / 8)), dim3(256), 0, stream, td, (long long)P, s.ds, s.fg, color ? s.ft : nullptr, view_dirs,
+                       s.X0, s.T0, color ? s.C0 : nullptr);
+    NM_LAUNCH_CHECK();
+    // geometry MLP on (value | tangent) rows
+    {
+        NmGemm m = nm_t_gemm(s.X0, td.K0p, 1, s.W0p, td.K0p, 1, s.ZU[0], W, P, W, td.K0p);
+        m.bias = d->geo_bias[0]; m.bias_rows = P;
+        NM_T_GEMM(m, 1);
+        if (tangent) NM_T_GEMM(nm_t_gemm(s.T0, td.Kt, 1, s.W0p, td.K0p, 1, s.ZU[0] + toff, W, P, W, td.Kt), 1);
+    }
+    const unsigned act_blocks = (unsigned)((P * W / 4 + 255) / 256);
+    for (int l = 0; l < td.Dg; ++l) {
+        if (l > 0) {
+            NmGemm m = nm_t_gemm(s.HT[l - 1], W, 1, d->geo_weight[l], W, 1, s.ZU[l], W, rows, W, W);
+            m.bias = d->geo_bias[l]; m.bias_rows = P;
+            NM_T_GEMM(m, 1);
+        }
+        hipLaunchKernelGGL(nm_t_softplus_kernel, dim3(act_blocks), dim3(256), 0, stream, s.ZU[l], s.HT[l], P * W, toff, tangent);
+    }
+    hipLaunchKernelGGL(nm_t_geo_head_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, stream, td, (long long)P, s.HT[td.Dg - 1], d->density_weight,
+                       d->density_bias, s.gds, tangent, s.sdf, s.alpha, s.nabla, color ? s.C0 : nullptr);
+    NM_LAUNCH_CHECK();
+    NM_HIP(hipMemcpyAsync(sdf, s.sdf, (size_t)P * 4, hipMemcpyDeviceToDevice, stream));
+    if (nabla && tangent) NM_HIP(hipMemcpyAsync(nabla, s.nabla, (size_t)P * 12, hipMemcpyDeviceToDevice, stream));
+    if (!color) return 0;
+    for (int l = 0; l < td.Dc; ++l) {
+        NmGemm m = l == 0 ? nm_t_gemm(s.C0, td.Kc0p, 1, s.Wc0p, td.Kc0p, 1, s.HC[0], W, P, W, td.Kc0p)
+                          : nm_t_gemm(s.HC[l - 1], W, 1, d->col_weight[l], W, 1, s.HC[l], W, P, W, W);
+        m.bias = d->col_bias[l]; m.bias_rows = P; m.relu = 1;
+        NM_T_GEMM(m, 1);
+    }
+    hipLaunchKernelGGL(nm_t_col_head_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, stream, td, (long long)P, s.HC[td.Dc - 1], d->rgb_weight, d->rgb_bias, s.rgb);
+    NM_LAUNCH_CHECK();
+    NM_HIP(hipMemcpyAsync(rgb, s.rgb, (size_t)P * 12, hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
+int nm_train_backward(const nm_field_desc* d, nm_grid_t g, const nm_field_tables* t, int64_t P, int with_nabla, int with_color,
+                      const float* g_sdf, const float* g_nabla, const float* g_rgb, void* workspace, const nm_train_grads* out,
+                      nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (nm_train_validate(d, "nm_train_backward")) return 1;
+    if (!g || !t || !t->indicator_vector || !out) return nm_fail("nm_train_backward: NULL handle/tables/grads");
+    if (P < 0 || (P > 0 && !workspace)) return nm_fail("nm_train_backward: bad arguments");
+    if (P == 0) return 0;
+    const NmTrainDims td = nm_train_dims(d);
+    const bool color = with_color != 0;
+    const int tangent = (with_nabla || (color && td.use_nabla)) ? 1 : 0;
+    NmTrainWs s = nm_train_carve(workspace, P, td);
+    const long long W = td.W, rows = tangent ? 2 * P : P, toff = P * W;
+    const unsigned strips = 256;      // workgroups of the strip-reducing head kernels (4 waves each)
+    NM_HIP(hipMemsetAsync(s.dds, 0, (size_t)P * 4, stream));
+    NM_HIP(hipMemsetAsync(s.dnab, 0, (size_t)P * 12, stream));
+    float *cur = s.DA, *oth = s.DB;
+    if (color) {
+        // rgb head + ReLU mask of the last hidden layer; gradients of a NULL member go to the (unused) padded scratch
+        float* dWr = out->rgb_weight ? out->rgb_weight : s.dWc0p;
+        float* dbr = out->rgb_bias ? out->rgb_bias : s.dWc0p;
+        hipLaunchKernelGGL(nm_t_col_head_bwd_kernel, dim3(strips), dim3(256), 0, stream, td, (long long)P, g_rgb, s.rgb, s.HC[td.Dc - 1], d->rgb_weight, cur, dWr, dbr);
+        NM_LAUNCH_CHECK();
+        NM_HIP(hipMemsetAsync(s.dWc0p, 0, (size_t)W * td.Kc0p * 4, stream));
+        for (int l = td.Dc - 1; l >= 0; --l) {
+            if (out->col_bias[l]) hipLaunchKernelGGL(nm_t_colsum_kernel, dim3((unsigned)((P + 511) / 512)), dim3(256), 0, stream, cur, (long long)P, (int)W, out->col_bias[l]);
+            if (l > 0) {
+                if (out->col_weight[l]) NM_T_GEMM(nm_t_gemm(cur, W, 0, s.HC[l - 1], W, 0, out->col_weight[l], W, W, W, P, 1), nm_t_split(W, W, P));
+                NmGemm m = nm_t_gemm(cur, W, 1, d->col_weight[l], W, 0, oth, W, P, W, W);
+                m.mask = s.HC[l - 1]; m.ldmask = W;
+                NM_T_GEMM(m, 1);
+                float* x = cur; cur = oth; oth = x;
+            } else {
+                if (out->col_weight[0]) NM_T_GEMM(nm_t_gemm(cur, W, 0, s.C0, td.Kc0p, 0, s.dWc0p, td.Kc0p, W, td.Kc0p, P, 1), nm_t_split(W, td.Kc0p, P));
+                NM_T_GEMM(nm_t_gemm(cur, W, 1, s.Wc0p, td.Kc0p, 0, s.DC0, td.Kc0p, P, td.Kc0p, W), 1);
+            }
+        }
+        if (out->col_weight[0])
+            hipLaunchKernelGGL(nm_t_pad_kernel, dim3((unsigned)((W * td.Kc0p + 255) / 256)), dim3(256), 0, stream, s.dWc0p, out->col_weight[0], (int)W, td.Kc0, td.Kc0p, 1);
+        hipLaunchKernelGGL(nm_t_col_input_bwd_kernel, dim3((unsigned)((P + 7) / 8)), dim3(256), 0, stream, td, (long long)P, s.DC0, s.ds, s.ft, s.idx, s.w,
+                           s.dnab, s.dds, out->color_features);
+        NM_LAUNCH_CHECK();
+    }
+    // density head + last layer's activation backward
+    {
+        float* dwd = out->density_weight ? out->density_weight : s.dW0p;
+        float* dbd = out->density_bias ? out->density_bias : s.dW0p;
+        hipLaunchKernelGGL(nm_t_geo_head_bwd_kernel, dim3(strips), dim3(256), 0, stream, td, (long long)P, g_sdf, g_nabla, color ? s.dnab : nullptr, s.gds, s.alpha,
+                           d->density_weight, s.ZU[td.Dg - 1], s.HT[td.Dg - 1], tangent, cur, s.gvec, dwd, dbd);
+        NM_LAUNCH_CHECK();
+        NM_HIP(hipMemsetAsync(s.dW0p, 0, (size_t)W * td.K0p * 4, stream));
+    }
+    const unsigned act_blocks = (unsigned)((P * W / 4 + 255) / 256);
+    for (int l = td.Dg - 1; l >= 0; --l) {
+        if (out->geo_bias[l]) hipLaunchKernelGGL(nm_t_colsum_kernel, dim3((unsigned)((P + 511) / 512)), dim3(256), 0, stream, cur, (long long)P, (int)W, out->geo_bias[l]);
+        if (l > 0) {
+            if (out->geo_weight[l]) NM_T_GEMM(nm_t_gemm(cur, W, 0, s.HT[l - 1], W, 0, out->geo_weight[l], W, W, W, rows, 1), nm_t_split(W, W, rows));
+            NM_T_GEMM(nm_t_gemm(cur, W, 1, d->geo_weight[l], W, 0, oth, W, rows, W, W), 1);
+            hipLaunchKernelGGL(nm_t_softplus_bwd_kernel, dim3(act_blocks), dim3(256), 0, stream, oth, s.ZU[l - 1], oth, P * W, toff, tangent);
+            float* x = cur; cur = oth; oth = x;
+        } else {
+            if (out->geo_weight[0]) {
+                NM_T_GEMM(nm_t_gemm(cur, W, 0, s.X0, td.K0p, 0, s.dW0p, td.K0p, W, td.K0p, P, 1), nm_t_split(W, td.K0p, P));
+                if (tangent) NM_T_GEMM(nm_t_gemm(cur + toff, W, 0, s.T0, td.Kt, 0, s.dW0p, td.K0p, W, td.Kt, P, 1), nm_t_split(W, td.Kt, P));
+            }
+            NM_T_GEMM(nm_t_gemm(cur, W, 1, s.W0p, td.K0p, 0, s.DX0, td.K0p, P, td.K0p, W), 1);
+            if (tangent) NM_T_GEMM(nm_t_gemm(cur + toff, W, 1, s.W0p, td.K0p, 0, s.DT0, td.Kt, P, td.Kt, W), 1);
+        }
+    }
+    if (out->geo_weight[0])
+        hipLaunchKernelGGL(nm_t_pad_kernel, dim3((unsigned)((W * td.K0p + 255) / 256)), dim3(256), 0, stream, s.dW0p, out->geo_weight[0], (int)W, td.K0, td.K0p, 1);
+    hipLaunchKernelGGL(nm_t_geo_input_bwd_kernel, dim3((unsigned)((P + 7) / 8)), dim3(256), 0, stream, td, (long long)P, s.DX0, tangent ? s.DT0 : nullptr, s.ds, s.fg,
+                       s.idx, s.w, s.dds, out->geometry_features);
+    if (out->indicator_vector || out->indicator_weight)
+        hipLaunchKernelGGL(nm_t_distance_bwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, stream, (long long)P, s.xyz, s.idx, s.w, g->verts,
+                           t->indicator_vector, t->indicator_weight, s.dds, tangent ? s.gvec : nullptr, out->indicator_vector, out->indicator_weight);
+    NM_LAUNCH_CHECK();
+    return 0;
 }
 
 // ============================================================================== renderer

@@ -29,11 +29,8 @@ NM_HD float nm_div(float a, float b) {
 #endif
 }
 
-// K = 8 neighbours.  verts/indicator: [V,3] in ORIGINAL vertex order.
-// w_out[8] normalised weights; returns ds; grad (may be nullptr) receives d ds / d xyz.
-NM_HD float nm_projected_distance8(float qx, float qy, float qz, const float (&d2)[8], const int (&idx)[8],
-                                   const float* __restrict__ verts, const float* __restrict__ indicator,
-                                   float w1, float (&w_out)[8], float* grad) {
+// inverse-distance weights of the K = 8 neighbours (mesh_grid.py:121-124), normalised
+NM_HD void nm_weights8(const float (&d2)[8], float (&w_out)[8]) {
     float wsum = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -41,10 +38,17 @@ NM_HD float nm_projected_distance8(float qx, float qy, float qz, const float (&d
         w_out[k] = nm_div(1.0f, nm_add(dis, 1e-7f));
         wsum = nm_add(wsum, w_out[k]);
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w_out[k] = nm_div(w_out[k], wsum);
+}
+
+// projected signed distance from normalised weights (and its gradient in closed form)
+NM_HD float nm_projected_from_weights8(float qx, float qy, float qz, const int (&idx)[8], const float (&w_out)[8],
+                                       const float* __restrict__ verts, const float* __restrict__ indicator,
+                                       float w1, float* grad) {
     float ds = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        w_out[k] = nm_div(w_out[k], wsum);
         const int i = idx[k];
         const float vx = verts[3 * i], vy = verts[3 * i + 1], vz = verts[3 * i + 2];
         const float nx = indicator[3 * i], ny = indicator[3 * i + 1], nz = indicator[3 * i + 2];
@@ -74,4 +78,13 @@ NM_HD float nm_projected_distance8(float qx, float qy, float qz, const float (&d
         grad[2] = gz;
     }
     return ds;
+}
+
+// K = 8 neighbours.  verts/indicator: [V,3] in ORIGINAL vertex order.
+// w_out[8] normalised weights; returns ds; grad (may be nullptr) receives d ds / d xyz.
+NM_HD float nm_projected_distance8(float qx, float qy, float qz, const float (&d2)[8], const int (&idx)[8],
+                                   const float* __restrict__ verts, const float* __restrict__ indicator,
+                                   float w1, float (&w_out)[8], float* grad) {
+    nm_weights8(d2, w_out);
+    return nm_projected_from_weights8(qx, qy, qz, idx, w_out, verts, indicator, w1, grad);
 }

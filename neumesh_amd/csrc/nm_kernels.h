@@ -83,8 +83,19 @@ __device__ __forceinline__ void nm_fetch_point(const NmPointSrc& s, long long r,
 }
 
 #define NM_KNN_BLOCK 256   // threads per workgroup of every kernel that runs the K-NN traversal (the leaf stage in LDS is sized by it)
-#define NM_KNN_WAVES 6     // waves per SIMD the K-NN kernels are compiled for (register budget 512 / NM_KNN_WAVES; measured round 3: 4 and 6 tie,
-                           // 3 is 13 % slower -- the kernels are bound by vector-instruction issue, not by the scratch traffic of the 80-register budget)
+// Waves per SIMD the K-NN kernels are compiled for (register budget 512 / waves).  Measured per kernel on the bench frame, round 3
+// (tools/knn_variants.sh; K-NN ms per frame, one gpurun call): fine / mid-point passes 4: 90.6, 5: 88.7, 6: 95.3 (0 / 36 / 80 spilled
+// registers -- the spills sit in the epilogue, once per point, and cost HBM write traffic rather than issue slots: 17.5 / 45 GB per frame
+// at 4 / 6); chained coarse pass 3: +5.5 ms, 4 = 5 = 6; probe walk 4: 92.6, 5: 88.5, 6: 86.1.
+#ifndef NM_KNN_WAVES
+#define NM_KNN_WAVES 5
+#endif
+#ifndef NM_KNN_WAVES_CHAIN
+#define NM_KNN_WAVES_CHAIN 4
+#endif
+#ifndef NM_KNN_WAVES_PROBE
+#define NM_KNN_WAVES_PROBE 6
+#endif
 
 // ------------------------------------------------------------ wave-cooperative K-NN search
 // The 64 queries of a wave are neighbours in space (consecutive samples of adjacent rays), so
@@ -386,11 +397,9 @@ __global__ __launch_bounds__(NM_KNN_BLOCK) void nm_knn_kernel(NmGridView g, NmPo
 // ------------------------------------------------- K-NN + weights + projected signed distance
 // (models/mesh_grid.py:88-144 fused; nothing of shape [Q,8,3] is ever materialised)
 // Any output pointer may be null.  ds_out is indexed by q (compact).
-// Occupancy: 6 waves per SIMD (<= 85 VGPRs; the distance epilogue spills a little).  The traversal is
-// bound by scalar-load latency, so waves per SIMD matter more than registers: K-NN time per frame with 4
-// waves 156 ms, 5: 141, 6: 136, 7: 155 (spills reach the traversal), 8: 540.
+// Occupancy: NM_KNN_WAVES / NM_KNN_WAVES_CHAIN above.
 template <bool CHAIN>
-__global__ __launch_bounds__(NM_KNN_BLOCK, NM_KNN_WAVES) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
+__global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_WAVES) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
                                                           const float* __restrict__ verts,
                                                           const float* __restrict__ indicator, float w1,
                                                           float* __restrict__ ds_out, int* __restrict__ idx32_out,
@@ -494,7 +503,7 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, NM_KNN_WAVES) void nm_distance_kernel
 // S = probes per ray and step (4: 16 rays per wave, 8: 8 rays per wave -- half as many serial steps per wave, up to 4 more probes
 // per ray and walk; nm_render_rays picks)
 template <int S>
-__global__ __launch_bounds__(NM_KNN_BLOCK, NM_KNN_WAVES) void nm_probe_bounds_kernel(NmGridView g, const float* __restrict__ rays_o,
+__global__ __launch_bounds__(NM_KNN_BLOCK, NM_KNN_WAVES_PROBE) void nm_probe_bounds_kernel(NmGridView g, const float* __restrict__ rays_o,
                                                                  const float* __restrict__ dirn, const float* __restrict__ nearfar0,
                                                                  long long R, int P, float thresh, const float* __restrict__ verts,
                                                                  const float* __restrict__ indicator, float w1,

@@ -117,6 +117,103 @@ class _FusedField(autograd.Function):
         return (None, None, gx, None, *grads[1:])
 
 
+class _HipField(autograd.Function):
+    """Training-side form of the field queries with BOTH directions on the HIP library (C ABI
+    nm_train_forward / nm_train_backward, csrc/nm_train.h): forward keeps every intermediate in a device workspace, backward is the
+    closed-form reverse pass -- nabla is the kernel's forward-mode tangent, so a cotangent on it (eikonal loss, normals, the
+    colour MLP's nabla input) needs no create_graph=True pass (neumesh.py:223-232 in the reference) -- and no torch-op
+    graph is built or replayed.  Tensor inputs (gradients returned for those that require them): weight-norm-FOLDED geometry
+    weights (autograd maps their gradients on to g / v), biases, colour weights / biases, both code tables, the indicator
+    vectors and the indicator weight w1 = sigmoid(raw)."""
+
+    @staticmethod
+    def forward(ctx, model, mode, xyz, view_dirs, *tensors):
+        lib = _lib.load()
+        q = xyz.detach().float().reshape(-1, 3).contiguous()
+        dev = q.device
+        tile = model._tile_order(xyz.shape, dev)
+        v = None
+        if mode == "forward":
+            v = view_dirs.detach().float().expand_as(xyz).reshape(-1, 3).contiguous()
+        if tile is not None:
+            q = q[tile[0]]
+            v = None if v is None else v[tile[0]]
+        P = q.shape[0]
+        desc, keep = model._train_desc(tensors)
+        t = _lib.FieldTables()
+        n_geo, n_col = model._cfg["D_density"], model._cfg["D_color"]
+        gf, cf, iv = (x.detach().float().contiguous() for x in tensors[-4:-1])
+        t.geometry_features, t.color_features, t.indicator_vector = gf.data_ptr(), cf.data_ptr(), iv.data_ptr()
+        t.indicator_weight, t.s = model._host_scalars()
+        with_nabla = 0 if mode == "density" else 1
+        f32 = dict(dtype=torch.float32, device=dev)
+        sdf = torch.empty((P,), **f32)
+        nab = torch.empty((P, 3), **f32) if with_nabla else None
+        rgb = torch.empty((P, 3), **f32) if mode == "forward" else None
+        ws = torch.empty((int(lib.nm_train_workspace_bytes(C.byref(desc), P)),), dtype=torch.uint8, device=dev)
+        grid = model.grid_for(dev).grid.handle
+        with torch.cuda.device(dev):
+            _lib.check(lib.nm_train_forward(C.byref(desc), grid, C.byref(t), _lib.ptr(q), _lib.ptr(v), P, with_nabla, _lib.ptr(sdf), _lib.ptr(nab),
+                                            _lib.ptr(rgb), _lib.ptr(ws), _lib.current_stream(dev)), "nm_train_forward")
+        ctx.model, ctx.mode, ctx.ws, ctx.tile, ctx.P = model, mode, ws, tile, P
+        ctx.desc, ctx.tables, ctx.keep = desc, t, (keep, gf, cf, iv, tensors)
+        ctx.grid = grid
+        ctx.shapes = [tuple(x.shape) for x in tensors]
+        lead = xyz.shape[:-1]
+        def back(a, w_):
+            return (a if tile is None else a[tile[1]]).reshape(*lead, w_)
+        if mode == "density":
+            return back(sdf, 1)
+        if mode == "density_nabla":
+            return back(sdf, 1), back(nab, 3)
+        return back(sdf, 1), back(rgb, 3)
+
+    @staticmethod
+    def backward(ctx, *cot):
+        lib = _lib.load()
+        model, mode, tile, P = ctx.model, ctx.mode, ctx.tile, ctx.P
+        dev = ctx.ws.device
+
+        def fwd(g, w_):
+            if g is None:
+                return None
+            g = g.detach().float().reshape(-1, w_)
+            return (g if tile is None else g[tile[0]]).contiguous()
+        g_sdf = fwd(cot[0], 1)
+        g_nab = fwd(cot[1], 3) if mode == "density_nabla" else None
+        g_rgb = fwd(cot[1], 3) if mode == "forward" else None
+        n_geo, n_col = model._cfg["D_density"], model._cfg["D_color"]
+        need = list(ctx.needs_input_grad[4:])
+        if mode != "forward":     # geometry-only queries: the colour MLP and the colour table are not part of the graph
+            for i in list(range(2 * (n_geo + 1), 2 * (n_geo + 1) + 2 * (n_col + 1))) + [len(need) - 3]:
+                need[i] = False
+        grads = [torch.zeros(shape, dtype=torch.float32, device=dev) if nd else None for shape, nd in zip(ctx.shapes, need)]
+        out = _lib.TrainGrads()
+        it = iter(grads)
+        def nxt():
+            g = next(it)
+            return None if g is None else g.data_ptr()
+        for l in range(n_geo):
+            out.geo_weight[l] = nxt()
+        out.density_weight = nxt()
+        for l in range(n_geo):
+            out.geo_bias[l] = nxt()
+        out.density_bias = nxt()
+        for l in range(n_col):
+            out.col_weight[l] = nxt()
+        out.rgb_weight = nxt()
+        for l in range(n_col):
+            out.col_bias[l] = nxt()
+        out.rgb_bias = nxt()
+        out.geometry_features, out.color_features, out.indicator_vector, out.indicator_weight = nxt(), nxt(), nxt(), nxt()
+        with torch.cuda.device(dev):
+            _lib.check(lib.nm_train_backward(C.byref(ctx.desc), ctx.grid, C.byref(ctx.tables), P, 0 if mode == "density" else 1,
+                                             1 if mode == "forward" else 0, _lib.ptr(g_sdf), _lib.ptr(g_nab), _lib.ptr(g_rgb), _lib.ptr(ctx.ws),
+                                             C.byref(out), _lib.current_stream(dev)), "nm_train_backward")
+        ctx.ws = None
+        return (None, None, None, None, *grads)
+
+
 class FieldHandle:
     """Owns one nm_field_t (packed MLP weights on one device).  NeuMesh keeps a reference; nn.DataParallel replicas are
     shallow copies of the module's __dict__ and therefore share THIS object until they rebuild their own (see
@@ -176,9 +273,10 @@ class NeuMesh(nn.Module):
         self._field_dev = None
         self._field_epoch = 0     # bumped by invalidate_field()
         self._range_checked = False
-        # With autograd enabled: False (default) = the torch-op restatement end to end; True = fused HIP forward
-        # + recomputing backward (_FusedField): same gradients, no activation graph kept.
-        self.fused_autograd = os.environ.get("NEUMESH_FUSED_AUTOGRAD", "0") == "1"
+        # With autograd enabled (training): "hip" = forward AND backward on the HIP library (_HipField: nm_train_forward /
+        # nm_train_backward, closed-form reverse pass); "recompute" = fused HIP forward + a backward that re-evaluates the
+        # torch-op restatement (_FusedField); "torch" = the torch-op restatement end to end.  Same gradients.
+        self.autograd_backend = os.environ.get("NEUMESH_AUTOGRAD", "hip")
         self._keep = None         # tensors whose pointers the last FieldDesc referenced
 
     # ------------------------------------------------------------------ scalars
@@ -425,6 +523,38 @@ class NeuMesh(nn.Module):
             out = out + (ds.reshape(*lead, 1), idx.reshape(*lead, 8), w.reshape(*lead, 8))
         return out
 
+    # ------------------------------------------------------------------ HIP training path (_HipField)
+    def _train_tensors(self):
+        """Tensor inputs of _HipField, in its fixed order: folded geometry weights (+ density head), their biases, colour weights
+        (+ rgb head), their biases, geometry / colour tables, indicator vectors, w1.  The folding W = v * (g / |v|_row)
+        (torch.nn.utils.weight_norm, dim 0) is done here with torch ops so that autograd carries the gradient on to g and v."""
+        def folded(m):
+            return m.weight_v * (m.weight_g / m.weight_v.norm(dim=1, keepdim=True))
+        geo, col = self._geo_layers() + [self.density_linear], self._col_layers() + [self.color_linear[0]]
+        w1 = self.forward_indicator_weight() if self.learn_indicator_weight else self.ln_s.new_tensor([0.1])
+        return ([folded(m) for m in geo] + [m.bias for m in geo] + [m.weight for m in col] + [m.bias for m in col] +
+                [self.geometry_features, self.color_features, self.indicator_vector, w1])
+
+    def _train_desc(self, tensors):
+        """nm_field_desc over the fp32 weights in `tensors` (the order of _train_tensors); returns (desc, tensors to keep alive)."""
+        c = self._cfg
+        ng, nc = c["D_density"], c["D_color"]
+        flat = [x.detach().float().contiguous() for x in tensors[:2 * (ng + 1) + 2 * (nc + 1)]]
+        gw, gb = flat[:ng + 1], flat[ng + 1:2 * (ng + 1)]
+        cw, cb = flat[2 * (ng + 1):2 * (ng + 1) + nc + 1], flat[2 * (ng + 1) + nc + 1:]
+        d = _lib.FieldDesc()
+        d.W, d.D_density, d.D_color = c["W"], ng, nc
+        d.geometry_dim, d.color_dim = c["geometry_dim"], c["color_dim"]
+        d.multires_d, d.multires_fg, d.multires_ft, d.multires_view = c["multires_d"], c["multires_fg"], c["multires_ft"], c["multires_view"]
+        d.enable_nablas_input, d.use_view_dirs, d.mlp_precision = int(self.enable_nablas_input), 1, 0
+        for l in range(ng):
+            d.geo_weight[l], d.geo_bias[l] = gw[l].data_ptr(), gb[l].data_ptr()
+        d.density_weight, d.density_bias = gw[ng].data_ptr(), gb[ng].data_ptr()
+        for l in range(nc):
+            d.col_weight[l], d.col_bias[l] = cw[l].data_ptr(), cb[l].data_ptr()
+        d.rgb_weight, d.rgb_bias = cw[nc].data_ptr(), cb[nc].data_ptr()
+        return d, flat
+
     # ------------------------------------------------------------------ public API (reference names)
     def compute_distance(self, xyz):
         """neumesh.py:262-273."""
@@ -437,7 +567,9 @@ class NeuMesh(nn.Module):
         """neumesh.py:140-145."""
         if not torch.is_grad_enabled():
             return self._fused_density(xyz, False)[0]
-        if self.fused_autograd:
+        if self.autograd_backend == "hip" and not xyz.requires_grad:
+            return _HipField.apply(self, "density", xyz, None, *self._train_tensors())
+        if self.autograd_backend == "recompute":
             return _FusedField.apply(self, "density", xyz, None, *self._trainable())
         return self._density_autograd(xyz, False)[0]
 
@@ -445,7 +577,9 @@ class NeuMesh(nn.Module):
         """neumesh.py:147-154."""
         if not torch.is_grad_enabled():
             return self._fused_density(xyz, True)
-        if self.fused_autograd:
+        if self.autograd_backend == "hip" and not xyz.requires_grad:
+            return _HipField.apply(self, "density_nabla", xyz, None, *self._train_tensors())
+        if self.autograd_backend == "recompute":
             return _FusedField.apply(self, "density_nabla", xyz, None, *self._trainable())
         return self._density_autograd(xyz, True)[:2]
 
@@ -455,8 +589,11 @@ class NeuMesh(nn.Module):
             sdf, rgb, nab, *rest = self._fused_forward(xyz, view_dirs, return_ds)
             out = (sdf, nab) if nablas_only else (sdf, rgb)
             return out + tuple(rest)
-        if self.fused_autograd and torch.is_grad_enabled() and need_nablas and not nablas_only and not return_ds:
-            return _FusedField.apply(self, "forward", xyz, view_dirs.expand_as(xyz), *self._trainable())
+        if torch.is_grad_enabled() and need_nablas and not nablas_only and not return_ds:
+            if self.autograd_backend == "hip" and not xyz.requires_grad and not view_dirs.requires_grad:
+                return _HipField.apply(self, "forward", xyz, view_dirs, *self._train_tensors())
+            if self.autograd_backend == "recompute":
+                return _FusedField.apply(self, "forward", xyz, view_dirs.expand_as(xyz), *self._trainable())
         return self._forward_autograd(xyz, view_dirs, need_nablas, nablas_only, return_ds)
 
     # ------------------------------------------------------------------ torch-op (autograd) forms of the queries

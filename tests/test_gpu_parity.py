@@ -891,20 +891,21 @@ def test_fused_renderer_equals_staged_renderer_other_configs(dtu_scale, cuda_dev
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fused_autograd", [False, True])
-def test_trainer_step_matches_reference_trainer(cuda_device, torch_mod, fused_autograd):
+@pytest.mark.parametrize("backend", ["hip", "recompute", "torch"])
+def test_trainer_step_matches_reference_trainer(cuda_device, torch_mod, backend):
     """One optimisation step through neumesh_amd.trainer.Trainer.forward (the 2nd element of get_model's tuple,
     called as train.py:176 calls it) against the REFERENCE Trainer on the same scene / camera / ground truth
     (tests/golden/train_step_v3000.npz): the same pixels are drawn, every loss term agrees, and d total / d parameter
     of every model parameter agrees -- with the eikonal term on (second derivative of the nabla graph), the
-    distillation terms on (samples_output through the staged renderer) and the mask loss on.  fused_autograd=True runs
-    the field's forward through the fused HIP kernels + recomputing backward (_FusedField)."""
+    distillation terms on (samples_output through the staged renderer) and the mask loss on.  backend: "hip" = the field's forward
+    and closed-form backward on the HIP library (_HipField, the default), "recompute" = fused HIP forward + recomputing torch-op
+    backward (_FusedField), "torch" = torch ops end to end."""
     torch = torch_mod
     from neumesh_amd.trainer import Trainer
     f = common.golden("train_step_v3000")
     mesh = common.scene_mesh(int(f["V"]))
     model = common.make_model(mesh, common.scene_state(mesh), cuda_device)
-    model.fused_autograd = fused_autograd
+    model.autograd_backend = backend
     model.train()
     lw = {str(k): float(v) for k, v in zip(f["loss_weight_keys"], f["loss_weight_vals"])}
     trainer = Trainer(model, loss_weights=lw, teacher_model=None, device_ids=[cuda_device.index or 0])
