@@ -164,6 +164,7 @@ int nm_grid_create(const float* verts_device, int64_t V, int leaf_level, nm_stre
     g->view.L = dg.L;
     g->view.V = (int)V;
     g->view.coop_extent = 0.75f * dg.root.root_size;   // (as nm_host_view)
+    g->view.n_nodes = (int)dg.n_nodes;
     g->view.nodes = dg.nodes;
     g->view.sverts = dg.sverts;
     g->verts = vcopy;
@@ -260,6 +261,10 @@ static NmPointSrc nm_src_xyz(const float* xyz, long long Q = 0) {
     s.lanes = 64;
     if (Q > 0)
         while (s.lanes > 8 && Q / s.lanes < 4096) s.lanes >>= 1;   // aim at >= 4096 waves (4 per SIMD of the chip)
+    static const int warm_env = getenv("NEUMESH_KNN_WARM") ? atoi(getenv("NEUMESH_KNN_WARM")) : 1;
+    static const int lanes_env = getenv("NEUMESH_KNN_LANES") ? atoi(getenv("NEUMESH_KNN_LANES")) : 0;
+    if (lanes_env > 0) s.lanes = lanes_env;
+    s.warm = (Q > 0 && Q < (1 << 20)) ? warm_env : 0;
     return s;
 }
 
@@ -780,7 +785,7 @@ int nm_train_backward(const nm_field_desc* d, nm_grid_t g, const nm_field_tables
     const int tangent = (with_nabla || (color && td.use_nabla)) ? 1 : 0;
     NmTrainWs s = nm_train_carve(workspace, P, td);
     const long long W = td.W, rows = tangent ? 2 * P : P, toff = P * W;
-    const unsigned strips = 256;      // workgroups of the strip-reducing head kernels (4 waves each)
+    const unsigned strips = (unsigned)(P / 64 < 64 ? 64 : P / 64 > 2048 ? 2048 : P / 64);   // workgroups of the strip-reducing head kernels (4 waves each, >= 16 points per wave)
     NM_HIP(hipMemsetAsync(s.dds, 0, (size_t)P * 4, stream));
     NM_HIP(hipMemsetAsync(s.dnab, 0, (size_t)P * 12, stream));
     float *cur = s.DA, *oth = s.DB;
@@ -792,7 +797,7 @@ int nm_train_backward(const nm_field_desc* d, nm_grid_t g, const nm_field_tables
         NM_LAUNCH_CHECK();
         NM_HIP(hipMemsetAsync(s.dWc0p, 0, (size_t)W * td.Kc0p * 4, stream));
         for (int l = td.Dc - 1; l >= 0; --l) {
-            if (out->col_bias[l]) hipLaunchKernelGGL(nm_t_colsum_kernel, dim3((unsigned)((P + 511) / 512)), dim3(256), 0, stream, cur, (long long)P, (int)W, out->col_bias[l]);
+            if (out->col_bias[l]) hipLaunchKernelGGL(nm_t_colsum_kernel, dim3((unsigned)((P + NM_T_COLSUM_ROWS - 1) / NM_T_COLSUM_ROWS)), dim3(256), 0, stream, cur, (long long)P, (int)W, out->col_bias[l]);
             if (l > 0) {
                 if (out->col_weight[l]) NM_T_GEMM(nm_t_gemm(cur, W, 0, s.HC[l - 1], W, 0, out->col_weight[l], W, W, W, P, 1), nm_t_split(W, W, P));
                 NmGemm m = nm_t_gemm(cur, W, 1, d->col_weight[l], W, 0, oth, W, P, W, W);
@@ -821,7 +826,7 @@ int nm_train_backward(const nm_field_desc* d, nm_grid_t g, const nm_field_tables
     }
     const unsigned act_blocks = (unsigned)((P * W / 4 + 255) / 256);
     for (int l = td.Dg - 1; l >= 0; --l) {
-        if (out->geo_bias[l]) hipLaunchKernelGGL(nm_t_colsum_kernel, dim3((unsigned)((P + 511) / 512)), dim3(256), 0, stream, cur, (long long)P, (int)W, out->geo_bias[l]);
+        if (out->geo_bias[l]) hipLaunchKernelGGL(nm_t_colsum_kernel, dim3((unsigned)((P + NM_T_COLSUM_ROWS - 1) / NM_T_COLSUM_ROWS)), dim3(256), 0, stream, cur, (long long)P, (int)W, out->geo_bias[l]);
         if (l > 0) {
             if (out->geo_weight[l]) NM_T_GEMM(nm_t_gemm(cur, W, 0, s.HT[l - 1], W, 0, out->geo_weight[l], W, W, W, rows, 1), nm_t_split(W, W, rows));
             NM_T_GEMM(nm_t_gemm(cur, W, 1, d->geo_weight[l], W, 0, oth, W, rows, W, W), 1);

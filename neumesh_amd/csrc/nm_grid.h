@@ -67,6 +67,7 @@ struct NmGridView {
     int L;                     // leaf level of the octree the records were built from
     int V;                     // number of vertices
     float coop_extent;         // waves whose queries fit a box of this edge search cooperatively
+    int n_nodes;               // number of node records
     const NmNode* nodes;       // node records, root = 0, levels stored one after another
     const float4* sverts;      // [V + 4] sorted vertices (.w = bit pattern of the original
                                // index), padded with 4 far-away dummies for batched scans

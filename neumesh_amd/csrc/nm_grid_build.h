@@ -200,6 +200,7 @@ static inline NmGridView nm_host_view(const NmHostGrid& g) {
     v.L = g.L;
     v.V = g.V;
     v.coop_extent = 0.75f * g.root_size;
+    v.n_nodes = (int)g.nodes.size();
     v.nodes = g.nodes.data();
     v.sverts = g.sverts.data();
     return v;

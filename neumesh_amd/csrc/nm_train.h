@@ -299,8 +299,9 @@ __global__ __launch_bounds__(256) void nm_t_col_head_bwd_kernel(NmTrainDims t, l
 }
 
 // column sums of D[rows, W] -> out[W] (bias gradients)
+#define NM_T_COLSUM_ROWS 64
 __global__ __launch_bounds__(256) void nm_t_colsum_kernel(const float* __restrict__ D, long long rows, int W, float* __restrict__ out) {
-    const long long r0 = (long long)blockIdx.x * 512, r1 = r0 + 512 < rows ? r0 + 512 : rows;
+    const long long r0 = (long long)blockIdx.x * NM_T_COLSUM_ROWS, r1 = r0 + NM_T_COLSUM_ROWS < rows ? r0 + NM_T_COLSUM_ROWS : rows;
     for (int c = threadIdx.x; c < W; c += 256) {
         float s = 0.f;
         for (long long r = r0; r < r1; ++r) s += D[r * W + c];

@@ -64,8 +64,30 @@ def quat_to_rot(q):
         torch.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1)], -2)
 
 
-def get_rays(c2w, intrinsics, H, W, N_rays=-1):
-    device = c2w.device
+def _to_device_async(t: torch.Tensor, device) -> torch.Tensor:
+    """Small host tensor -> device without draining the stream: a pageable host-to-device copy is synchronous with respect to the
+    host AND ordered in the stream, i.e. it waits for everything queued before it; a copy from pinned memory is just queued."""
+    if t.device.type == "cuda":
+        return t
+    return t.pin_memory().to(device, non_blocking=True)
+
+
+_LAST_SELECTION = [0, None]
+
+
+def host_selection(select_inds: torch.Tensor) -> torch.Tensor:
+    """Host copy of the pixel list get_rays returned last (it was drawn on the host: no device round trip), else .cpu()."""
+    if select_inds.device.type == "cuda" and _LAST_SELECTION[1] is not None and select_inds.data_ptr() == _LAST_SELECTION[0] \
+            and _LAST_SELECTION[1].shape == select_inds.shape:
+        return _LAST_SELECTION[1]
+    return select_inds.cpu()
+
+
+def get_rays(c2w, intrinsics, H, W, N_rays=-1, device=None):
+    """utils/rend_util.py:123-176.  `device` (extension): where the rays are produced when the pose is handed over on the host --
+    the reference moves the pose to the GPU first (trainer.py:61-63); a single pinhole pose is consumed on the host here (the
+    camera goes into the kernels by value), so no transfer and no stream synchronisation is needed for it."""
+    device = torch.device(device) if device is not None else c2w.device
     if c2w.shape[-1] == 7:  # quaternion + location
         R = quat_to_rot(c2w[..., :4])
         p = torch.eye(4, device=device).repeat([*c2w.shape[:-1], 1, 1]).float()
@@ -79,6 +101,18 @@ def get_rays(c2w, intrinsics, H, W, N_rays=-1):
         ro, rd = make_rays(p.reshape(4, 4), intrinsics.reshape(4, 4), H, W, device)
         sel = torch.arange(H * W, device=device).expand([*prefix, H * W])
         return ro.reshape(*prefix, H * W, 3), rd.reshape(*prefix, H * W, 3), sel
+    if p.numel() == 16 and N_rays > 0 and device.type == "cuda" and intrinsics.numel() == 16:
+        # training batch of one camera: the reference's two host-side draws (same generator, same order => the same pixels),
+        # one queued copy of the pixel list, rays by nm_make_rays_indexed
+        N_rays = min(N_rays, H * W)
+        hs = torch.randint(0, H, size=[N_rays])
+        wsel = torch.randint(0, W, size=[N_rays])
+        sel_host = hs * W + wsel
+        sel = _to_device_async(sel_host, device)
+        _LAST_SELECTION[:] = [sel.data_ptr(), sel_host.expand([*prefix, N_rays])]
+        ro, rd = make_rays_indexed(p.reshape(4, 4), intrinsics.reshape(4, 4), H, W, sel)
+        return ro.reshape(*prefix, N_rays, 3), rd.reshape(*prefix, N_rays, 3), sel.expand([*prefix, N_rays])
+    p, intrinsics = p.to(device), intrinsics.to(device)
     # general case in torch ops (same arithmetic as the reference)
     cam_loc = p[..., :3, 3]
     i, j = torch.meshgrid(torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H), indexing="ij")

@@ -315,8 +315,12 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
     # nm_render_rays does on the device for the fused path), so that 16 consecutive rays are neighbours in space even when
     # the caller hands over random pixels (training: trainer.py draws N_rays random pixels per step); per-ray outputs go
     # back to the caller's order at the end.  (trace: diagnostics follow the caller's rays one by one -- no reordering.)
+    # Fewer than 4096 rays per call are a training batch of random pixels (trainer.py draws 512 per step), not an image: neighbours
+    # in the ray order are then ~35 pixels apart, farther than an octree leaf, so a 16-ray x 4-sample tile is NOT a compact packet
+    # -- consecutive samples of ONE ray are (measured on a training step, K-NN kernel time: ray-major 7.1 ms, sorted + tiled 9.0).
+    dense = Rall >= 4096
     ray_inv = None
-    if Rall >= 32 and trace is None and not os.environ.get("NEUMESH_NO_RAY_SORT"):
+    if dense and trace is None and not os.environ.get("NEUMESH_NO_RAY_SORT"):
         with torch.no_grad():
             dn = rays_d / torch.linalg.norm(rays_d, dim=-1, keepdim=True).clamp_min(1e-12)
             pc = rays_o - (rays_o * dn).sum(-1, keepdim=True) * dn
@@ -337,7 +341,7 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
         in ray-major order a wave would get 64 samples strung along ONE ray and fall back to lane-private traversals),
         then whatever does not fill a tile.  Any order gives the same per-point results."""
         key = (R, P)
-        if os.environ.get("NEUMESH_NO_TILE_ORDER"):
+        if not dense or os.environ.get("NEUMESH_NO_TILE_ORDER"):
             return None
         if key not in tile_perms:
             idx = torch.arange(R * P, device=dev).view(R, P)

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .rays import get_rays
+from .rays import get_rays, host_selection
 from .renderer import SingleRenderer
 
 
@@ -74,15 +74,28 @@ class Trainer(nn.Module):
         """Pick N_rays random pixels of the batch's camera(s), render them, compare with the ground truth
         (models/trainer.py:50-117)."""
         lw = self.loss_weights
-        rays_o, rays_d, select_inds = get_rays(model_input["c2w"].to(device), model_input["intrinsics"].to(device),
-                                               render_kwargs_train["H"], render_kwargs_train["W"], N_rays=_cfg(args, "data", "N_rays"))
+        rays_o, rays_d, select_inds = get_rays(model_input["c2w"], model_input["intrinsics"], render_kwargs_train["H"], render_kwargs_train["W"],
+                                               N_rays=_cfg(args, "data", "N_rays"), device=device)
         distill = lw["distill_density"] > 0 or lw["distill_color"] > 0
         rgb, _depth, extras = self.renderer(rays_o, rays_d, detailed_output=True, samples_output=distill, **render_kwargs_train)
 
-        def pick(t):  # per-pixel ground truth of the selected rays
-            return torch.gather(t.to(device), 1, select_inds)
+        # Ground truth of the selected pixels: gathered WHERE THE IMAGE LIVES (the data loader hands over host tensors; the reference
+        # ships the whole image to the GPU every step, trainer.py:84-91) and only the N_rays values are sent -- from pinned memory, so
+        # the copy is queued instead of draining the stream.
+        sel_host = None
 
-        target_rgb = torch.gather(ground_truth["rgb"].to(device), 1, select_inds.unsqueeze(-1).expand(*select_inds.shape, 3))
+        def pick(t, width=0):
+            nonlocal sel_host
+            if t.device.type == "cuda":
+                idx = select_inds
+            else:
+                if sel_host is None:
+                    sel_host = host_selection(select_inds)
+                idx = sel_host
+            out = torch.gather(t, 1, idx.unsqueeze(-1).expand(*idx.shape, width) if width else idx)
+            return out if out.device.type == "cuda" else out.pin_memory().to(device, non_blocking=True)
+
+        target_rgb = pick(ground_truth["rgb"], 3)
         ret = self.compute_loss(
             args, rgb, target_rgb, extras,
             mask=pick(model_input["object_mask"]) if lw["mask"] > 0 else None,
@@ -120,6 +133,10 @@ class Trainer(nn.Module):
         else:
             keep, kind = (mask if mask_ignore is None else torch.logical_and(mask, mask_ignore)), "mean"
         loss = (per_pixel * keep[..., None].float()).sum() / (keep.sum() + 1e-10)
+        if kind == "mean":   # psnr(rgb[keep], target[keep]) without the host round trip of boolean indexing
+            k3 = keep[..., None].float()
+            mse = (((rgb - target_rgb) ** 2) * k3).sum() / (k3.sum() * rgb.shape[-1])
+            return loss, -10 * torch.log10(mse)
         return loss, psnr(rgb[keep], target_rgb[keep], reduction=kind)
 
     def compute_loss(self, args, rgb, target_rgb, extras, mask=None, mask_ignore=None, use_eikonal_loss=False,

@@ -38,6 +38,8 @@ t0 = time.perf_counter()
 for _ in range(8):
     step(); torch.cuda.synchronize()
 print("8 steps, one synchronisation after each step: ms per step", round((time.perf_counter() - t0) / 8 * 1e3, 2), flush=True)
+if os.environ.get("NM_TRAIN_STEPS_ONLY"):
+    sys.exit(0)
 if os.environ.get("NM_TRAIN_AB"):
     for tag, env in (("baseline", {"NEUMESH_NO_TILE_ORDER": "1", "NEUMESH_NO_RAY_SORT": "1"}), ("tile order", {"NEUMESH_NO_RAY_SORT": "1"}), ("tile order + ray sort", {}),
                      ("baseline", {"NEUMESH_NO_TILE_ORDER": "1", "NEUMESH_NO_RAY_SORT": "1"})):
