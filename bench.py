@@ -192,8 +192,9 @@ def consumer_rows(mesh, model, dev, H, W):
         lw = {"img": 1.0, "eikonal": 0.1, "mask": 0.1, "indicator_reg": 0.1, "distill_density": 0.0, "distill_color": 0.0}
         trainer = Trainer(model, loss_weights=lw, teacher_model=None, device_ids=[dev.index or 0])
         opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=0.0)   # (the full update runs; a zero step keeps the timed steps on one and the same field)
-        # (the view's tensors resident on the device, like every other timed input here; train.py's data loader hands over host tensors)
-        model_input = {"intrinsics": torch.from_numpy(np.asarray(K, np.float32))[None].to(dev), "c2w": torch.from_numpy(np.asarray(pose, np.float32))[None].to(dev),
+        # (the view's images resident on the device, like every other timed input here; the 4x4 pose / intrinsics stay host tensors, as
+        #  train.py's data loader hands them over: they go into the kernels by value)
+        model_input = {"intrinsics": torch.from_numpy(np.asarray(K, np.float32))[None], "c2w": torch.from_numpy(np.asarray(pose, np.float32))[None],
                        "object_mask": torch.ones(1, H * W, dtype=torch.bool, device=dev)}
         gt = {"rgb": torch.full((1, H * W, 3), 0.5, device=dev)}
         kw = dict(N_nograd_samples=2048, N_upsample_iters=4, obj_bounding_radius=1.0, batched=True, perturb=True, white_bkgd=False,
@@ -208,12 +209,18 @@ def consumer_rows(mesh, model, dev, H, W):
             ret["losses"]["total"].backward()
             opt.step()
         dt = timed(step, 8, 8)   # (the first steps pay for allocator growth and GEMM heuristics)
+        backend = model.autograd_backend
+        model.autograd_backend = "torch"      # the same step with the field evaluated by torch ops under autograd (what rounds 1-2 measured)
+        dt_torch = timed(step, 4, 4)
+        model.autograd_backend = backend
         model.load_state_dict(saved)
         model.train(was_training)
         for p_ in model.parameters():
             p_.grad = None
         out["train_step (512 rays x 128 samples of one view, img + eikonal + mask + indicator losses, forward + backward + Adam)"] = {
-            "ms_per_step": dt * 1e3, "value": 512 / dt, "unit": "rays/s", "steps": 8}
+            "ms_per_step": dt * 1e3, "value": 512 / dt, "unit": "rays/s", "steps": 8,
+            "field_backend": f"{backend}: nm_train_forward / nm_train_backward (closed-form reverse pass, fp32 MFMA GEMMs)" if backend == "hip" else backend,
+            "ms_per_step_torch_autograd_field": dt_torch * 1e3}
     except Exception as ex:
         out["train_step"] = {"error": str(ex)[-300:]}
     o, d = frame_rays(0, H, W)
@@ -557,6 +564,21 @@ def main():
         traffic, tsrc = _load_profile("pmc_traffic")
         mfma_pmc, msrc = _load_profile("pmc_mfma")
         knn_pmc, ksrc = _load_profile("pmc_knn")
+        issue = None
+        if knn_pmc and "knn_probe_bounds" in knn_pmc and "knn_distance" in knn_pmc and kd["ms"] > 0:
+            # Issue-bound roofline of the K-NN kernels: vector instructions (wave-wide) the kernels executed per
+            # searched point, from the committed SQ counter pass of this same workload (one probe launch per frame there), against the
+            # rate the 1024 SIMDs can issue them: a wave64 fp32 vector instruction occupies a 16-lane SIMD for 4 cycles.
+            frames_p = max(int(knn_pmc["knn_probe_bounds"].get("launches", 1)), 1)
+            valu = sum(knn_pmc[k]["counters"]["SQ_INSTS_VALU"] for k in ("knn_probe_bounds", "knn_distance")) / frames_p
+            salu = sum(knn_pmc[k]["counters"]["SQ_INSTS_SALU"] for k in ("knn_probe_bounds", "knn_distance")) / frames_p
+            pts_f = kd["points"] / max(args.steps, 1)
+            ms_f = kd["ms"] / max(args.steps, 1)
+            valu_peak = 256 * 4 * 2.4e9 / 4 / 1e9
+            issue = {"bound": "vector-instruction issue", "valu_wave_instructions_per_searched_point": valu / pts_f,
+                     "salu_wave_instructions_per_searched_point": salu / pts_f,
+                     "achieved": valu / (ms_f * 1e-3) / 1e9, "peak": valu_peak, "unit": "G wave-instructions/s (VALU)", "frac": valu / (ms_f * 1e-3) / 1e9 / valu_peak,
+                     "note": "instruction counts from the profile named in issue_pmc_source (same workload), time from this run"}
         nabla_k, fixed_k = {"geo_mlp": "false", "geo_mlp_tangent": "true"}, "true"
         kname = ({"geo_mlp": "nm_geo_mlp_h2_kernel<false,true,NP>", "geo_mlp_tangent": "nm_geo_mlp_h2_kernel<true,true,NP>", "color_mlp": "nm_col_mlp_h2_kernel<true,NP>"} if split else
                  {"geo_mlp": "nm_geo_mlp_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_kernel<true>", "color_mlp": "nm_col_mlp_kernel"})[dom]
@@ -612,7 +634,7 @@ def main():
                            "ms_per_frame": kd["ms"] / max(n_frames, 1),
                            "algorithmic_GBs_at_76B_per_query": searched_per_s * KNN_BYTES_PER_QUERY / 1e9,
                            "hbm_frac_at_76B_per_query": searched_per_s * KNN_BYTES_PER_QUERY / 1e9 / PEAK_HBM_GBS,
-                           "issue_pmc": knn_pmc, "issue_pmc_source": ksrc,
+                           "issue_roofline": issue, "issue_pmc": knn_pmc, "issue_pmc_source": ksrc,
                            "traffic": (traffic or {}).get("knn_distance", {}).get("hbm_bytes_per_launch")},
         }
         cfgd = out["config"]
@@ -674,6 +696,9 @@ def main():
                 extra["other_scene"] = {"error": str(ex)}
             model.mlp_precision = args.mlp_precision
             extra.update(consumer_rows(mesh, model, dev, args.H, args.W))
+            for k_, v_ in extra.items():
+                if k_.startswith("train_step") and "ms_per_step" in v_:
+                    cfgd["train_step_ms_512_rays"], cfgd["train_step_ms_512_rays_torch_autograd_field"] = v_["ms_per_step"], v_.get("ms_per_step_torch_autograd_field")
         if world == 1 and args.cpu_rays > 0:
             try:
                 r0 = (rays0[0].cpu().numpy(), rays0[1].cpu().numpy())
