@@ -261,10 +261,10 @@ static NmPointSrc nm_src_xyz(const float* xyz, long long Q = 0) {
     s.lanes = 64;
     if (Q > 0)
         while (s.lanes > 8 && Q / s.lanes < 4096) s.lanes >>= 1;   // aim at >= 4096 waves (4 per SIMD of the chip)
-    static const int warm_env = getenv("NEUMESH_KNN_WARM") ? atoi(getenv("NEUMESH_KNN_WARM")) : 1;
-    static const int lanes_env = getenv("NEUMESH_KNN_LANES") ? atoi(getenv("NEUMESH_KNN_LANES")) : 0;
+#ifdef NM_TESTING
+    static const int lanes_env = getenv("NEUMESH_KNN_LANES") ? atoi(getenv("NEUMESH_KNN_LANES")) : 0;   // tools/knn_small.py: queries per wave A/B
     if (lanes_env > 0) s.lanes = lanes_env;
-    s.warm = (Q > 0 && Q < (1 << 20)) ? warm_env : 0;
+#endif
     return s;
 }
 

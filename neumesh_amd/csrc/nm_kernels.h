@@ -46,31 +46,7 @@ struct NmPointSrc {
     const int* ray_index;
     // mode 2 (optional): the P samples are proposals p_off .. p_off + P - 1 of a p_total-point linspace (0 = the P points themselves)
     int p_off, p_total;
-    // small launches: every workgroup first touches its share of the node records and sorted vertices (nm_warm_index)
-    int warm;
 };
-
-// The L2 of an XCD starts a kernel without the mesh index (the caches are written back / invalidated at kernel boundaries), and
-// the traversal is a chain of ~150 DEPENDENT loads per wave: in a launch that lives for one wave's traversal every link of that
-// chain is a miss to the memory side (measured: 0.4 ms for 512 coherent queries, 35 us per wave in the steady state of a big
-// launch).  Here the workgroups of one XCD (workgroups are dealt round robin to the 8 XCDs) share the job of touching every
-// 128-byte line of the node records and the sorted vertices once, all loads independent, before they start walking.
-__device__ __forceinline__ void nm_warm_index(const NmGridView& g) {
-    const long long lines_n = ((long long)g.n_nodes * (long long)sizeof(NmNode) + 127) >> 7;
-    const long long lines = lines_n + ((((long long)g.V + 4) * 16 + 127) >> 7);
-    const long long per_xcd = (gridDim.x + 7) >> 3, me = blockIdx.x >> 3;
-    const long long share = (lines + per_xcd - 1) / per_xcd;
-    const long long lo = me * share, hi = lo + share < lines ? lo + share : lines;
-    unsigned acc = 0;
-    int n = 0;
-    for (long long i = lo + threadIdx.x; i < hi && n < 64; i += blockDim.x, ++n) {
-        const char* base = i < lines_n ? reinterpret_cast<const char*>(g.nodes) + (i << 7)
-                                       : reinterpret_cast<const char*>(g.sverts) + ((i - lines_n) << 7);
-        acc ^= *reinterpret_cast<const unsigned*>(base);
-    }
-    if (acc == 0x9e3779b9u && g.V < 0) *reinterpret_cast<volatile unsigned*>(const_cast<NmNode*>(g.nodes)) = acc;   // never taken: keeps the loads
-    __syncthreads();
-}
 
 // (r, p) = (ray, sample) of query q = r*P + p, as produced by nm_lane_query (mode 0: r = q, p = 0)
 __device__ __forceinline__ long long nm_out_index(const NmPointSrc& s, long long q, long long r, int p) {
@@ -399,7 +375,6 @@ __device__ __forceinline__ float nm_bound_from_neighbours(const float* __restric
 template <int K>
 __global__ __launch_bounds__(NM_KNN_BLOCK) void nm_knn_kernel(NmGridView g, NmPointSrc src, long long Q, int Kout,
                                                      long long* __restrict__ idx_out, float* __restrict__ d2_out) {
-    if (src.warm) nm_warm_index(g);
     long long q, r;
     int p;
     const bool active = nm_lane_query(src, Q, q, r, p);
@@ -438,7 +413,6 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_W
     // proven bound -- the K-th-neighbour radius of the LAST sample of the previous tile on the same
     // ray plus the depth gap to it (triangle inequality along a unit direction) -- instead of +INF.
     // (CHAIN = false is the plain single-tile kernel: no loop-carried state in its registers)
-    if (src.warm) nm_warm_index(g);
     const int chain = CHAIN ? nm_chain_len(src) : 1;
     const int lane = threadIdx.x & 63;
     float prev_rad = NM_INF_F, prev_dep = 0.f;

@@ -91,3 +91,43 @@ def test_hip_field_ragged_and_empty(cuda_device, torch_mod):
     s0, n0 = model.forward_with_nablas(xyz[:0])
     assert s0.shape == (0, 1) and n0.shape == (0, 3)
     (s0.sum() + n0.sum()).backward()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(D_density=2, D_color=3, W=128, geometry_dim=16, color_dim=8, multires_view=2, multires_d=4, multires_fg=1, multires_ft=0,
+         enable_nablas_input=False, learn_indicator_weight=False),
+    dict(D_density=4, D_color=2, W=64, geometry_dim=8, color_dim=16, multires_view=0, multires_d=2, multires_fg=0, multires_ft=3,
+         enable_nablas_input=True, learn_indicator_weight=True),
+])
+def test_hip_field_other_configurations(cuda_device, torch_mod, cfg):
+    """The training kernels take their sizes from the descriptor (any width that is a multiple of 16, any depth up to 8, any
+    band counts, with / without the nabla input and the learned indicator weight): two configurations that are not the reference's
+    default, random default-init weights, against the torch-op restatement.  (The fused INFERENCE kernels are built for W = 256,
+    so only the autograd-side methods are used here.)"""
+    torch = torch_mod
+    from neumesh_amd import MeshGrid, NeuMesh
+    mesh = common.scene_mesh(3000)
+    torch.manual_seed(4)
+    model = NeuMesh(MeshGrid(common.MeshObj(mesh), cuda_device), **cfg).to(cuda_device)
+    with torch.no_grad():
+        model.geometry_features.mul_(0.3)
+        model.color_features.mul_(0.3)
+        model.ln_s.fill_(0.3)
+    model.train()
+    xyz, dirs = _points(mesh, 1500, 8, cuda_device, torch)
+    gen = torch.Generator(device="cpu").manual_seed(2)
+    for mode in ("density_nabla", "forward"):
+        def run(backend):
+            model.autograd_backend = backend
+            return model.forward_with_nablas(xyz.clone()) if mode == "density_nabla" else model.forward(xyz.clone(), dirs)
+        out_t = run("torch")
+        cots = [torch.randn(o.shape, generator=gen).to(cuda_device) for o in out_t]
+        g_t = _grads(model, out_t, cots, torch)
+        out_h = run("hip")
+        g_h = _grads(model, out_h, cots, torch)
+        for a, b in zip(out_h, out_t):
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), mode
+        assert set(g_h) == set(g_t)
+        for name in g_t:
+            err, scale = float((g_h[name].double() - g_t[name].double()).abs().max()), float(g_t[name].abs().max())
+            assert err <= 2e-3 * scale + 1e-7, (mode, name, err, scale)

@@ -1,4 +1,5 @@
-"""tools/knn_small.py -- GPU box: K-NN + distance kernel time of small point sets (a training step's launches) in different point orders."""
+"""tools/knn_small.py -- GPU box: K-NN + distance kernel time of small point sets (a training step's launches) in different point orders.
+(NEUMESH_KNN_LANES=n forces the number of queries per wave: honoured by the -DNM_TESTING build only -- NEUMESH_HIP_LIB=tests/_build/libneumesh_hip_testing.so.)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
