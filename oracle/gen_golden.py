@@ -227,7 +227,8 @@ def gen_grad_fixture(tag, render_tag, V, mlp_state):
                         rgb=rgb[0].detach().numpy(), **grads)
 
 
-def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=800, mlp_state=None, s_value=200.0):
+def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=800, mlp_state=None, s_value=200.0,
+                      n_samples=64, n_importance=64, white_bkgd=False):
     """Headline-scale pin (BASELINE configs[1] shape, SURVEY 8d scene S-DTU): `n_rays` strided rays of
     frame 0 of the 800x800 orbit rendered by the IMPORTED REFERENCE at V = 140 000, with the stages a
     diverging ray can be traced through (near/far, coarse SDF, sorted depths after every up-sampling
@@ -258,7 +259,7 @@ def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=8
     sel = np.linspace(0, H * W - 1, n_rays).astype(np.int64)
     rays_o, rays_d = o_all[sel], d_all_[sel]
     kw = dict(kw)
-    kw.update(rayschunk=n_rays, calc_normal=True, N_samples=64, N_importance=64, perturb=False, white_bkgd=False)
+    kw.update(rayschunk=n_rays, calc_normal=True, N_samples=n_samples, N_importance=n_importance, perturb=False, white_bkgd=white_bkgd)
 
     def run(rd, trace):
         """one reference render; trace (dict or None) receives the per-stage arrays"""
@@ -309,7 +310,7 @@ def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=8
     t_ref = time.perf_counter() - t0
     print(f"    reference render: {t_ref:.1f} s ({n_rays / t_ref:.0f} rays/s on {os.cpu_count()} cores, torch threads {torch.get_num_threads()})")
     d_all = trace["d_iter4"]
-    assert d_all.shape == (n_rays, 128)
+    assert d_all.shape == (n_rays, n_samples + n_importance)
     acc = ref["mask_volume"]
     stats = {"rays_acc_eq_0": int((acc == 0).sum()), "rays_acc_lt_1e-3": int((acc < 1e-3).sum()),
              "rays_partial(1e-3..0.999)": int(((acc >= 1e-3) & (acc <= 0.999)).sum()), "rays_acc_gt_0.999": int((acc > 0.999).sum()),
@@ -334,7 +335,7 @@ def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=8
     # oracle restatement on the same rays (report; the V=3000 fixtures gate it tightly)
     orc = oracle_from_reference(model, mesh)
     orc.knn_fn = lambda q, v, K: oknn.knn_kdtree(q, v, K, tree=tree)
-    out = orender.render_rays(orc, rays_o, rays_d, orender.RenderConfig(calc_normal=True), detailed=True)
+    out = orender.render_rays(orc, rays_o, rays_d, orender.RenderConfig(calc_normal=True, N_samples=n_samples, N_importance=n_importance, white_bkgd=white_bkgd), detailed=True)
     e = np.abs(out["rgb"] - ref["rgb"]).max(-1)
     same = np.all(out["d_all"] == d_all, axis=1)
     print(f"    oracle vs reference: {int((e > 1e-4).sum())}/{n_rays} rays > 1e-4, median {np.median(e):.1e}, PSNR {compare.psnr(out['rgb'], ref['rgb']):.1f} dB; "
@@ -354,6 +355,7 @@ def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=8
         sdf_all=ref["implicit_surface"].astype(np.float32),
         rgb=ref["rgb"], depth_volume=ref["depth_volume"], mask_volume=ref["mask_volume"], normals_volume=ref["normals_volume"],
         self_err_1ulp=self_err, s=np.float32(model.forward_s().item()), state_sha256=np.array(state_digest(mlp_state) if mlp_state is not None else ""),
+        N_samples=np.int64(n_samples), N_importance=np.int64(n_importance), white_bkgd=np.int64(white_bkgd),
     )
 
 
@@ -518,12 +520,15 @@ def gen_rays_fixture():
 
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
-    if len(sys.argv) > 1 and sys.argv[1] in ("scale", "train", "surface", "surf"):   # only one of the later fixtures (the others are unchanged)
+    if len(sys.argv) > 1 and sys.argv[1] in ("scale", "train", "surface", "surf", "surf3"):   # only one of the later fixtures (the others are unchanged)
         sd = dict(np.load(os.path.join(GOLDEN, "model_seed0.npz")))
         if sys.argv[1] == "scale":
             gen_scale_fixture("render_v140k_dtu", mlp_state=sd)
         elif sys.argv[1] == "surf":   # the scene with a surface (neumesh_amd.synthetic.surface_mlp_state), s = 400
             gen_scale_fixture("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0)
+        elif sys.argv[1] == "surf3":  # BASELINE configs[3] shape (32 + 32 samples, white background) on the same scene, at headline scale
+            gen_scale_fixture("render_v140k_surf_c3", n_rays=1024, mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0,
+                              n_samples=32, n_importance=32, white_bkgd=True)
         elif sys.argv[1] == "train":
             gen_train_step_fixture("train_step_v3000", V=3000, mlp_state=sd)
         else:
@@ -548,6 +553,8 @@ def main():
     gen_surface_fixture("surface_v3000", V=3000, mlp_state=sd)
     gen_scale_fixture("render_v140k_dtu", mlp_state=sd)
     gen_scale_fixture("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0)
+    gen_scale_fixture("render_v140k_surf_c3", n_rays=1024, mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0,
+                      n_samples=32, n_importance=32, white_bkgd=True)
     with open(os.path.join(GOLDEN, "REPORT.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
     print("all oracle-vs-reference checks passed; fixtures written to", GOLDEN)

