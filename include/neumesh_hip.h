@@ -344,6 +344,20 @@ int nm_train_backward(const nm_field_desc* desc, nm_grid_t g, const nm_field_tab
                       const float* g_sdf, const float* g_nabla, const float* g_rgb, void* workspace,
                       const nm_train_grads* out, nm_stream_t stream);
 
+/* Differentiable compositing of the training step (renderer.py:264-333: sdf_to_alpha, alpha_to_w, the weighted sums) on given sample SDFs
+ * sdf [R,N] at sorted depths, mid-point depths d_mid (row stride d_mid_stride >= N-1), radiance [R,N-1,3] (or NULL), nablas [R,N,3] (or NULL:
+ * no normals), s = forward_s() read from DEVICE memory (one float).  Forward writes rgb [R,3], depth [R], acc [R], normals [R,3] and the
+ * per-sample cdf [R,N], alpha / weights / transmittance [R,N-1] (the last three are also what backward reads back).  Backward: cotangents of
+ * rgb / depth / acc / normals (NULL = zero) -> g_sdf [R,N], g_radiance [R,N-1,3], g_nablas [R,N,3] (either may be NULL), and g_s[0] += d/ds. */
+int nm_train_composite_forward(const float* sdf, const float* s, const float* d_mid, int d_mid_stride, const float* radiance,
+                               const float* nablas, int64_t R, int N, int white_bkgd, float* rgb, float* depth, float* acc, float* normals,
+                               float* cdf, float* alpha, float* weights, float* transmittance, nm_stream_t stream);
+int nm_train_composite_backward(const float* sdf, const float* s, const float* d_mid, int d_mid_stride, const float* radiance,
+                                const float* nablas, int64_t R, int N, int white_bkgd, const float* cdf, const float* alpha,
+                                const float* weights, const float* transmittance, const float* acc, const float* depth,
+                                const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_normals,
+                                float* g_sdf, float* g_radiance, float* g_nablas, float* g_s, nm_stream_t stream);
+
 /* ----------------------------------------------------------------------------- image assembly
  * What render.py:219-249 does on the host with the three outputs of a frame, per pixel, on the device
  * (the frame then leaves the GPU as 7 bytes per pixel instead of 28):

@@ -113,6 +113,9 @@ SIGNATURES = {
     "nm_train_forward": (C.c_int, [C.POINTER(FieldDesc), _P, C.POINTER(FieldTables), _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P]),
     "nm_train_backward": (C.c_int, [C.POINTER(FieldDesc), _P, C.POINTER(FieldTables), C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P,
                                     C.POINTER(TrainGrads), _P]),
+    "nm_train_composite_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "nm_train_composite_backward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P,
+                                              _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "nm_surface_workspace_bytes": (C.c_int64, [_P, C.c_int64]),
     "nm_surface_hits": (C.c_int, [_P, _P, C.POINTER(FieldTables), _P, _P, C.c_int64, _P, C.POINTER(SurfaceCfg), _P, _P, _P, _P, _P, _P]),
     "nm_assemble_frame": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P]),

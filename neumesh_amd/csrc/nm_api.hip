@@ -728,7 +728,6 @@ int nm_train_forward(const nm_field_desc* d, nm_grid_t g, const nm_field_tables*
     if (with_nabla && !nabla) return nm_fail("nm_train_forward: nabla is NULL");
     NmTrainWs s = nm_train_carve(workspace, P, td);
     const long long W = td.W, rows = tangent ? 2 * P : P, toff = P * W;
-    NM_HIP(hipMemcpyAsync(s.xyz, xyz, (size_t)P * 12, hipMemcpyDeviceToDevice, stream));
     const NmGather ga = {t->geometry_features, td.G, s.fg, color ? t->color_features : nullptr, color ? td.Cd : 0, color ? s.ft : nullptr};
     if (nm_launch_distance(g, nm_src_xyz(xyz, P), P, t->indicator_vector, t->indicator_weight, s.ds, s.idx, nullptr, s.w, s.gds, stream,
                            nullptr, ga)) return 1;
@@ -736,7 +735,7 @@ int nm_train_forward(const nm_field_desc* d, nm_grid_t g, const nm_field_tables*
     if (color)
         hipLaunchKernelGGL(nm_t_pad_kernel, dim3((unsigned)((W * td.Kc0p + 255) / 256)), dim3(256), 0, stream, d->col_weight[0], s.Wc0p, (int)W, td.Kc0, td.Kc0p, 0);
     hipLaunchKernelGGL(nm_t_embed_kernel, dim3((unsigned)((P + 7) / 8)), dim3(256), 0, stream, td, (long long)P, s.ds, s.fg, color ? s.ft : nullptr, view_dirs,
-                       s.X0, s.T0, color ? s.C0 : nullptr);
+                       s.X0, s.T0, color ? s.C0 : nullptr, xyz, s.xyz);
     NM_LAUNCH_CHECK();
     // geometry MLP on (value | tangent) rows
     {
@@ -755,10 +754,8 @@ int nm_train_forward(const nm_field_desc* d, nm_grid_t g, const nm_field_tables*
         hipLaunchKernelGGL(nm_t_softplus_kernel, dim3(act_blocks), dim3(256), 0, stream, s.ZU[l], s.HT[l], P * W, toff, tangent);
     }
     hipLaunchKernelGGL(nm_t_geo_head_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, stream, td, (long long)P, s.HT[td.Dg - 1], d->density_weight,
-                       d->density_bias, s.gds, tangent, s.sdf, s.alpha, s.nabla, color ? s.C0 : nullptr);
+                       d->density_bias, s.gds, tangent, s.sdf, s.alpha, s.nabla, color ? s.C0 : nullptr, sdf, nabla);
     NM_LAUNCH_CHECK();
-    NM_HIP(hipMemcpyAsync(sdf, s.sdf, (size_t)P * 4, hipMemcpyDeviceToDevice, stream));
-    if (nabla && tangent) NM_HIP(hipMemcpyAsync(nabla, s.nabla, (size_t)P * 12, hipMemcpyDeviceToDevice, stream));
     if (!color) return 0;
     for (int l = 0; l < td.Dc; ++l) {
         NmGemm m = l == 0 ? nm_t_gemm(s.C0, td.Kc0p, 1, s.Wc0p, td.Kc0p, 1, s.HC[0], W, P, W, td.Kc0p)
@@ -766,9 +763,38 @@ int nm_train_forward(const nm_field_desc* d, nm_grid_t g, const nm_field_tables*
         m.bias = d->col_bias[l]; m.bias_rows = P; m.relu = 1;
         NM_T_GEMM(m, 1);
     }
-    hipLaunchKernelGGL(nm_t_col_head_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, stream, td, (long long)P, s.HC[td.Dc - 1], d->rgb_weight, d->rgb_bias, s.rgb);
+    hipLaunchKernelGGL(nm_t_col_head_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, stream, td, (long long)P, s.HC[td.Dc - 1], d->rgb_weight, d->rgb_bias, s.rgb, rgb);
     NM_LAUNCH_CHECK();
-    NM_HIP(hipMemcpyAsync(rgb, s.rgb, (size_t)P * 12, hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+
+int nm_train_composite_forward(const float* sdf, const float* s, const float* d_mid, int d_mid_stride, const float* radiance,
+                               const float* nablas, int64_t R, int N, int white_bkgd, float* rgb, float* depth, float* acc, float* normals,
+                               float* cdf, float* alpha, float* weights, float* transmittance, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (R < 0 || N < 2 || d_mid_stride < N - 1) return nm_fail("nm_train_composite_forward: bad sizes");
+    if (R == 0) return 0;
+    if (!sdf || !s || !d_mid || !rgb || !depth || !acc || !cdf || !alpha || !weights || !transmittance) return nm_fail("nm_train_composite_forward: NULL argument");
+    if (nablas && !normals) return nm_fail("nm_train_composite_forward: normals is NULL");
+    hipLaunchKernelGGL(nm_t_composite_fwd_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, stream, (long long)R, N, sdf, s, d_mid, d_mid_stride, radiance,
+                       nablas, white_bkgd, rgb, depth, acc, nablas ? normals : nullptr, cdf, alpha, weights, transmittance);
+    NM_LAUNCH_CHECK();
+    return 0;
+}
+
+int nm_train_composite_backward(const float* sdf, const float* s, const float* d_mid, int d_mid_stride, const float* radiance,
+                                const float* nablas, int64_t R, int N, int white_bkgd, const float* cdf, const float* alpha,
+                                const float* weights, const float* transmittance, const float* acc, const float* depth,
+                                const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_normals,
+                                float* g_sdf, float* g_radiance, float* g_nablas, float* g_s, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (R < 0 || N < 2 || d_mid_stride < N - 1) return nm_fail("nm_train_composite_backward: bad sizes");
+    if (R == 0) return 0;
+    if (!sdf || !s || !d_mid || !cdf || !alpha || !weights || !transmittance || !acc || !depth || !g_sdf) return nm_fail("nm_train_composite_backward: NULL argument");
+    hipLaunchKernelGGL(nm_t_composite_bwd_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, stream, (long long)R, N, sdf, s, d_mid, d_mid_stride, radiance,
+                       nablas, white_bkgd, cdf, alpha, weights, transmittance, acc, depth, g_rgb, g_depth, g_acc, nablas ? g_normals : nullptr, g_sdf,
+                       g_radiance, nablas ? g_nablas : nullptr, g_s);
+    NM_LAUNCH_CHECK();
     return 0;
 }
 

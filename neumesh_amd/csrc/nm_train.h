@@ -131,10 +131,12 @@ __global__ void nm_t_pad_kernel(const float* __restrict__ src, float* __restrict
 // colour input C0 = [nabla | emb(ds) | emb(view) | emb(ft)] (the nabla columns are written by the geometry head).
 __global__ __launch_bounds__(256) void nm_t_embed_kernel(NmTrainDims t, long long P, const float* __restrict__ ds, const float* __restrict__ fg,
                                                          const float* __restrict__ ft, const float* __restrict__ view,
-                                                         float* __restrict__ X0, float* __restrict__ T0, float* __restrict__ C0) {
+                                                         float* __restrict__ X0, float* __restrict__ T0, float* __restrict__ C0,
+                                                         const float* __restrict__ xyz, float* __restrict__ xyz_keep) {
     const long long p = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
     const int j = threadIdx.x & 31;
     if (p >= P) return;
+    if (j < 3) xyz_keep[p * 3 + j] = xyz[p * 3 + j];      // the backward pass of the distance stage needs the positions again
     const float d = ds[p];
     float* x0 = X0 + p * t.K0p;
     float* t0 = T0 + p * t.Kt;
@@ -212,7 +214,7 @@ __device__ __forceinline__ float nm_t_wave_sum(float v) {
 __global__ __launch_bounds__(256) void nm_t_geo_head_kernel(NmTrainDims t, long long P, const float* __restrict__ HT, const float* __restrict__ wd,
                                                             const float* __restrict__ bd, const float* __restrict__ gds, int tangent,
                                                             float* __restrict__ sdf, float* __restrict__ alpha, float* __restrict__ nabla,
-                                                            float* __restrict__ C0) {
+                                                            float* __restrict__ C0, float* __restrict__ sdf_out, float* __restrict__ nabla_out) {
     const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= P) return;
@@ -226,18 +228,20 @@ __global__ __launch_bounds__(256) void nm_t_geo_head_kernel(NmTrainDims t, long 
     a = nm_t_wave_sum(a);
     if (lane == 0) {
         sdf[p] = s + bd[0];
+        sdf_out[p] = s + bd[0];
         if (tangent) alpha[p] = a;
     }
     if (tangent && lane < 3) {
         const float nv = a * gds[p * 3 + lane];
         nabla[p * 3 + lane] = nv;
+        if (nabla_out) nabla_out[p * 3 + lane] = nv;
         if (C0 && t.use_nabla) C0[p * t.Kc0p + lane] = nv;
     }
 }
 
 // colour head (neumesh.py:103,259): rgb = sigmoid(h Wr^T + br)
 __global__ __launch_bounds__(256) void nm_t_col_head_kernel(NmTrainDims t, long long P, const float* __restrict__ HC, const float* __restrict__ Wr,
-                                                            const float* __restrict__ br, float* __restrict__ rgb) {
+                                                            const float* __restrict__ br, float* __restrict__ rgb, float* __restrict__ rgb_out) {
     const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (p >= P) return;
@@ -249,7 +253,9 @@ __global__ __launch_bounds__(256) void nm_t_col_head_kernel(NmTrainDims t, long 
     a0 = nm_t_wave_sum(a0); a1 = nm_t_wave_sum(a1); a2 = nm_t_wave_sum(a2);
     if (lane < 3) {
         const float z = (lane == 0 ? a0 : lane == 1 ? a1 : a2) + br[lane];
-        rgb[p * 3 + lane] = 1.0f / (1.0f + expf(-z));
+        const float c = 1.0f / (1.0f + expf(-z));
+        rgb[p * 3 + lane] = c;
+        rgb_out[p * 3 + lane] = c;
     }
 }
 
@@ -481,4 +487,114 @@ __global__ __launch_bounds__(256) void nm_t_distance_bwd_kernel(long long P, con
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = gw1;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(dw1, part[0] + part[1] + part[2] + part[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ differentiable compositing
+// renderer.py:264-333 on given sample SDFs (sdf_to_alpha :17-24, alpha_to_w :49-63, the weighted sums :299-333) with its reverse pass.
+// One lane per ray, serial over the samples (the transmittance is a running product).  s = forward_s() is read from device memory
+// (it is a function of the trained ln_s: its gradient is returned, and reading it on the host would drain the stream).
+//   c_i = sigmoid(s sdf_i),  a_i = max((c_i - c_{i+1}) / (c_i + 1e-10), 0),  T_0 = 1,  T_{i+1} = T_i (1 - a_i + 1e-10),  w_i = a_i T_i
+//   rgb = sum w_i rad_i (+ 1 - acc on a white background),  acc = sum w_i,  depth = sum w_i d_i / (acc + 1e-10),
+//   normals = sum w_i nabla_i / max(|nabla_i|, 1e-12)
+__device__ __forceinline__ float nm_t_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(64) void nm_t_composite_fwd_kernel(long long R, int N, const float* __restrict__ sdf, const float* __restrict__ s_ptr,
+                                                                const float* __restrict__ dmid, int dmid_stride, const float* __restrict__ rad,
+                                                                const float* __restrict__ nab, int white, float* __restrict__ rgb,
+                                                                float* __restrict__ depth, float* __restrict__ acc, float* __restrict__ normals,
+                                                                float* __restrict__ cdf, float* __restrict__ alpha, float* __restrict__ w_out,
+                                                                float* __restrict__ trans) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float s = s_ptr[0];
+    const float* sd = sdf + r * N;
+    float c0 = nm_t_sigmoid(sd[0] * s), T = 1.0f;
+    float cr = 0.f, cg = 0.f, cb = 0.f, A = 0.f, D = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+    for (int i = 0; i < N - 1; ++i) {
+        const float c1 = nm_t_sigmoid(sd[i + 1] * s);
+        const float a = fmaxf((c0 - c1) / (c0 + 1e-10f), 0.f);
+        const float w = a * T;
+        const long long m = r * (N - 1) + i;
+        cdf[r * N + i] = c0; alpha[m] = a; w_out[m] = w; trans[m] = T;
+        if (rad) { cr += w * rad[m * 3]; cg += w * rad[m * 3 + 1]; cb += w * rad[m * 3 + 2]; }
+        A += w;
+        D += w * dmid[r * dmid_stride + i];
+        if (nab) {
+            const float x = nab[(r * N + i) * 3], y = nab[(r * N + i) * 3 + 1], z = nab[(r * N + i) * 3 + 2];
+            const float inv = 1.0f / fmaxf(sqrtf(x * x + y * y + z * z), 1e-12f);
+            nx += w * x * inv; ny += w * y * inv; nz += w * z * inv;
+        }
+        T = T * (1.0f - a + 1e-10f);
+        c0 = c1;
+    }
+    cdf[r * N + N - 1] = c0;
+    if (white) { cr += 1.0f - A; cg += 1.0f - A; cb += 1.0f - A; }
+    rgb[r * 3] = cr; rgb[r * 3 + 1] = cg; rgb[r * 3 + 2] = cb;
+    acc[r] = A;
+    depth[r] = D / (A + 1e-10f);
+    if (normals) { normals[r * 3] = nx; normals[r * 3 + 1] = ny; normals[r * 3 + 2] = nz; }
+}
+
+__global__ __launch_bounds__(64) void nm_t_composite_bwd_kernel(long long R, int N, const float* __restrict__ sdf, const float* __restrict__ s_ptr,
+                                                                const float* __restrict__ dmid, int dmid_stride, const float* __restrict__ rad,
+                                                                const float* __restrict__ nab, int white, const float* __restrict__ cdf,
+                                                                const float* __restrict__ alpha, const float* __restrict__ w_in,
+                                                                const float* __restrict__ trans, const float* __restrict__ acc,
+                                                                const float* __restrict__ depth, const float* __restrict__ g_rgb,
+                                                                const float* __restrict__ g_depth, const float* __restrict__ g_acc,
+                                                                const float* __restrict__ g_normals, float* __restrict__ g_sdf,
+                                                                float* __restrict__ g_rad, float* __restrict__ g_nab, float* __restrict__ g_s) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    float gs = 0.f;
+    if (r < R) {
+        const float s = s_ptr[0];
+        const float gr = g_rgb ? g_rgb[r * 3] : 0.f, gg = g_rgb ? g_rgb[r * 3 + 1] : 0.f, gb = g_rgb ? g_rgb[r * 3 + 2] : 0.f;
+        const float gA = (g_acc ? g_acc[r] : 0.f) - (white ? gr + gg + gb : 0.f);
+        const float gD = g_depth ? g_depth[r] : 0.f;
+        const float gnx = g_normals ? g_normals[r * 3] : 0.f, gny = g_normals ? g_normals[r * 3 + 1] : 0.f, gnz = g_normals ? g_normals[r * 3 + 2] : 0.f;
+        const float iA = 1.0f / (acc[r] + 1e-10f), dep = depth[r];
+        float G = 0.f;            // cotangent of the transmittance entering the next interval
+        float carry = 0.f;        // what interval i+1 contributed to the cotangent of c_{i+1} (as its first operand)
+        for (int i = N - 2; i >= 0; --i) {
+            const long long m = r * (N - 1) + i;
+            const float a = alpha[m], w = w_in[m], T = trans[m];
+            float wbar = gA + gD * (dmid[r * dmid_stride + i] - dep) * iA;
+            if (rad) {
+                wbar += gr * rad[m * 3] + gg * rad[m * 3 + 1] + gb * rad[m * 3 + 2];
+                if (g_rad) { g_rad[m * 3] = w * gr; g_rad[m * 3 + 1] = w * gg; g_rad[m * 3 + 2] = w * gb; }
+            }
+            if (nab) {
+                const float x = nab[(r * N + i) * 3], y = nab[(r * N + i) * 3 + 1], z = nab[(r * N + i) * 3 + 2];
+                const float len = sqrtf(x * x + y * y + z * z), inv = 1.0f / fmaxf(len, 1e-12f);
+                const float hx = x * inv, hy = y * inv, hz = z * inv;
+                const float dot = gnx * hx + gny * hy + gnz * hz;
+                wbar += dot;
+                if (g_nab) {
+                    // F.normalize: v / max(|v|, eps); below eps the denominator is the constant
+                    const float k = len > 1e-12f ? dot : 0.f;
+                    g_nab[(r * N + i) * 3] = w * (gnx - k * hx) * inv;
+                    g_nab[(r * N + i) * 3 + 1] = w * (gny - k * hy) * inv;
+                    g_nab[(r * N + i) * 3 + 2] = w * (gnz - k * hz) * inv;
+                }
+            }
+            const float abar = (wbar - G) * T;
+            G = wbar * a + G * (1.0f - a + 1e-10f);
+            const float c0 = cdf[r * N + i], c1 = cdf[r * N + i + 1], den = c0 + 1e-10f;
+            const bool on = (c0 - c1) / den >= 0.f;           // clamp_min passes the gradient at the kink too
+            const float to_c1 = on ? -abar / den : 0.f, to_c0 = on ? abar * (c1 + 1e-10f) / (den * den) : 0.f;
+            const float cb1 = carry + to_c1;                  // cotangent of c_{i+1} is complete
+            const float k1 = cb1 * c1 * (1.0f - c1);
+            g_sdf[r * N + i + 1] = k1 * s;
+            gs += k1 * sdf[r * N + i + 1];
+            carry = to_c0;
+        }
+        const float c0 = cdf[r * N], k0 = carry * c0 * (1.0f - c0);
+        g_sdf[r * N] = k0 * s;
+        gs += k0 * sdf[r * N];
+        if (g_nab)      // the last sample's nabla is not used by the normals (renderer.py:326 takes [:N-1])
+            g_nab[(r * N + N - 1) * 3] = g_nab[(r * N + N - 1) * 3 + 1] = g_nab[(r * N + N - 1) * 3 + 2] = 0.f;
+    }
+    if (!g_s) return;
+    gs = nm_t_wave_sum(gs);
+    if ((threadIdx.x & 63) == 0) atomicAdd(g_s, gs);
 }

@@ -20,6 +20,7 @@ import contextlib
 import ctypes as C
 import os
 
+import numpy as np
 import torch
 import torch.nn as nn
 from torch import autograd
@@ -187,7 +188,13 @@ class _HipField(autograd.Function):
         if mode != "forward":     # geometry-only queries: the colour MLP and the colour table are not part of the graph
             for i in list(range(2 * (n_geo + 1), 2 * (n_geo + 1) + 2 * (n_col + 1))) + [len(need) - 3]:
                 need[i] = False
-        grads = [torch.zeros(shape, dtype=torch.float32, device=dev) if nd else None for shape, nd in zip(ctx.shapes, need)]
+        # one zeroed buffer for every wanted gradient (one fill launch instead of one per parameter); 64-float alignment per tensor
+        sizes = [(-(-int(np.prod(shape)) // 64) * 64 if nd else 0) for shape, nd in zip(ctx.shapes, need)]
+        flat = torch.zeros((sum(sizes),), dtype=torch.float32, device=dev)
+        grads, off = [], 0
+        for shape, nd, sz in zip(ctx.shapes, need, sizes):
+            grads.append(flat[off:off + int(np.prod(shape))].view(shape) if nd else None)
+            off += sz
         out = _lib.TrainGrads()
         it = iter(grads)
         def nxt():

@@ -522,8 +522,64 @@ def _mid_directions(dirn, pts_mid, random_color_direction: bool):
     return rnd / torch.linalg.norm(rnd, axis=-1, keepdims=True)
 
 
+class _HipComposite(torch.autograd.Function):
+    """renderer.py:264-333 (sdf_to_alpha, alpha_to_w, the weighted sums) as ONE kernel forward and ONE backward (C ABI
+    nm_train_composite_forward / _backward) instead of ~100 small torch kernels each way.  Differentiable outputs: rgb, depth, acc,
+    normals (cotangents flow to sdf, radiance, nablas and s); cdf / alpha / weights are returned for the detailed outputs without a
+    graph (nothing of the reference's trainer differentiates through them; NEUMESH_COMPOSITE=torch keeps the torch-op form)."""
+
+    @staticmethod
+    def forward(ctx, sdf, radiance, nablas, s, dmid, white):
+        lib = _lib.load()
+        dev = sdf.device
+        R, N = sdf.shape
+        f32 = dict(dtype=torch.float32, device=dev)
+        sdf_c, rad_c = sdf.detach().float().contiguous(), radiance.detach().float().contiguous()
+        nab_c = None if nablas is None else nablas.detach().float().contiguous()
+        s_c, dm = s.detach().float().reshape(1).contiguous(), dmid.detach().float().contiguous()
+        rgb, depth, acc = torch.empty((R, 3), **f32), torch.empty((R,), **f32), torch.empty((R,), **f32)
+        normals = torch.empty((R, 3), **f32) if nab_c is not None else None
+        cdf, alpha = torch.empty((R, N), **f32), torch.empty((R, N - 1), **f32)
+        w, trans = torch.empty((R, N - 1), **f32), torch.empty((R, N - 1), **f32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nm_train_composite_forward(_lib.ptr(sdf_c), _lib.ptr(s_c), _lib.ptr(dm), dm.shape[1], _lib.ptr(rad_c), _lib.ptr(nab_c), R, N,
+                                                      int(bool(white)), _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(acc), _lib.ptr(normals), _lib.ptr(cdf),
+                                                      _lib.ptr(alpha), _lib.ptr(w), _lib.ptr(trans), _lib.current_stream(dev)), "nm_train_composite_forward")
+        ctx.save_for_backward(sdf_c, rad_c, nab_c if nab_c is not None else sdf_c.new_zeros(0), s_c, dm, cdf, alpha, w, trans, acc, depth)
+        ctx.has_nablas, ctx.white, ctx.s_shape = nab_c is not None, bool(white), tuple(s.shape)
+        ctx.mark_non_differentiable(cdf, alpha, w)
+        if normals is None:
+            normals = rgb.new_zeros((R, 3))
+            ctx.mark_non_differentiable(normals)
+        return rgb, depth, acc, normals, cdf, alpha, w
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_acc, g_normals, *_unused):
+        lib = _lib.load()
+        sdf, rad, nab, s, dm, cdf, alpha, w, trans, acc, depth = ctx.saved_tensors
+        nab = nab if ctx.has_nablas else None
+        dev = sdf.device
+        R, N = sdf.shape
+
+        def c(g):
+            return None if g is None else g.detach().float().contiguous()
+        g_rgb, g_depth, g_acc, g_normals = c(g_rgb), c(g_depth), c(g_acc), (c(g_normals) if ctx.has_nablas else None)
+        g_sdf = torch.empty_like(sdf)
+        g_rad = torch.empty_like(rad) if ctx.needs_input_grad[1] else None
+        g_nab = torch.empty_like(nab) if (nab is not None and ctx.needs_input_grad[2]) else None
+        g_s = torch.zeros((1,), dtype=torch.float32, device=dev) if ctx.needs_input_grad[3] else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.nm_train_composite_backward(_lib.ptr(sdf), _lib.ptr(s), _lib.ptr(dm), dm.shape[1], _lib.ptr(rad), _lib.ptr(nab), R, N,
+                                                       int(ctx.white), _lib.ptr(cdf), _lib.ptr(alpha), _lib.ptr(w), _lib.ptr(trans), _lib.ptr(acc),
+                                                       _lib.ptr(depth), _lib.ptr(g_rgb), _lib.ptr(g_depth), _lib.ptr(g_acc), _lib.ptr(g_normals),
+                                                       _lib.ptr(g_sdf), _lib.ptr(g_rad), _lib.ptr(g_nab), _lib.ptr(g_s), _lib.current_stream(dev)),
+                       "nm_train_composite_backward")
+        return g_sdf, g_rad, g_nab, (None if g_s is None else g_s.reshape(ctx.s_shape)), None, None
+
+
 def _composite_autograd(model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf, samples_output=False, random_color_direction=False):
-    """renderer.py:264-348 as differentiable torch ops on the (detached) sample depths d [R,N]."""
+    """renderer.py:264-348 on the (detached) sample depths d [R,N], differentiable: the field through the model's methods under autograd,
+    alpha / weights / sums by _HipComposite (default) or torch ops (NEUMESH_COMPOSITE=torch)."""
     R, N = d.shape
     nablas = None
     if cfg.calc_normal:
@@ -531,21 +587,28 @@ def _composite_autograd(model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf,
     else:
         sdf = query(model.forward_density_only, pts)[0]
     sdf = sdf.reshape(R, N)
-    cdf, alpha = sdf_to_alpha(sdf, model.forward_s())
     pm = ro[:, None, :] + dmid[:, :N - 1, None] * dirn[:, None, :]
     view = _mid_directions(dirn, pm, random_color_direction)
     sdf_mid, radiance = query(lambda x, v: model.forward(x, v)[:2], pm, view)
-    w = alpha_to_w(alpha)
-    rgb = torch.sum(w[..., None] * radiance, dim=-2)
     d_final = dmid[:, :N - 1]
-    depth = torch.sum(w / (w.sum(-1, keepdim=True) + 1e-10) * d_final, dim=-1)
-    acc = torch.sum(w, -1)
-    if cfg.white_bkgd:
-        rgb = rgb + (1.0 - acc[..., None])
-    ret = OrderedDict(rgb=rgb, depth_volume=depth, mask_volume=acc)
-    if cfg.calc_normal:
-        nn_ = torch.nn.functional.normalize(nablas[:, :N - 1], dim=-1)
-        ret["normals_volume"] = (nn_ * w[..., None]).sum(dim=-2)
+    if sdf.is_cuda and os.environ.get("NEUMESH_COMPOSITE", "hip") != "torch":
+        rgb, depth, acc, normals, cdf, alpha, w = _HipComposite.apply(sdf, radiance, nablas if cfg.calc_normal else None, model.forward_s(), dmid,
+                                                                       bool(cfg.white_bkgd))
+        ret = OrderedDict(rgb=rgb, depth_volume=depth, mask_volume=acc)
+        if cfg.calc_normal:
+            ret["normals_volume"] = normals
+    else:
+        cdf, alpha = sdf_to_alpha(sdf, model.forward_s())
+        w = alpha_to_w(alpha)
+        rgb = torch.sum(w[..., None] * radiance, dim=-2)
+        depth = torch.sum(w / (w.sum(-1, keepdim=True) + 1e-10) * d_final, dim=-1)
+        acc = torch.sum(w, -1)
+        if cfg.white_bkgd:
+            rgb = rgb + (1.0 - acc[..., None])
+        ret = OrderedDict(rgb=rgb, depth_volume=depth, mask_volume=acc)
+        if cfg.calc_normal:
+            nn_ = torch.nn.functional.normalize(nablas[:, :N - 1], dim=-1)
+            ret["normals_volume"] = (nn_ * w[..., None]).sum(dim=-2)
     if detailed:
         if cfg.calc_normal:
             ret["implicit_nablas"] = nablas

@@ -131,3 +131,53 @@ def test_hip_field_other_configurations(cuda_device, torch_mod, cfg):
         for name in g_t:
             err, scale = float((g_h[name].double() - g_t[name].double()).abs().max()), float(g_t[name].abs().max())
             assert err <= 2e-3 * scale + 1e-7, (mode, name, err, scale)
+
+
+@pytest.mark.parametrize("white,normals", [(False, True), (True, True), (False, False)])
+def test_hip_composite_matches_torch_ops(cuda_device, torch_mod, white, normals):
+    """nm_train_composite_forward / _backward (renderer._HipComposite) against the torch-op statement of renderer.py:264-333 under
+    autograd: rgb / depth / acc / normals and the gradients with respect to the sample SDFs, the radiance, the nablas and s, on rays that
+    cross a surface (decreasing SDF), graze it and miss it, R not a multiple of 64."""
+    torch = torch_mod
+    from neumesh_amd.renderer import _HipComposite, alpha_to_w, sdf_to_alpha
+    g = torch.Generator(device="cpu").manual_seed(3)
+    R, N = 333, 96
+    t = torch.linspace(0, 1, N)[None, :].expand(R, N)
+    off = torch.rand(R, 1, generator=g) * 1.6 - 0.3                      # crossing inside, before or after the interval
+    sdf0 = (off - t) * 0.05 + 0.002 * torch.randn(R, N, generator=g)      # noisy, mostly decreasing
+    sdf0[::5] = 0.02 + 0.03 * t[::5]                                      # every fifth ray misses: the SDF only grows along it
+    d = torch.sort(torch.rand(R, N, generator=g) * 2 + 0.5, dim=-1).values
+    dmid = torch.cat([0.5 * (d[:, 1:] + d[:, :-1]), d[:, -1:]], dim=-1)
+    rad0, nab0 = torch.rand(R, N - 1, 3, generator=g), torch.randn(R, N, 3, generator=g)
+    nab0[5, 7] = 0.0                                                     # a zero nabla: F.normalize's eps branch
+    cots = [torch.randn(R, 3, generator=g), torch.randn(R, generator=g), torch.randn(R, generator=g), torch.randn(R, 3, generator=g)]
+    cots = [c.to(cuda_device) for c in cots]
+
+    def leafs():
+        return [x.clone().to(cuda_device).requires_grad_(True) for x in (sdf0, rad0, nab0, torch.tensor([150.0]))]
+
+    sdf, rad, nab, s = leafs()
+    cdf, alpha = sdf_to_alpha(sdf, s)
+    w = alpha_to_w(alpha)
+    rgb = (w[..., None] * rad).sum(-2)
+    acc = w.sum(-1)
+    depth = (w / (w.sum(-1, keepdim=True) + 1e-10) * dmid.to(cuda_device)[:, :N - 1]).sum(-1)
+    if white:
+        rgb = rgb + (1.0 - acc[..., None])
+    outs_t = [rgb, depth, acc] + ([(torch.nn.functional.normalize(nab[:, :N - 1], dim=-1) * w[..., None]).sum(-2)] if normals else [])
+    torch.autograd.backward(outs_t, cots[:len(outs_t)])
+    g_t = [x.grad.clone() for x in (sdf, rad, s)] + ([nab.grad.clone()] if normals else [])
+
+    sdf2, rad2, nab2, s2 = leafs()
+    o = _HipComposite.apply(sdf2, rad2, nab2 if normals else None, s2, dmid.to(cuda_device), white)
+    outs_h = list(o[:3]) + ([o[3]] if normals else [])
+    torch.autograd.backward(outs_h, cots[:len(outs_h)])
+    g_h = [x.grad.clone() for x in (sdf2, rad2, s2)] + ([nab2.grad.clone()] if normals else [])
+    for a, b in zip(outs_h, outs_t):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+    for a, b in zip(o[4:], (cdf, alpha, w)):
+        assert float((a - b).abs().max()) <= 2e-6
+    assert float(acc.min()) < 1e-3 and float(acc.max()) > 0.99                 # rays that miss and rays that are opaque
+    for name, a, b in zip(("sdf", "radiance", "s", "nablas"), g_h, g_t):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * scale + 1e-9, (name, float((a - b).abs().max()), scale)
