@@ -508,7 +508,7 @@ def test_render_headline_scale_matches_reference_fixture(dtu_scale, cuda_device,
     f = common.golden("render_v140k_dtu")
     assert int(f["V"]) == mesh.num_vertices
     ro, rd = _t(f["rays_o"], cuda_device), _t(f["rays_d"], cuda_device)
-    kw = dict(calc_normal=True, N_samples=ns, N_importance=ni, white_bkgd=white, perturb=False, rayschunk=65536)
+    kw = dict(calc_normal=True, N_samples=64, N_importance=64, perturb=False, rayschunk=65536)
     with torch.no_grad():
         rgb, depth, ex = volume_render(ro, rd, model, detailed_output=True, **kw)
         rgb_p, depth_p, ex_p = volume_render(ro, rd, model, detailed_output=False, **kw)
