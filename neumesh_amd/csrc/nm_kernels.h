@@ -354,14 +354,17 @@ __global__ __launch_bounds__(256) void nm_interp_kernel(const float* __restrict_
 // a nearby query): their largest exact distance to the new query.  Far from the surface the K-NN set
 // barely changes between consecutive samples of a ray, so this is within a hair of the true radius,
 // whereas "radius of the previous sample + step" (triangle inequality) over-covers the surface cap by a
-// factor that grows with the distance to the surface.  `src_lane` holds the indices; all lanes call.
-__device__ __forceinline__ float nm_bound_from_neighbours(const float* __restrict__ verts, const int (&nbr)[8], int src_lane,
-                                                          bool usable, float x, float y, float z) {
+// factor that grows with the distance to the surface.  `src_thread` (same wave) holds the indices.
+// The neighbour lists live in LDS ([k][thread of the workgroup]) rather than in eight loop-carried registers per lane read through eight
+// cross-lane shuffles: the chained kernels write a lane's list after every search and read the list of the lane they warm-start
+// from (same wave: DS operations of a wave execute in order, no barrier needed).
+__device__ __forceinline__ float nm_bound_from_neighbours_lds(const float* __restrict__ verts, const int (*nbr)[NM_KNN_BLOCK], int src_thread,
+                                                              bool usable, float x, float y, float z) {
     float worst = 0.f;
     bool ok = usable;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int i = __shfl(nbr[k], src_lane);
+        const int i = nbr[k][src_thread];
         ok = ok && i != 0x7fffffff;
         if (ok) {
             const float vx = verts[3 * (size_t)i], vy = verts[3 * (size_t)i + 1], vz = verts[3 * (size_t)i + 2];
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_W
     const int chain = CHAIN ? nm_chain_len(src) : 1;
     const int lane = threadIdx.x & 63;
     float prev_rad = NM_INF_F, prev_dep = 0.f;
-    int prev_bi[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    __shared__ int prev_bi[CHAIN ? 8 : 1][NM_KNN_BLOCK];   // neighbours of each lane's previous sample (chained tiles only)
     for (int it = 0; it < chain; ++it) {
         long long q, r;
         int p;
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_W
                 init = fminf(init, b * b);
             }
             // ... and from the exact distances to that sample's 8 neighbours (usually far tighter)
-            const float nb = nm_bound_from_neighbours(verts, prev_bi, lane | 3, it > 0 && active, x, y, z);
+            const float nb = nm_bound_from_neighbours_lds(verts, prev_bi, threadIdx.x | 3, it > 0 && active, x, y, z);
             init = fminf(init, nb);
         }
         float bd[8], wk[8], gr[3];
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_W
         prev_dep = dep;
         if (CHAIN) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) prev_bi[k] = active ? bi[k] : 0x7fffffff;
+            for (int k = 0; k < 8; ++k) prev_bi[k][threadIdx.x] = active ? bi[k] : 0x7fffffff;
         }
         float ds = 0.f;
         long long o = 0;
@@ -525,12 +528,15 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, NM_KNN_WAVES_PROBE) void nm_probe_bou
     int first_idx = -1, last_idx = -1;
     unsigned n_searched = 0;  // probes this wave searched (profiling: one atomic per wave at the end)
     // one step: probe p of this lane's ray; returns ds (and the K-th-neighbour radius for the next warm start)
-    int nbr[8] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};  // of this lane's last probe
+    __shared__ int nbr[8][NM_KNN_BLOCK];  // neighbours of each lane's last probe
+#pragma unroll
+    for (int k = 0; k < 8; ++k) nbr[k][threadIdx.x] = 0x7fffffff;
+    const int wave_base = threadIdx.x & ~63;
     // src_lane: the lane of this ray whose last probe is the closest one already evaluated (-1: none)
     auto probe = [&](int p, bool act, float init, int src_lane, float& dep, float& rad) -> float {
         dep = nm_lerp_depth(n0, f0, nm_linspace01(p < P ? p : P - 1, P));
         const float x = nm_add(ox, nm_mul(dep, dx)), y = nm_add(oy, nm_mul(dep, dy)), z = nm_add(oz, nm_mul(dep, dz));
-        if (src_lane >= 0) init = fminf(init, nm_bound_from_neighbours(verts, nbr, src_lane, act, x, y, z));
+        if (src_lane >= 0) init = fminf(init, nm_bound_from_neighbours_lds(verts, nbr, wave_base | src_lane, act, x, y, z));
         if (searched) n_searched += (unsigned)__popcll(__ballot(act));
         unsigned long long kk[8];
         nm_knn_wave<8>(g, x, y, z, act, kk, init);
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, NM_KNN_WAVES_PROBE) void nm_probe_bou
         for (int k = 0; k < 8; ++k) {
             bd[k] = nm_key_d2(kk[k]);
             bi[k] = nm_key_idx(kk[k]);
-            nbr[k] = act ? bi[k] : 0x7fffffff;
+            nbr[k][threadIdx.x] = act ? bi[k] : 0x7fffffff;
         }
         rad = (act && bi[7] != 0x7fffffff) ? nm_sqrt(bd[7]) : NM_INF_F;
         return act ? nm_projected_distance8(x, y, z, bd, bi, verts, indicator, w1, wk, nullptr) : NM_INF_F;
