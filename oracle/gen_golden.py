@@ -359,6 +359,91 @@ def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=8
     )
 
 
+def gen_render_py_trace(tag="render_py_trace", H=60, W=80, n_views=3, V=3000):
+    """What the reference's own driver does around the renderer (VERDICT r2 missing #7): `render.render_function`
+    (/root/reference/render.py:99-260) is RUN here, unmodified, on a 6-pose data set object, with a recording stand-in for the
+    renderer -- so the fixture holds exactly what render.py hands to `render_fn` (rays from rend_util.get_rays for its own spiral
+    camera path, the keyword arguments: build_framework's render_kwargs_test + what render_function adds) and what it writes from
+    the stand-in's return values (cv2.imwrite / imageio.imwrite / imageio.mimwrite payloads).  The GPU test replays these calls on
+    the product renderer and reproduces the written images with the product's frame assembly."""
+    import json
+    import tempfile
+    import types
+    import torch
+    harness._activate()
+    import cv2 as cv2_stub
+    import imageio as imageio_stub
+    import render as ref_render                    # /root/reference/render.py
+    from utils import rend_util as ref_rend_util   # reference
+    mesh = synthetic.fibonacci_blob(V)
+    _model, kw_test, _renderer, args = harness.build_reference(mesh, seed=0)
+    K = np.eye(4, dtype=np.float32)
+    K[:3, :3] = np.asarray(synthetic.pinhole_intrinsics(H, W), np.float32)[:3, :3]
+
+    class FakeDataset:                                   # the attributes render_function reads (render.py:108-131)
+        def __init__(self):
+            self.H, self.W = H, W
+            self.c2w_all = [torch.from_numpy(np.asarray(synthetic.orbit_pose(7 * i), np.float32)) for i in range(6)]
+
+        def __getitem__(self, i):
+            return i, {"intrinsics": torch.from_numpy(K.copy()), "c2w": self.c2w_all[i], "object_mask": torch.ones(H * W, dtype=torch.bool)}, \
+                {"rgb": torch.zeros(H * W, 3)}
+
+    calls, rays_calls, written = [], [], []
+    rng = np.random.default_rng(17)
+
+    def recording_render_fn(rays_o, rays_d, **kw):
+        n = rays_o.shape[-2]
+        rgb = torch.from_numpy(rng.random((1, n, 3), dtype=np.float32))
+        depth = torch.from_numpy((rng.random((1, n), dtype=np.float32) * 3 + 0.5).astype(np.float32))
+        normals = torch.from_numpy((rng.random((1, n, 3), dtype=np.float32) * 2 - 1).astype(np.float32))
+        calls.append({"rays_o": rays_o.numpy().copy(), "rays_d": rays_d.numpy().copy(), "kw": dict(kw),
+                      "rgb": rgb.numpy().copy(), "depth": depth.numpy().copy(), "normals": normals.numpy().copy()})
+        return rgb, depth, {"normals_volume": normals, "mask_volume": torch.ones(1, n), "depth_volume": depth}
+
+    orig_get_rays = ref_rend_util.get_rays
+
+    def spy_get_rays(c2w, intrinsics, H_, W_, N_rays=-1):
+        rays_calls.append({"c2w": c2w.numpy().copy(), "intrinsics": intrinsics.numpy().copy(), "H": H_, "W": W_, "N_rays": N_rays})
+        return orig_get_rays(c2w, intrinsics, H_, W_, N_rays=N_rays)
+
+    rargs = types.SimpleNamespace(dataset_split=None, background=None, downscale=1, H=None, H_scale=None, W=None, W_scale=None,
+                                  camera_path="spiral", test_frame=None, spiral_rad=[], num_views=n_views, rayschunk=4096, outbase="trace",
+                                  expname="trace", outdirectory=None, disable_rgb=False, fps=30, data=args.data)
+    saved = (ref_render.get_data, ref_rend_util.get_rays, torch.Tensor.cuda, cv2_stub.imwrite, imageio_stub.imwrite, imageio_stub.mimwrite)
+    cwd = os.getcwd()
+    try:
+        ref_render.get_data = lambda a, downscale=1: FakeDataset()
+        ref_rend_util.get_rays = spy_get_rays
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        cv2_stub.imwrite = lambda path, img: written.append(("cv2.imwrite", os.path.basename(path), np.asarray(img).copy()))
+        imageio_stub.imwrite = lambda path, img: written.append(("imageio.imwrite", os.path.basename(path), np.asarray(img).copy()))
+        imageio_stub.mimwrite = lambda path, imgs, **k: written.append(("imageio.mimwrite", os.path.basename(path), np.stack([np.asarray(i) for i in imgs])))
+        os.chdir(tempfile.mkdtemp())
+        ref_render.render_function(rargs, dict(kw_test), recording_render_fn)
+    finally:
+        os.chdir(cwd)
+        (ref_render.get_data, ref_rend_util.get_rays, torch.Tensor.cuda, cv2_stub.imwrite, imageio_stub.imwrite, imageio_stub.mimwrite) = saved
+    assert len(calls) == n_views == len(rays_calls)
+    kw0 = calls[0]["kw"]
+    assert all(c["kw"] == kw0 for c in calls)
+    out = {"H": np.int64(H), "W": np.int64(W), "V": np.int64(V), "n_views": np.int64(n_views),
+           "kwargs_json": np.array(json.dumps({k: (v if not isinstance(v, (np.floating, np.integer)) else v.item()) for k, v in kw0.items()}, sort_keys=True))}
+    for i, (c, r) in enumerate(zip(calls, rays_calls)):
+        out[f"c2w_{i}"], out[f"intrinsics_{i}"] = r["c2w"], r["intrinsics"]
+        assert r["H"] == H and r["W"] == W and r["N_rays"] == -1
+        for k in ("rays_o", "rays_d", "rgb", "depth", "normals"):
+            out[f"{k}_{i}"] = c[k]
+    names = []
+    for j, (fn, name, arr) in enumerate(written):
+        names.append(f"{fn}:{name}")
+        out[f"written_{j}"] = arr
+    out["written_names"] = np.array(names)
+    np.savez_compressed(os.path.join(GOLDEN, f"{tag}.npz"), **out)
+    print(f"[{tag}] {n_views} renderer calls recorded from render.render_function; kwargs {sorted(kw0)}; files written: {names}")
+    REPORT[f"{tag}"] = {"renderer_kwargs": sorted(kw0), "written": names}
+
+
 def state_digest(state) -> str:
     """sha256 over the MLP tensors of a state dict (sorted keys, raw fp32 bytes): the product side
     re-derives the surface scene's weights and must arrive at these very bytes."""
@@ -520,7 +605,7 @@ def gen_rays_fixture():
 
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
-    if len(sys.argv) > 1 and sys.argv[1] in ("scale", "train", "surface", "surf", "surf3"):   # only one of the later fixtures (the others are unchanged)
+    if len(sys.argv) > 1 and sys.argv[1] in ("scale", "train", "surface", "surf", "surf3", "trace"):   # only one of the later fixtures (the others are unchanged)
         sd = dict(np.load(os.path.join(GOLDEN, "model_seed0.npz")))
         if sys.argv[1] == "scale":
             gen_scale_fixture("render_v140k_dtu", mlp_state=sd)
@@ -529,6 +614,8 @@ def main():
         elif sys.argv[1] == "surf3":  # BASELINE configs[3] shape (32 + 32 samples, white background) on the same scene, at headline scale
             gen_scale_fixture("render_v140k_surf_c3", n_rays=1024, mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0,
                               n_samples=32, n_importance=32, white_bkgd=True)
+        elif sys.argv[1] == "trace":
+            gen_render_py_trace()
         elif sys.argv[1] == "train":
             gen_train_step_fixture("train_step_v3000", V=3000, mlp_state=sd)
         else:
@@ -555,6 +642,7 @@ def main():
     gen_scale_fixture("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0)
     gen_scale_fixture("render_v140k_surf_c3", n_rays=1024, mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0,
                       n_samples=32, n_importance=32, white_bkgd=True)
+    gen_render_py_trace()
     with open(os.path.join(GOLDEN, "REPORT.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
     print("all oracle-vs-reference checks passed; fixtures written to", GOLDEN)
