@@ -142,7 +142,6 @@ class _HipField(autograd.Function):
         P = q.shape[0]
         desc, keep = model._train_desc(tensors)
         t = _lib.FieldTables()
-        n_geo, n_col = model._cfg["D_density"], model._cfg["D_color"]
         gf, cf, iv = (x.detach().float().contiguous() for x in tensors[-4:-1])
         t.geometry_features, t.color_features, t.indicator_vector = gf.data_ptr(), cf.data_ptr(), iv.data_ptr()
         t.indicator_weight, t.s = model._host_scalars()
