@@ -126,6 +126,7 @@ SIGNATURES = {
 }
 # test hooks of the -DNM_TESTING build (tests/_build/libneumesh_hip_testing.so): not in the product library, not in the header
 TESTING_SIGNATURES = {
+    "nm_debug_wave_log": (C.c_int, [_P]),
     "nm_debug_phase_log": (C.c_int, [_P]),
     "nm_grid_create_host": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.POINTER(_P)]),
     "nm_grid_debug_export": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64]),

@@ -1586,6 +1586,11 @@ int nm_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* unit
 
 #ifdef NM_TESTING
 // test library only: install (or clear, with NULL) the device buffer the MLP kernels write phase timestamps to
+int nm_debug_wave_log(void* device_buf_i64) {   // [1 + 3 * 2^20] int64 (or NULL): per-wave start / end / wave index of the distance kernels
+    long long* p = (long long*)device_buf_i64;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_nm_wave_log), &p, sizeof(p)) != hipSuccess) return nm_fail("nm_debug_wave_log: hipMemcpyToSymbol failed");
+    return 0;
+}
 int nm_debug_phase_log(void* device_buf_32x16_i64) {
     long long* p = (long long*)device_buf_32x16_i64;
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_nm_phase_log), &p, sizeof(p)) != hipSuccess) return nm_fail("nm_debug_phase_log: hipMemcpyToSymbol failed");

@@ -48,6 +48,22 @@ struct NmPointSrc {
     int p_off, p_total;
 };
 
+#ifdef NM_TESTING
+// test library only: per-wave life of the distance kernels (tools/knn_wave_times.py): log[0] = number of entries, then (start, end,
+// wave index) per wave, written by lane 0 at the end of the kernel
+__device__ long long* g_nm_wave_log = nullptr;
+__device__ __forceinline__ void nm_wave_log_write(long long t0, long long wave) {
+    long long* log = g_nm_wave_log;
+    if (!log || (threadIdx.x & 63)) return;
+    const long long i = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(log), 1ull);
+    if (i < (1 << 20)) {
+        log[1 + 3 * i] = t0;
+        log[2 + 3 * i] = (long long)__builtin_amdgcn_s_memrealtime();
+        log[3 + 3 * i] = wave;
+    }
+}
+#endif
+
 // (r, p) = (ray, sample) of query q = r*P + p, as produced by nm_lane_query (mode 0: r = q, p = 0)
 __device__ __forceinline__ long long nm_out_index(const NmPointSrc& s, long long q, long long r, int p) {
     if (s.mode == 0 || s.out_stride == 0) return q;
@@ -146,11 +162,25 @@ __device__ __forceinline__ float nm_wave_max(float v) {
 template <int K>
 __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float qx, float qy, float qz, bool active,
                                                      float rx, float ry, float rz, unsigned long long (&kk)[K], float init_d2) {
+    const unsigned long long act_mask = __builtin_amdgcn_ballot_w64(active);
+    // ONE query in the wave (small point-wise launches, NmPointSrc.lanes = 1): the leaf scans turn from "this lane's query against
+    // every staged vertex, one at a time" into "the query against THIS lane's vertex" -- 64 candidate distances per step, the few
+    // that beat the current K-th best are inserted one by one into a list every lane keeps a copy of.  The packet centre IS the query
+    // then (0.5 (q + q) = q exactly), so every lane computes with the same position and the list stays wave-uniform.  Such launches
+    // live as long as their slowest wave, and the slowest ones hold a query near the medial axis of the object, for which almost
+    // every leaf has to be scanned (tools/knn_wave_times.py: median wave 0.10 ms, slowest 1.2 ms = the whole launch).  Measured:
+    // 8 k-point launches of a training step 0.26-0.33 -> 0.18-0.20 ms.  (The same idea for 2-16 queries per wave -- one broadcast
+    // query at a time against 64 vertices -- gained 13 % at 4 queries and lost 2.5 x at 16: not kept.)
+    const bool single = __popcll(act_mask) == 1;
+    if (single) {
+        const int src = __builtin_ctzll(act_mask);
+        qx = rx; qy = ry; qz = rz;
+        init_d2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(init_d2), src));
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) kk[k] = nm_key(init_d2, 0x7fffffff);
     const uint32_t kx = (uint32_t)NM_UNIFORM_I(nm_float_key(rx)), ky = (uint32_t)NM_UNIFORM_I(nm_float_key(ry)),
                    kz = (uint32_t)NM_UNIFORM_I(nm_float_key(rz));  // wave-uniform, kept in SGPRs
-    const unsigned long long act_mask = __builtin_amdgcn_ballot_w64(active);
     NmNode rec = nm_ld_node(g.nodes, 0);
     int first = nm_octant(rec, kx, ky, kz);
     unsigned om = nm_visit_mask(rec, first);
@@ -190,6 +220,22 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
             float4* stage = nm_leaf_lds[threadIdx.x >> 6];
             const nm_f32x2 qyz = {qy, qz};          // with __launch_bounds__(NM_KNN_BLOCK) and launched with that block size
             const uint32_t ln = threadIdx.x & 63u;
+            if (single) {
+                for (uint32_t p0 = crec.first; p0 < crec.end; p0 += 64) {
+                    const uint32_t cnt = crec.end - p0 < 64u ? crec.end - p0 : 64u;
+                    const float4 sv = g.sverts[p0 + (ln < cnt ? ln : 0u)];
+                    unsigned long long key = nm_key(nm_dist2(qx, qy, qz, sv.x, sv.y, sv.z), nm_as_int(sv.w));
+                    if (ln >= cnt) key = ~0ull;
+                    for (unsigned long long cand = __builtin_amdgcn_ballot_w64(key < kk[K - 1]); cand; cand &= cand - 1ull) {
+                        const int l = __builtin_ctzll(cand);
+                        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key & 0xffffffffull), l);
+                        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), l);
+                        const unsigned long long c = ((unsigned long long)hi << 32) | lo;
+                        if (c < kk[K - 1]) nm_topk_insert<K>(kk, c);       // (wave-uniform: every lane holds the same list)
+                    }
+                }
+                continue;
+            }
             for (uint32_t p0 = crec.first; p0 < crec.end; p0 += 64) {
                 const uint32_t cnt = crec.end - p0 < 64u ? crec.end - p0 : 64u;
                 {   // staged as {y, z, index, x}: the scan below then finds (y, z) in an aligned register pair (one packed subtract /
@@ -416,6 +462,9 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_W
     // proven bound -- the K-th-neighbour radius of the LAST sample of the previous tile on the same
     // ray plus the depth gap to it (triangle inequality along a unit direction) -- instead of +INF.
     // (CHAIN = false is the plain single-tile kernel: no loop-carried state in its registers)
+#ifdef NM_TESTING
+    const long long nm_t0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     const int chain = CHAIN ? nm_chain_len(src) : 1;
     const int lane = threadIdx.x & 63;
     float prev_rad = NM_INF_F, prev_dep = 0.f;
@@ -491,6 +540,9 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_W
             grad_out[o * 3 + 2] = gr[2];
         }
     }
+#ifdef NM_TESTING
+    nm_wave_log_write(nm_t0, ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+#endif
 }
 
 // ---------------------------------------------------- bounded near/far straight from the probes
