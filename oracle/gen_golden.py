@@ -359,6 +359,59 @@ def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=8
     )
 
 
+def gen_painting_step_fixture(tag="painting_step_v3000", V=3000, mlp_state=None, n_paint=40, n_bg=56):
+    """The texture-painting fine-tune step through the REFERENCE's Trainer.forward_painting (models/trainer.py:119-172): painted rays
+    rendered with random colour directions (renderer.py:279-289), background rays with per-sample outputs for the distillation terms
+    (stub teacher), compute_loss on their concatenation, backward.  torch.rand_like -- the random directions -- is replaced by a
+    host-generator draw of the same shape (seed below) so that the GPU test can feed the product the very same numbers."""
+    import torch
+    print(f"[{tag}] reference Trainer.forward_painting + backward, V={V}")
+    mesh = synthetic.fibonacci_blob(V)
+    lw = {"img": 1.0, "mask": 0.1, "eikonal": 0.1, "distill_density": 1.0, "distill_color": 1.0, "indicator_reg": 0.001}
+    model, kw_test, renderer, args = harness.build_reference(mesh, seed=0, mlp_state=mlp_state, overrides={"training:loss_weights": dict(lw)})
+    from models.trainer import Trainer  # reference
+    trainer = Trainer(model, loss_weights=dict(lw), teacher_model=None, device_ids=["cpu"])
+    trainer.teacher_model = StubTeacher()
+    H = W = 40
+    o_all, d_all = synthetic.camera_rays(synthetic.orbit_pose(4), synthetic.pinhole_intrinsics(H, W, 1.0), H, W)
+    rng = np.random.default_rng(41)
+    pick = rng.permutation(H * W)[:n_paint + n_bg]
+    ip, ib = pick[:n_paint], pick[n_paint:]
+    arr = {"rays_o_paint": o_all[ip], "rays_d_paint": d_all[ip], "rays_o_bg": o_all[ib], "rays_d_bg": d_all[ib],
+           "mask_paint": rng.uniform(0, 1, n_paint) > 0.2, "mask_bg": rng.uniform(0, 1, n_bg) > 0.4,
+           "rgb_paint": rng.uniform(0, 1, (n_paint, 3)).astype(np.float32), "rgb_bg": rng.uniform(0, 1, (n_bg, 3)).astype(np.float32)}
+    model_input = {k: torch.from_numpy(v) for k, v in arr.items() if not k.startswith("rgb_")}
+    ground_truth = {k: torch.from_numpy(v) for k, v in arr.items() if k.startswith("rgb_")}
+    kw = dict(kw_test)
+    kw.pop("rayschunk", None)
+    kw.update(perturb=False, calc_normal=True, N_samples=64, N_importance=64, rayschunk=4096)
+    model.train()
+    gen = torch.Generator().manual_seed(77)
+    orig = torch.rand_like
+    torch.rand_like = lambda t, **k: torch.rand(t.shape, generator=gen, dtype=t.dtype)
+    try:
+        ret = trainer.forward_painting(args, None, model_input, ground_truth, kw, 0, device="cpu")
+    finally:
+        torch.rand_like = orig
+    losses = ret["losses"]
+    losses["total"].backward()
+    out = {"loss." + k: np.float32(v.item()) for k, v in losses.items()}
+    for name, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach().numpy().astype(np.float32)
+        out["norm." + name] = np.float32(np.linalg.norm(g.astype(np.float64)))
+        if g.ndim == 2 and g.size > 4096:
+            rows = np.sort(np.argsort(-np.linalg.norm(g, axis=1))[:48]).astype(np.int32)
+            out["rows." + name] = rows
+            g = g[rows]
+        out["grad." + name] = g
+    print("    losses:", {k: round(float(v), 6) for k, v in out.items() if k.startswith("loss.")})
+    np.savez_compressed(os.path.join(GOLDEN, f"{tag}.npz"), V=np.int64(V), rand_seed=np.int64(77), psnr=np.float32(ret["extras"]["psnr"].item()),
+                        loss_weight_keys=np.array(sorted(lw)), loss_weight_vals=np.array([lw[k] for k in sorted(lw)], np.float32), **arr, **out)
+    REPORT[f"{tag}.losses"] = {k: float(v) for k, v in out.items() if k.startswith("loss.")}
+
+
 def gen_render_py_trace(tag="render_py_trace", H=60, W=80, n_views=3, V=3000):
     """What the reference's own driver does around the renderer (VERDICT r2 missing #7): `render.render_function`
     (/root/reference/render.py:99-260) is RUN here, unmodified, on a 6-pose data set object, with a recording stand-in for the
@@ -605,7 +658,7 @@ def gen_rays_fixture():
 
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
-    if len(sys.argv) > 1 and sys.argv[1] in ("scale", "train", "surface", "surf", "surf3", "trace"):   # only one of the later fixtures (the others are unchanged)
+    if len(sys.argv) > 1 and sys.argv[1] in ("scale", "train", "surface", "surf", "surf3", "trace", "paint"):   # only one of the later fixtures (the others are unchanged)
         sd = dict(np.load(os.path.join(GOLDEN, "model_seed0.npz")))
         if sys.argv[1] == "scale":
             gen_scale_fixture("render_v140k_dtu", mlp_state=sd)
@@ -616,6 +669,8 @@ def main():
                               n_samples=32, n_importance=32, white_bkgd=True)
         elif sys.argv[1] == "trace":
             gen_render_py_trace()
+        elif sys.argv[1] == "paint":
+            gen_painting_step_fixture("painting_step_v3000", V=3000, mlp_state=sd)
         elif sys.argv[1] == "train":
             gen_train_step_fixture("train_step_v3000", V=3000, mlp_state=sd)
         else:
@@ -643,6 +698,7 @@ def main():
     gen_scale_fixture("render_v140k_surf_c3", n_rays=1024, mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0,
                       n_samples=32, n_importance=32, white_bkgd=True)
     gen_render_py_trace()
+    gen_painting_step_fixture("painting_step_v3000", V=3000, mlp_state=sd)
     with open(os.path.join(GOLDEN, "REPORT.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
     print("all oracle-vs-reference checks passed; fixtures written to", GOLDEN)

@@ -181,3 +181,47 @@ def test_hip_composite_matches_torch_ops(cuda_device, torch_mod, white, normals)
     for name, a, b in zip(("sdf", "radiance", "s", "nablas"), g_h, g_t):
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 1e-4 * scale + 1e-9, (name, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("backend", ["hip", "torch"])
+def test_painting_step_matches_reference_trainer(cuda_device, torch_mod, backend, monkeypatch):
+    """Trainer.forward_painting (models/trainer.py:119-172: painted rays rendered with random colour directions, background rays with
+    per-sample outputs, compute_loss on their concatenation) + backward against the REFERENCE trainer's run on the same rays
+    (tests/golden/painting_step_v3000.npz, oracle/gen_golden.py paint).  The random directions come from torch.rand_like; both sides
+    replace it by the same host-generator draw."""
+    torch = torch_mod
+    from neumesh_amd.trainer import Trainer
+    f = common.golden("painting_step_v3000")
+    mesh = common.scene_mesh(int(f["V"]))
+    model = common.make_model(mesh, common.scene_state(mesh), cuda_device)
+    model.autograd_backend = backend
+    model.train()
+    lw = {str(k): float(v) for k, v in zip(f["loss_weight_keys"], f["loss_weight_vals"])}
+    trainer = Trainer(model, loss_weights=lw, teacher_model=None, device_ids=[cuda_device.index or 0])
+    trainer.teacher_model = common.StubTeacher()
+    kw = dict(N_nograd_samples=2048, N_upsample_iters=4, obj_bounding_radius=1.0, batched=True, perturb=False, white_bkgd=False,
+              bounded_near_far=True, calc_normal=True, N_samples=64, N_importance=64, rayschunk=4096)
+    names = ("rays_o_paint", "rays_d_paint", "mask_paint", "rays_o_bg", "rays_d_bg", "mask_bg")
+    model_input = {k: torch.from_numpy(f[k]) for k in names}
+    ground_truth = {k: torch.from_numpy(f[k]) for k in ("rgb_paint", "rgb_bg")}
+    gen = torch.Generator().manual_seed(int(f["rand_seed"]))
+    monkeypatch.setattr(torch, "rand_like", lambda t, **k: torch.rand(t.shape, generator=gen, dtype=t.dtype).to(t.device))
+    ret = trainer.forward_painting({"data": {"N_rays": 96}}, None, model_input, ground_truth, kw, 0, device=cuda_device)
+    for k in ("loss_img", "loss_density", "loss_color", "loss_mask", "total"):
+        got, want = float(ret["losses"][k]), float(f["loss." + k])
+        assert abs(got - want) <= 2e-4 * max(1.0, abs(want)), (k, got, want)
+    assert abs(float(ret["extras"]["psnr"]) - float(f["psnr"])) < 1e-2
+    ret["losses"]["total"].backward()
+    checked = 0
+    for name, p in model.named_parameters():
+        if "grad." + name not in f.files:
+            continue
+        assert p.grad is not None, name
+        g = p.grad.detach().cpu().numpy()
+        nrm = float(f["norm." + name])
+        assert abs(float(np.linalg.norm(g.astype(np.float64))) - nrm) <= 1e-2 * nrm + 1e-6, name
+        if "rows." + name in f.files:
+            g = g[f["rows." + name]]
+        assert np.abs(g - f["grad." + name]).max() <= 1e-2 * max(np.abs(f["grad." + name]).max(), 1e-8) + 1e-6, name
+        checked += 1
+    assert checked >= 20
