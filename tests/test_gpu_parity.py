@@ -1191,3 +1191,36 @@ def test_device_octree_build_is_bit_identical_to_host_build(cuda_device, torch_m
     bad = _t(np.array([[0, 0, 0], [np.nan, 0, 0], [1, 1, 1]], np.float32), cuda_device)
     h = C.c_void_p()
     assert lib.nm_grid_create(_lib.ptr(bad), 3, 0, st, C.byref(h)) != 0 and b"non-finite" in lib.nm_last_error()
+
+
+@pytest.mark.gpu
+def test_small_rayschunk_is_a_lower_bound_by_default(small, cuda_device, torch_mod, monkeypatch):
+    """render.py calls the renderer with rayschunk = 4096 (its memory bound).  By default the fused renderer cuts a call into ITS OWN
+    chunks (NEUMESH_RAYSCHUNK, default 2^20 rays) because every chunk costs ~26 launch latencies: same pixels bit for bit, one
+    nm_render_rays call instead of many; NEUMESH_RAYSCHUNK=0 (what this test suite sets globally) honours the caller's value."""
+    torch = torch_mod
+    from neumesh_amd import renderer as rmod
+    from neumesh_amd import synthetic
+    mesh, state, model = small
+    H = W = 96
+    o, d = synthetic.camera_rays(synthetic.orbit_pose(3), synthetic.pinhole_intrinsics(H, W), H, W)
+    o, d = _t(o, cuda_device), _t(d, cuda_device)
+    kw = dict(calc_normal=True, perturb=False, detailed_output=False)
+    calls = []
+    lib = rmod._lib.load()
+    real = lib.nm_render_rays
+
+    class Spy:
+        def __call__(self, *a):
+            calls.append(int(a[5]))
+            return real(*a)
+    monkeypatch.setattr(lib, "nm_render_rays", Spy())
+    with torch.no_grad():
+        monkeypatch.setenv("NEUMESH_RAYSCHUNK", "0")
+        rgb_a, dep_a, ex_a = rmod.volume_render(o, d, model, rayschunk=1000, **kw)
+        n_exact = len(calls)
+        monkeypatch.delenv("NEUMESH_RAYSCHUNK")
+        rgb_b, dep_b, ex_b = rmod.volume_render(o, d, model, rayschunk=1000, **kw)
+    assert n_exact == -(-H * W // 1000) and calls[:n_exact] == [1000] * (n_exact - 1) + [H * W - 1000 * (n_exact - 1)]
+    assert calls[n_exact:] == [H * W]
+    assert torch.equal(rgb_a, rgb_b) and torch.equal(dep_a, dep_b) and torch.equal(ex_a["normals_volume"], ex_b["normals_volume"])
