@@ -70,6 +70,12 @@ class _Mesh:
         return self
 
 
+# This script sets the chunking of every run itself (whole frame in one call for the headline, half frames for the two-stream row, one
+# 800x800 frame per chunk for config 4): the library's own policy -- the caller's rayschunk is only a lower bound, renderer._fused_chunk --
+# is switched off so that each row measures what its label says.
+os.environ.setdefault("NEUMESH_RAYSCHUNK", "0")
+
+
 def build_scene(V, device, seed=0, s_value=None, scene="surf"):
     """Scene S-DTU.  MLP weights: the set shared by every golden fixture
     (tests/golden/model_seed0.npz = the reference constructor under torch.manual_seed(0)), so that the
