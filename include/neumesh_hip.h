@@ -189,7 +189,9 @@ typedef struct nm_render_cfg {
        weights (same ds; view direction and nabla rotated into the reference's frame when edit_use_rot[i]).  Geometry, depth, acc and
        normals are the main model's. */
     int32_t n_edit;              /* 0 = plain model; at most NM_MAX_EDIT */
-    int32_t edit_reserved;
+    int32_t code_dims;           /* geometry_dim | color_dim << 16 of the field the call renders: sizes the K-NN records of the workspace
+                                    (nm_render_workspace_bytes; 0 = not given: records of the maximum width, 64 + 64 floats).  nm_render_rays
+                                    refuses a field whose code widths exceed the ones given here */
     nm_field_t edit_field[4];    /* reference models: their colour MLPs (same color_dim / embedders as the main model) */
     const uint8_t* edit_mask[4]; /* device [V] */
     const float* edit_color_features; /* device [V, color_dim]  (main_editing_colorfeats) */

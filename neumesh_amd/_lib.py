@@ -44,7 +44,7 @@ class RenderCfg(C.Structure):
                 ("near_bypass", C.c_float), ("far_bypass", C.c_float),
                 ("flags", C.c_uint32), ("chain_tiles", C.c_int32), ("fine_group_rays", C.c_int32),
                 ("mid_group_rays", C.c_int32), ("weight_eps", C.c_float),
-                ("n_edit", C.c_int32), ("edit_reserved", C.c_int32), ("edit_field", C.c_void_p * 4),
+                ("n_edit", C.c_int32), ("code_dims", C.c_int32), ("edit_field", C.c_void_p * 4),
                 ("edit_mask", C.c_void_p * 4), ("edit_color_features", C.c_void_p),
                 ("edit_use_rot", C.c_int32 * 4), ("edit_rot", (C.c_float * 9) * 4)]
 

@@ -537,7 +537,7 @@ int nm_field_overflow(nm_field_t f, int* flag, nm_stream_t stream_) {
     return 0;
 }
 
-// scratch layout for P points: ds | idx32[8] | w[8] | grad[3] | nabla[3] | fg[64] | ft[64]
+// scratch layout for P points: ds | idx32[8] | w[8] | grad[3] | nabla[3] | fg[gdim] | ft[cdim]   (parts a caller does not use: 0 bytes)
 struct NmScratch {
     float* ds;
     int* idx;
@@ -548,7 +548,7 @@ struct NmScratch {
     float* ft;  // interpolated colour codes   [P][color_dim]
     size_t bytes;
 };
-static NmScratch nm_carve(void* base, long long P, bool with_idx_w = true) {
+static NmScratch nm_carve(void* base, long long P, bool with_idx_w = true, int gdim = 64, int cdim = 64, bool with_nabla = true) {
     NmScratch s;
     char* p = (char*)base;
     size_t o = 0;
@@ -556,9 +556,9 @@ static NmScratch nm_carve(void* base, long long P, bool with_idx_w = true) {
     s.idx = (int*)(p + o);     o += nm_align(with_idx_w ? (size_t)P * 32 : 0);
     s.w = (float*)(p + o);     o += nm_align(with_idx_w ? (size_t)P * 32 : 0);
     s.grad = (float*)(p + o);  o += nm_align((size_t)P * 12);
-    s.nabla = (float*)(p + o); o += nm_align((size_t)P * 12);
-    s.fg = (float*)(p + o);    o += nm_align((size_t)P * 64 * 4);
-    s.ft = (float*)(p + o);    o += nm_align((size_t)P * 64 * 4);
+    s.nabla = (float*)(p + o); o += nm_align(with_nabla ? (size_t)P * 12 : 0);
+    s.fg = (float*)(p + o);    o += nm_align((size_t)P * gdim * 4);
+    s.ft = (float*)(p + o);    o += nm_align((size_t)P * cdim * 4);
     s.bytes = o;
     return s;
 }
@@ -992,10 +992,17 @@ static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) 
         const size_t e_mid = e16 > e32 ? (e16 > e64 ? e16 : e64) : (e32 > e64 ? e32 : e64);
         w.order = (unsigned short*)take((e_fine > e_mid ? e_fine : e_mid) * 2);
     }
-    w.slots = nm_carve(p + o, R * N, false);
+    // K-NN records sized by the field's code widths (nm_render_cfg.code_dims; 0 = not given: the maximum, 64 + 64): the sample slots
+    // hold ds, grad, the geometry code (144 B at 32 dims), the mid-point records the colour code as well (272 B) -- 63 KB per ray at
+    // 128 samples instead of the 148 KB of maximum-width records (a texture-edited call gathers the edited colour codes into the
+    // mid-points' geometry slot: sized by the wider of the two)
+    int gdim = c->code_dims & 0xffff, cdim = (c->code_dims >> 16) & 0xffff;
+    if (gdim <= 0 || gdim > 64) gdim = 64;
+    if (cdim <= 0 || cdim > 64) cdim = 64;
+    w.slots = nm_carve(p + o, R * N, false, gdim, 0, false);
     o += w.slots.bytes;
     const long long pts_n = mid_slots > R * N ? mid_slots : R * N;
-    w.pts = nm_carve(p + o, pts_n, c->n_edit > 0);   // (texture editing needs the mid-points' neighbour lists)
+    w.pts = nm_carve(p + o, pts_n, c->n_edit > 0, (c->n_edit > 0 && cdim > gdim) ? cdim : gdim, cdim, false);   // (texture editing needs the neighbour lists)
     o += w.pts.bytes;
     w.rgb_ref = (float*)take(c->n_edit > 0 ? (size_t)R * N * 12 : 0);
     w.edit_w = (float*)take(c->n_edit > 0 ? (size_t)pts_n * 32 : 0);
@@ -1032,6 +1039,12 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     if (R < 0 || (R > 0 && (!rays_o || !rays_d || !rgb || !depth || !acc || !workspace))) return nm_fail("nm_render_rays: bad arguments");
     if (c->calc_normal && !normals) return nm_fail("nm_render_rays: calc_normal set but normals is NULL");
     if (R == 0) return 0;
+    if (c->code_dims) {   // the workspace was sized for these code widths: the fields rendered through it must fit
+        const int gd = c->code_dims & 0xffff, cd = (c->code_dims >> 16) & 0xffff;
+        if (f->geo.gdim > gd || f->col.cdim > cd) return nm_fail("nm_render_rays: cfg.code_dims = (%d, %d) but the field has code widths (%d, %d)", gd, cd, f->geo.gdim, f->col.cdim);
+        for (int e = 0; e < c->n_edit; ++e)
+            if (c->edit_field[e]->col.cdim > cd) return nm_fail("nm_render_rays: reference field %d has a colour code of %d > cfg.code_dims %d", e, c->edit_field[e]->col.cdim, cd);
+    }
     const NmWorkspace ws = nm_carve_ws(workspace, c, R);
     const int N = c->N_samples + c->N_importance, cap = N;
     const dim3 rgrid(nm_blocks(R, 64)), rblock(64);

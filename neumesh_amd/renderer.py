@@ -132,7 +132,7 @@ def _lanes_for(device, stream_handle: int):
 
 
 def release_workspaces():
-    """Drop every cached render workspace (they are sized for the largest chunk seen: 56 KB per ray)."""
+    """Drop every cached render workspace (they are sized for the largest chunk seen: 63 KB per ray at 32 + 32-d codes)."""
     with _POOLS_LOCK:
         _POOLS.clear()
 
@@ -198,7 +198,7 @@ def _fused_chunk(lib, cfg, R: int, rayschunk: int, dev) -> int:
     """Rays per nm_render_rays call.  The reference's `rayschunk` (render.py passes 4096) bounds ITS memory; here every chunk is ~26 kernel
     launches whose cost is latency, not work, below ~10^5 rays (800x800 frame: 806 ms in chunks of 4096 rays, 362 ms at 65 536, 354 ms in
     one call) and the pixels do not depend on the chunking (bit-identical, tested), so the caller's value is only a LOWER bound: the call is
-    cut into chunks of NEUMESH_RAYSCHUNK rays (default 2^20 = whole frames up to 1024 x 1024), halved while two chunk workspaces (~56 KB
+    cut into chunks of NEUMESH_RAYSCHUNK rays (default 2^20 = whole frames up to 1024 x 1024), halved while two chunk workspaces (~63 KB
     per ray each) would take more than half of the free device memory.  NEUMESH_RAYSCHUNK=0 honours the caller's value exactly."""
     want = max(1, min(int(rayschunk), R))
     own = int(os.environ.get("NEUMESH_RAYSCHUNK") or (1 << 20))
@@ -236,6 +236,7 @@ def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed,
                      radiance=torch.empty((R, N - 1, 3), device=dev), near_far=torch.empty((R, 2), device=dev))
         if cfg.calc_normal:
             dbg_t["nablas_all"] = torch.empty((R, N, 3), device=dev)
+    cfg.code_dims = int(model._cfg["geometry_dim"]) | (int(model._cfg["color_dim"]) << 16)   # K-NN records of the workspace sized for this field
     chunk = _fused_chunk(lib, cfg, R, rayschunk, dev)
     ws_bytes = int(lib.nm_render_workspace_bytes(C.byref(cfg), chunk))
     if ws_bytes < 0:

@@ -276,3 +276,35 @@ def test_data_parallel_replicas_never_free_the_parents_field_handle(monkeypatch)
     del m
     gc.collect()
     assert destroyed.count("HANDLE-0") == 1
+
+
+def test_fused_chunk_policy_lower_bound_and_memory_guard(monkeypatch):
+    """renderer._fused_chunk (host logic, no GPU): the caller's rayschunk is a lower bound, the library's own chunk (NEUMESH_RAYSCHUNK,
+    default 2^20) is halved while two workspaces would take more than half of the free device memory, never below the caller's value;
+    NEUMESH_RAYSCHUNK=0 honours the caller exactly."""
+    import ctypes as C
+    import torch
+    from neumesh_amd import _lib, renderer
+    lib = _lib.load(require_device=False)
+    cfg = renderer.make_render_cfg(calc_normal=True)
+    assert 100e3 < int(lib.nm_render_workspace_bytes(C.byref(cfg), 1 << 16)) / (1 << 16) < 125e3    # code widths not given: records of 64 + 64 floats
+    cfg.code_dims = 32 | (32 << 16)                                         # what render_rays_fused sets from the model
+    per_ray = int(lib.nm_render_workspace_bytes(C.byref(cfg), 1 << 16)) / (1 << 16)
+    assert 55e3 < per_ray < 70e3                                             # 63 KB per ray (DESIGN section 2)
+    free = [int(400e9)]
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (free[0], int(288e9)))
+    monkeypatch.delenv("NEUMESH_RAYSCHUNK", raising=False)
+    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 640000            # render.py's 4096: whole frame in one call
+    assert renderer._fused_chunk(lib, cfg, 1920000, 4096, "cuda:0") == 1 << 20          # config 4: two chunks of <= 2^20 rays
+    assert renderer._fused_chunk(lib, cfg, 500, 4096, "cuda:0") == 500
+    free[0] = int(16e9)                                                                 # a nearly full device: halve until two workspaces fit
+    c = renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0")
+    assert 4096 <= c < 640000 and 2 * lib.nm_render_workspace_bytes(C.byref(cfg), c) <= free[0] // 2
+    free[0] = int(1e6)
+    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 4096             # never below what the caller asked for
+    monkeypatch.setenv("NEUMESH_RAYSCHUNK", "0")
+    free[0] = int(400e9)
+    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 4096
+    monkeypatch.setenv("NEUMESH_RAYSCHUNK", "100000")
+    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 100000
+    assert renderer._fused_chunk(lib, cfg, 640000, 300000, "cuda:0") == 300000         # the caller's larger value wins
