@@ -546,6 +546,18 @@ def _mid_directions(dirn, pts_mid, random_color_direction: bool):
     return rnd / torch.linalg.norm(rnd, axis=-1, keepdims=True)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One extra stream per device for the second field query of the differentiable tail (kept: creating a stream costs a driver call)."""
+    key = str(device)
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class _HipComposite(torch.autograd.Function):
     """renderer.py:264-333 (sdf_to_alpha, alpha_to_w, the weighted sums) as ONE kernel forward and ONE backward (C ABI
     nm_train_composite_forward / _backward) instead of ~100 small torch kernels each way.  Differentiable outputs: rgb, depth, acc,
@@ -606,14 +618,31 @@ def _composite_autograd(model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf,
     alpha / weights / sums by _HipComposite (default) or torch ops (NEUMESH_COMPOSITE=torch)."""
     R, N = d.shape
     nablas = None
+    pm = ro[:, None, :] + dmid[:, :N - 1, None] * dirn[:, None, :]
+    view = _mid_directions(dirn, pm, random_color_direction)
+    # The two field queries -- sdf + nablas at the samples, sdf + radiance at the mid-points -- do not depend on each other, and for a
+    # training batch each is a few launch-latency-bound kernels (a 65 k-point K-NN launch lives ~1.1 ms for its slowest wave while
+    # most of the chip idles): the mid-point query is issued on a second stream so that its kernels run beside the sample query's.
+    # autograd runs each node's backward on the stream of its forward, so the two backward passes overlap the same way.
+    side = _side_stream(pm.device) if (pm.is_cuda and pm.shape[0] * N <= (1 << 19) and os.environ.get("NEUMESH_TRAIN_STREAMS", "2") != "1") else None
+    if side is not None:
+        main = torch.cuda.current_stream(pm.device)
+        side.wait_stream(main)
+        pm.record_stream(side)        # allocated on the caller's stream, read by the side stream's kernels
+        view.record_stream(side)
+        with torch.cuda.stream(side):
+            sdf_mid, radiance = query(lambda x, v: model.forward(x, v)[:2], pm, view)
     if cfg.calc_normal:
         sdf, nablas = query(model.forward_with_nablas, pts)
     else:
         sdf = query(model.forward_density_only, pts)[0]
     sdf = sdf.reshape(R, N)
-    pm = ro[:, None, :] + dmid[:, :N - 1, None] * dirn[:, None, :]
-    view = _mid_directions(dirn, pm, random_color_direction)
-    sdf_mid, radiance = query(lambda x, v: model.forward(x, v)[:2], pm, view)
+    if side is not None:
+        main.wait_stream(side)
+        sdf_mid.record_stream(main)   # allocated on the side stream, consumed on the caller's from here on
+        radiance.record_stream(main)
+    else:
+        sdf_mid, radiance = query(lambda x, v: model.forward(x, v)[:2], pm, view)
     d_final = dmid[:, :N - 1]
     if sdf.is_cuda and os.environ.get("NEUMESH_COMPOSITE", "hip") != "torch":
         rgb, depth, acc, normals, cdf, alpha, w = _HipComposite.apply(sdf, radiance, nablas if cfg.calc_normal else None, model.forward_s(), dmid,
