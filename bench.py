@@ -39,6 +39,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import threading
 import socket
 import sys
 import time
@@ -429,6 +430,7 @@ def main():
                     help="calc_normal=False (SURVEY 8d config 2 asks for both): no nablas at the N sample points, no normals_volume")
     ap.add_argument("--data-independent", action="store_true",
                     help="evaluate every probe and every mid-point (NM_RENDER_FULL_PROBES | NM_RENDER_NO_ZERO_SKIP): the work the reference always does")
+    ap.add_argument("--extras-budget", type=float, default=240.0, help="seconds the rows after the headline may take before the line is printed without the rest")
     ap.add_argument("--no-extras", action="store_true", help="skip the short variant runs reported under `config` / `extra`")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N > 1: nccl = RCCL over xGMI (default); gloo = test mode for boxes with fewer GPUs than "
@@ -645,6 +647,35 @@ def main():
         }
         cfgd = out["config"]
         extra = {}
+        # Everything from here on is context beside the headline (variant rows, consumers of the path, the CPU baseline).  A watchdog makes sure
+        # the ONE line of the contract is printed even if one of those rows should stall: after --extras-budget seconds it prints the line with the
+        # rows finished so far and ends the process.  (Blocking HIP calls release the interpreter lock, so the thread runs.)
+        printed = threading.Lock()
+
+        def emit(note=None):
+            if not printed.acquire(blocking=False):
+                return False
+            for _attempt in range(5):       # (the main thread may be adding a row at this very moment)
+                try:
+                    snap = dict(extra)
+                    if note:
+                        snap["_watchdog"] = note
+                    line = json.dumps(dict(out, extra=snap) if snap else out, default=str)
+                    break
+                except RuntimeError:
+                    time.sleep(0.01)
+            else:
+                line = json.dumps({k: v for k, v in out.items() if k != "extra"}, default=str)
+            print(line, flush=True)
+            return True
+
+        def watchdog():
+            if emit(f"the rows after the headline did not finish within {args.extras_budget} s: line printed with the rows completed so far"):
+                os._exit(0)
+        timer = threading.Timer(args.extras_budget, watchdog)
+        timer.daemon = True
+        if world == 1:
+            timer.start()
         fixture = None
         fx_path = os.path.join(ROOT, "tests", "golden", "render_v140k_surf.npz" if args.scene == "surf" else "render_v140k_dtu.npz")
         if os.path.exists(fx_path):
@@ -746,9 +777,8 @@ def main():
                 cfgd["config5_frac_measured_hbm_of_peak"] = (mh / PEAK_HBM_GBS) if mh else None
             except Exception as ex:
                 extra["config5_stress (V=1M, 256-d table, 4096x4096 queries/step)"] = {"error": str(ex)}
-        if extra:
-            out["extra"] = extra
-        print(json.dumps(out), flush=True)
+        timer.cancel()
+        emit()
     if world > 1:
         dist.destroy_process_group()
 

@@ -622,9 +622,11 @@ def _composite_autograd(model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf,
     view = _mid_directions(dirn, pm, random_color_direction)
     # The two field queries -- sdf + nablas at the samples, sdf + radiance at the mid-points -- do not depend on each other, and for a
     # training batch each is a few launch-latency-bound kernels (a 65 k-point K-NN launch lives ~1.1 ms for its slowest wave while
-    # most of the chip idles): the mid-point query is issued on a second stream so that its kernels run beside the sample query's.
-    # autograd runs each node's backward on the stream of its forward, so the two backward passes overlap the same way.
-    side = _side_stream(pm.device) if (pm.is_cuda and pm.shape[0] * N <= (1 << 19) and os.environ.get("NEUMESH_TRAIN_STREAMS", "2") != "1") else None
+    # most of the chip idles): with NEUMESH_TRAIN_STREAMS=2 the mid-point query is issued on a second stream so that its kernels run
+    # beside the sample query's (autograd runs each node's backward on the stream of its forward, so the backward passes overlap the
+    # same way): 16.7 -> 15.9 ms per step in tools/train_profile.py.  Opt-in: the default bench run stalled once with it on (cause not
+    # found within the round's GPU budget), and a stall is not worth a millisecond.
+    side = _side_stream(pm.device) if (pm.is_cuda and pm.shape[0] * N <= (1 << 19) and os.environ.get("NEUMESH_TRAIN_STREAMS", "1") == "2") else None
     if side is not None:
         main = torch.cuda.current_stream(pm.device)
         side.wait_stream(main)
