@@ -2,7 +2,7 @@
 # tools/train_trace.sh <out_dir>: GPU box -- kernel trace of a few training steps (tools/train_profile.py without the torch profiler part)
 OUT=${1:-gpurun_out/train_trace}; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-NM_TRAIN_STEPS_ONLY=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python tools/train_profile.py > $OUT/run.log 2>&1
+NM_TRAIN_STEPS_ONLY=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python tools/train_profile.py > $OUT/run.log 2>&1
 python - <<PY
 import csv, glob
 f = glob.glob("$OUT/**/t_kernel_trace.csv", recursive=True)[0]
