@@ -392,6 +392,37 @@ def stress5_run(args, dev, world, rank, steps, warmup):
                              "measured HBM traffic (`traffic`) is far below it and the kernel is not HBM-bound in practice"}}
 
 
+def line_guard(out, extra, budget_s):
+    """(emit, timer) for the ONE line of the contract.  emit(note=None) prints `out` (+ `extra` as out["extra"]) exactly once; timer is an
+    unstarted threading.Timer that, when it fires after budget_s seconds, emits the line with the rows finished so far and ends the process
+    with status 0 -- so a stalled row after the headline cannot cost the line (tests/test_host.py runs this against a sleeping main thread)."""
+    printed = threading.Lock()
+
+    def emit(note=None):
+        if not printed.acquire(blocking=False):
+            return False
+        for _attempt in range(5):       # (the main thread may be adding a row at this very moment)
+            try:
+                snap = dict(extra)
+                if note:
+                    snap["_watchdog"] = note
+                line = json.dumps(dict(out, extra=snap) if snap else out, default=str)
+                break
+            except RuntimeError:
+                time.sleep(0.01)
+        else:
+            line = json.dumps({k: v for k, v in out.items() if k != "extra"}, default=str)
+        print(line, flush=True)
+        return True
+
+    def watchdog():
+        if emit(f"the rows after the headline did not finish within {budget_s} s: line printed with the rows completed so far"):
+            os._exit(0)
+    timer = threading.Timer(budget_s, watchdog)
+    timer.daemon = True
+    return emit, timer
+
+
 def self_spawn(args):
     """`python bench.py --gpus N` outside torch.distributed.run: re-exec under it (one rank per GPU)."""
     with socket.socket() as s:
@@ -650,30 +681,7 @@ def main():
         # Everything from here on is context beside the headline (variant rows, consumers of the path, the CPU baseline).  A watchdog makes sure
         # the ONE line of the contract is printed even if one of those rows should stall: after --extras-budget seconds it prints the line with the
         # rows finished so far and ends the process.  (Blocking HIP calls release the interpreter lock, so the thread runs.)
-        printed = threading.Lock()
-
-        def emit(note=None):
-            if not printed.acquire(blocking=False):
-                return False
-            for _attempt in range(5):       # (the main thread may be adding a row at this very moment)
-                try:
-                    snap = dict(extra)
-                    if note:
-                        snap["_watchdog"] = note
-                    line = json.dumps(dict(out, extra=snap) if snap else out, default=str)
-                    break
-                except RuntimeError:
-                    time.sleep(0.01)
-            else:
-                line = json.dumps({k: v for k, v in out.items() if k != "extra"}, default=str)
-            print(line, flush=True)
-            return True
-
-        def watchdog():
-            if emit(f"the rows after the headline did not finish within {args.extras_budget} s: line printed with the rows completed so far"):
-                os._exit(0)
-        timer = threading.Timer(args.extras_budget, watchdog)
-        timer.daemon = True
+        emit, timer = line_guard(out, extra, args.extras_budget)
         if world == 1:
             timer.start()
         fixture = None

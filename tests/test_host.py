@@ -308,3 +308,27 @@ def test_fused_chunk_policy_lower_bound_and_memory_guard(monkeypatch):
     monkeypatch.setenv("NEUMESH_RAYSCHUNK", "100000")
     assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 100000
     assert renderer._fused_chunk(lib, cfg, 640000, 300000, "cuda:0") == 300000         # the caller's larger value wins
+
+
+def test_bench_line_guard_prints_the_line_when_the_main_thread_stalls():
+    """bench.py's watchdog (line_guard): a row after the headline that never returns must not cost the ONE line of the contract -- after
+    the budget the line is printed with the rows finished so far and the process ends with status 0."""
+    import json
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "out = {'metric': 'm', 'value': 1.0}; extra = {'row_a': {'ms': 2.0}}\n"
+            "emit, timer = bench.line_guard(out, extra, 0.5); timer.start()\n"
+            "extra['row_b'] = {'ms': 3.0}\n"
+            "time.sleep(30)\n"
+            "print('NOT REACHED')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and "NOT REACHED" not in r.stdout
+    d = json.loads(lines[0])
+    assert d["value"] == 1.0 and set(d["extra"]) == {"row_a", "row_b", "_watchdog"}
+    # ... and the normal end: emit() once, a second call (the timer firing late) prints nothing
+    code2 = ("import sys; sys.path.insert(0, %r); import bench\n"
+             "emit, timer = bench.line_guard({'value': 2.0}, {}, 60.0)\n"
+             "assert emit() and not emit()\n") % ROOT
+    r2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120)
+    assert r2.returncode == 0 and r2.stdout.count("{") == 1, r2.stdout + r2.stderr[-300:]
