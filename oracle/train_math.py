@@ -97,3 +97,45 @@ def distance_backward(x, v, n, w, w1, g_ds, g_g):
     dn = w[..., None] * (cn[..., None] * d + cg[..., None] * g_g[:, None, :])
     dw1 = (w * (S * (a * r - r * r2) / D ** 2 + (A * D + lead - a * B) / D ** 2 - 2 * (lead * D - tail * B) / D ** 3)).sum()
     return dn, dw1
+
+
+def composite_backward(sdf, s, d_mid, rad, nab, white, g_rgb, g_depth, g_acc, g_normals):
+    """Reverse scan of renderer.py:264-333 as nm_t_composite_bwd_kernel runs it (one ray after the other here): cotangents of
+    rgb [R,3], depth [R], acc [R], normals [R,3] -> (g_sdf [R,N], g_rad [R,N-1,3], g_nab [R,N,3], g_s scalar)."""
+    R, N = sdf.shape
+    c = torch.sigmoid(sdf * s)
+    q = (c[:, :-1] - c[:, 1:]) / (c[:, :-1] + 1e-10)
+    a = q.clamp_min(0)
+    T = torch.cumprod(torch.cat([torch.ones(R, 1, dtype=sdf.dtype), 1 - a + 1e-10], -1), -1)[:, :-1]
+    w = a * T
+    A = w.sum(-1)
+    depth = (w * d_mid).sum(-1) / (A + 1e-10)
+    ln = nab[:, :N - 1].norm(dim=-1)
+    inv = 1.0 / ln.clamp_min(1e-12)
+    hat = nab[:, :N - 1] * inv[..., None]
+    gA = g_acc - (g_rgb.sum(-1) if white else 0.0)
+    g_sdf, g_rad, g_nab = torch.zeros_like(sdf), torch.zeros_like(rad), torch.zeros_like(nab)
+    g_s = sdf.new_zeros(())
+    for r in range(R):
+        G, carry = 0.0, 0.0
+        for i in range(N - 2, -1, -1):
+            dot = (g_normals[r] * hat[r, i]).sum()
+            wbar = gA[r] + g_depth[r] * (d_mid[r, i] - depth[r]) / (A[r] + 1e-10) + (g_rgb[r] * rad[r, i]).sum() + dot
+            g_rad[r, i] = w[r, i] * g_rgb[r]
+            k = dot if ln[r, i] > 1e-12 else 0.0
+            g_nab[r, i] = w[r, i] * (g_normals[r] - k * hat[r, i]) * inv[r, i]
+            abar = (wbar - G) * T[r, i]
+            G = wbar * a[r, i] + G * (1 - a[r, i] + 1e-10)
+            c0, c1 = c[r, i], c[r, i + 1]
+            den = c0 + 1e-10
+            on = q[r, i] >= 0
+            to_c1 = -abar / den if on else 0.0
+            to_c0 = abar * (c1 + 1e-10) / den ** 2 if on else 0.0
+            k1 = (carry + to_c1) * c1 * (1 - c1)
+            g_sdf[r, i + 1] = k1 * s
+            g_s = g_s + k1 * sdf[r, i + 1]
+            carry = to_c0
+        k0 = carry * c[r, 0] * (1 - c[r, 0])
+        g_sdf[r, 0] = k0 * s
+        g_s = g_s + k0 * sdf[r, 0]
+    return g_sdf, g_rad, g_nab, g_s

@@ -85,3 +85,35 @@ def test_softplus_threshold_branch_matches_torch():
     (g2,) = torch.autograd.grad(g1.sum(), z)
     s1, s2 = tm.softplus_d(z.detach())
     assert torch.allclose(s1, g1.detach(), atol=1e-12) and torch.allclose(s2, g2, atol=1e-9)
+
+
+@pytest.mark.parametrize("white", [False, True])
+def test_composite_reverse_scan_equals_autograd(white):
+    """nm_t_composite_bwd_kernel's scan (oracle/train_math.composite_backward) against autograd of renderer.py:17-24,49-63,299-333."""
+    g = torch.Generator().manual_seed(11)
+    R, N = 7, 20
+    t = torch.linspace(0, 1, N, dtype=torch.float64)[None, :].expand(R, N)
+    sdf = ((torch.rand(R, 1, generator=g, dtype=torch.float64) * 1.4 - 0.2 - t) * 0.05 + 0.003 * torch.randn(R, N, generator=g, dtype=torch.float64))
+    sdf[0] = 0.02 + 0.03 * t[0]                                   # a ray that misses
+    sdf = sdf.requires_grad_(True)
+    s = torch.tensor(150.0, dtype=torch.float64, requires_grad=True)
+    d_mid = torch.sort(torch.rand(R, N - 1, generator=g, dtype=torch.float64) * 2 + 0.5, dim=-1).values
+    rad = torch.rand(R, N - 1, 3, generator=g, dtype=torch.float64).requires_grad_(True)
+    nab = torch.randn(R, N, 3, generator=g, dtype=torch.float64).requires_grad_(True)
+    cots = [torch.randn(R, 3, generator=g, dtype=torch.float64), torch.randn(R, generator=g, dtype=torch.float64),
+            torch.randn(R, generator=g, dtype=torch.float64), torch.randn(R, 3, generator=g, dtype=torch.float64)]
+    cdf = torch.sigmoid(sdf * s)
+    alpha = ((cdf[:, :-1] - cdf[:, 1:]) / (cdf[:, :-1] + 1e-10)).clamp_min(0)
+    w = alpha * torch.cumprod(torch.cat([torch.ones(R, 1, dtype=torch.float64), 1 - alpha + 1e-10], -1), -1)[:, :-1]
+    rgb = (w[..., None] * rad).sum(-2)
+    acc = w.sum(-1)
+    depth = (w / (w.sum(-1, keepdim=True) + 1e-10) * d_mid).sum(-1)
+    if white:
+        rgb = rgb + (1 - acc[..., None])
+    normals = (torch.nn.functional.normalize(nab[:, :N - 1], dim=-1) * w[..., None]).sum(-2)
+    want = torch.autograd.grad(sum((o * c).sum() for o, c in zip((rgb, depth, acc, normals), cots)), [sdf, rad, nab, s])
+    with torch.no_grad():
+        got = tm.composite_backward(sdf.detach(), s.detach(), d_mid, rad.detach(), nab.detach(), white, *cots)
+    assert float(acc.min()) < 1e-6 and float(acc.max()) > 0.5
+    for name, a, b in zip(("sdf", "radiance", "nablas", "s"), got, want):
+        assert float((a - b).abs().max()) <= 1e-9 * max(1.0, float(b.abs().max())), (name, float((a - b).abs().max()))
