@@ -15,6 +15,12 @@ os.environ.setdefault("NEUMESH_RAYSCHUNK", "0")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # no test may sit on a GPU box for ever: pytest-timeout (installed in this image) ends a test after 10 minutes -- the longest one takes
+    # ~10 s on the GPU and ~10 s on the CPU
+    # (method "thread": a watchdog thread ends the process -- a signal handler would never run while the interpreter waits inside a HIP call)
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 600
+        config.option.timeout_method = "thread"
 
 
 @pytest.fixture(scope="session")
