@@ -81,3 +81,56 @@ class TextureEditableNeuMesh(nn.Module):
                                                     indices=idx[region], weights=ref_w[region], nabla=ref_nabla[region])
                 blend[region] = blend[region] * a_rest.unsqueeze(-1) + ref_color * a_paint.unsqueeze(-1)
         return sdf, blend
+
+
+# ---- geometry editing: the model follows a deformed mesh (editing/render_geometry_editing.py:19-67)
+
+def cos_between_vectors(x, y, do_clamp=True):
+    """render_geometry_editing.py:19-34: cosine of the angle between (...,3) vectors, clamped to [-1, 1]."""
+    c = torch.sum(x * y, dim=-1) / (torch.linalg.norm(x, dim=-1) * torch.linalg.norm(y, dim=-1))
+    return torch.clamp(c, -1, 1) if do_clamp else c
+
+
+def angle_axis_to_rotation_matrix(angle_axis: torch.Tensor) -> torch.Tensor:
+    """(N,3) rotation vectors -> (N,3,3).  The reference takes this from kornia 0.6.3 (environment.yml:42;
+    kornia.geometry.conversions.angle_axis_to_rotation_matrix, itself after ceres/rotation.h): Rodrigues' formula with the
+    axis normalised as v / (theta + 1e-6) where theta^2 = |v|^2 > 1e-6, and the first-order form I + [v]x below that.  Restated
+    here on device ops (one call per mesh edit, N = V) because the two quirks are visible in the result: the 1e-6 in the
+    normalisation, and that a zero vector gives exactly the identity."""
+    v = angle_axis
+    theta2 = (v * v).sum(-1, keepdim=True)
+    theta = torch.sqrt(theta2)
+    w = v / (theta + 1e-6)
+    wx, wy, wz = w[:, 0:1], w[:, 1:2], w[:, 2:3]
+    c, s = torch.cos(theta), torch.sin(theta)
+    k = 1.0 - c
+    full = torch.cat([c + wx * wx * k, wx * wy * k - wz * s, wy * s + wx * wz * k,
+                      wz * s + wx * wy * k, c + wy * wy * k, -wx * s + wy * wz * k,
+                      -wy * s + wx * wz * k, wx * s + wy * wz * k, c + wz * wz * k], dim=1).view(-1, 3, 3)
+    rx, ry, rz = v[:, 0:1], v[:, 1:2], v[:, 2:3]
+    one = torch.ones_like(rx)
+    small = torch.cat([one, -rz, ry, rz, one, -rx, -ry, rx, one], dim=1).view(-1, 3, 3)
+    big = (theta2 > 1e-6).view(-1, 1, 1).to(v.dtype)
+    return big * full + (1.0 - big) * small
+
+
+def deform_model(deformed_mesh, model, device, fix_indicator=False):
+    """render_geometry_editing.py:37-67, same arguments: the model's mesh index is rebuilt on the deformed mesh (octree built on the
+    device, < 1 ms) and, unless `fix_indicator`, every indicator vector is turned by the rotation that takes the vertex's old normal
+    to its new one.  As in the reference the rotation vector is `cross(n_old, n_new) * acos(cos)` with the cross product NOT
+    normalised (its length is sin(angle), so the turn is by angle * sin(angle)), a normal that flips exactly (cos == -1) negates
+    the indicator, and the result replaces `model.indicator_vector` as a new nn.Parameter."""
+    from .mesh_grid import MeshGrid
+    new_grid = MeshGrid(deformed_mesh, device, distance_method=model.mesh_grid.distance_method)
+    if not fix_indicator:
+        with torch.no_grad():
+            n_old = model.mesh_grid.get_vertex_normal_torch()
+            n_new = new_grid.get_vertex_normal_torch().to(n_old.device)
+            axis = torch.cross(n_old, n_new, dim=-1)
+            cos_theta = cos_between_vectors(n_old, n_new)
+            flipped = cos_theta == -1
+            rot = angle_axis_to_rotation_matrix(axis * torch.acos(cos_theta).unsqueeze(-1))
+            ind = torch.matmul(rot, model.indicator_vector.detach().unsqueeze(-1)).squeeze(-1)
+            ind[flipped] *= -1
+        model.indicator_vector = nn.Parameter(ind)
+    model.mesh_grid = new_grid

@@ -99,6 +99,12 @@ class _Workspace:
             self.buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
         return self.buf
 
+    def trim(self, keep_bytes: int):
+        """Give a workspace larger than `keep_bytes` back to torch's allocator (the block stays cached there and can serve other
+        allocations -- a training step after a validation render -- instead of sitting pinned in the pool)."""
+        if self.buf is not None and self.buf.numel() > keep_bytes:
+            self.buf = None
+
     def side_stream(self, device):
         if self.stream is None or self.stream.device != device:
             self.stream = torch.cuda.Stream(device=device)
@@ -113,6 +119,8 @@ class _Workspace:
 # NEUMESH_RENDER_STREAMS=1 restores the single-stream order.
 # Workspaces and side streams belong to one (device, caller stream) pair: calls issued on the same
 # stream are ordered by it (fork/join below), calls on different streams or devices never share scratch.
+DEFAULT_RAYSCHUNK = 1 << 16   # rays per nm_render_rays call unless NEUMESH_RAYSCHUNK says otherwise (_fused_chunk)
+WS_KEEP_BYTES = int(float(os.environ.get("NEUMESH_WS_KEEP_GB", "10")) * (1 << 30))   # pooled workspaces above this are returned after the call
 _POOLS = OrderedDict()      # (device, caller stream) -> two workspaces; least recently used first
 _POOLS_LOCK = threading.Lock()
 _POOLS_MAX = 4              # pools kept (each holds up to two full-chunk workspaces): callers on many short-lived streams
@@ -194,14 +202,17 @@ def render_rays_fused(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int
     return out
 
 
-def _fused_chunk(lib, cfg, R: int, rayschunk: int, dev) -> int:
+def _fused_chunk(lib, cfg, R: int, rayschunk: int, dev, extra_per_ray: int = 0) -> int:
     """Rays per nm_render_rays call.  The reference's `rayschunk` (render.py passes 4096) bounds ITS memory; here every chunk is ~26 kernel
     launches whose cost is latency, not work, below ~10^5 rays (800x800 frame: 806 ms in chunks of 4096 rays, 362 ms at 65 536, 354 ms in
     one call) and the pixels do not depend on the chunking (bit-identical, tested), so the caller's value is only a LOWER bound: the call is
-    cut into chunks of NEUMESH_RAYSCHUNK rays (default 2^20 = whole frames up to 1024 x 1024), halved while two chunk workspaces (~63 KB
-    per ray each) would take more than half of the free device memory.  NEUMESH_RAYSCHUNK=0 honours the caller's value exactly."""
+    cut into chunks of NEUMESH_RAYSCHUNK rays.  The default is 65 536: ~2 % slower than one call for ~10 x less pooled
+    workspace (63 KB per ray: 4 GB per lane instead of 40 GB for an 800x800 call), so a validation render during training or a shared
+    GPU keeps its memory; it is halved while the two lanes' workspaces plus what the call itself allocates per ray (`extra_per_ray`:
+    the detailed-output tensors) would take more than half of the free device memory.  NEUMESH_RAYSCHUNK=0 honours the caller's value
+    exactly; a larger value (bench.py: the whole frame) trades memory for the last 2 %."""
     want = max(1, min(int(rayschunk), R))
-    own = int(os.environ.get("NEUMESH_RAYSCHUNK") or (1 << 20))
+    own = int(os.environ.get("NEUMESH_RAYSCHUNK") or DEFAULT_RAYSCHUNK)
     if own <= want:
         return want
     chunk = min(R, own)
@@ -209,6 +220,7 @@ def _fused_chunk(lib, cfg, R: int, rayschunk: int, dev) -> int:
         free = torch.cuda.mem_get_info(dev)[0]
     except Exception:
         return want
+    free -= int(extra_per_ray) * R            # tensors of the whole call (allocated before the first chunk runs)
     while chunk > want:
         need = int(lib.nm_render_workspace_bytes(C.byref(cfg), chunk)) * (1 if chunk >= R else 2)
         if 0 <= need <= free // 2:
@@ -237,7 +249,8 @@ def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed,
         if cfg.calc_normal:
             dbg_t["nablas_all"] = torch.empty((R, N, 3), device=dev)
     cfg.code_dims = int(model._cfg["geometry_dim"]) | (int(model._cfg["color_dim"]) << 16)   # K-NN records of the workspace sized for this field
-    chunk = _fused_chunk(lib, cfg, R, rayschunk, dev)
+    # detailed output: ~12 more [R, N]-sized tensors are derived from the debug arrays after the last chunk
+    chunk = _fused_chunk(lib, cfg, R, rayschunk, dev, extra_per_ray=4 * N * 12 if detailed else 0)
     ws_bytes = int(lib.nm_render_workspace_bytes(C.byref(cfg), chunk))
     if ws_bytes < 0:
         _lib.check(1, "nm_render_workspace_bytes")
@@ -274,6 +287,9 @@ def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed,
                 C.byref(dbg) if dbg is not None else None, _lib.ptr(ws), stream), "nm_render_rays")
         for st in side:  # join
             main.wait_stream(st)
+        del wss, ws
+        for lane in lanes:   # (after the join: the block is handed back in the caller's stream order)
+            lane.trim(WS_KEEP_BYTES)
     del keep
     if detailed:
         s = model.forward_s().detach()

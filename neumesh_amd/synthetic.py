@@ -146,3 +146,72 @@ def surface_mlp_state(base: dict, shift: float = 0.1, bump_std: float = 0.002, c
     sd["color_linear.0.weight"] = (sd["color_linear.0.weight"] * f32(color_gain)).astype(f32)
     sd["ln_s"] = np.array([np.log(s_value) / speed_factor], f32)
     return sd
+
+
+# ---- texture / geometry editing scenes (fixtures tests/golden/texture_edit_v3000.npz, deform_v3000.npz; bench rows)
+
+def reference_color_state(base: dict, i: int, gain: float = 6.0) -> dict:
+    """State dict of the i-th texture REFERENCE model of an editing scene: the main model's weights with its colour network
+    (`views_linears.*`, `color_linear.*`) perturbed deterministically and the colour head scaled by `gain`, so that the
+    colour it paints is visibly different from the main model's (default-init heads give rgb = 0.5 +- 0.003)."""
+    out = dict(base)
+    rng = np.random.default_rng(20 + i)
+    for k in sorted(base):
+        if k.startswith("views_linears"):
+            out[k] = (base[k] + 0.05 * (i + 1) * rng.standard_normal(base[k].shape)).astype(np.float32)
+        elif k.startswith("color_linear"):
+            out[k] = (gain * base[k] + 0.05 * (i + 1) * rng.standard_normal(base[k].shape)).astype(np.float32)
+    return out
+
+
+def edit_scene(vertices: np.ndarray, n_ref: int, rotated: bool, color_dim: int = 32, seed: int = 40):
+    """(masks [n_ref, V] bool, edited colour table [V, color_dim] f32, T_r_m list of 4x4 f32 or None): a dozen painted caps per
+    reference (contiguous regions, so that points see all-painted, mixed and unpainted neighbour sets), random
+    edited codes, and -- if `rotated` -- a rigid transform per reference (editing/texture_neumesh/texture_neumesh.py:21-33)."""
+    rng = np.random.default_rng(seed)
+    V = vertices.shape[0]
+    unit = vertices / np.linalg.norm(vertices, axis=-1, keepdims=True)
+    masks = []
+    for i in range(n_ref):   # a dozen caps scattered over the object: every view sees painted, mixed and unpainted surface
+        centres = rng.standard_normal((12, 3))
+        centres /= np.linalg.norm(centres, axis=-1, keepdims=True)
+        masks.append((unit @ centres.T).max(-1) > (0.9 if i == 0 else 0.93))
+    feats = rng.standard_normal((V, color_dim)).astype(np.float32)
+    T_list = None
+    if rotated:
+        T_list = []
+        for i in range(n_ref):
+            q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+            T = np.eye(4, dtype=np.float32)
+            T[:3, :3] = (q * np.sign(np.linalg.det(q))).astype(np.float32)
+            T[:3, 3] = 0.1 * (i + 1)
+            T_list.append(T)
+    return np.stack(masks), feats, T_list
+
+
+def deformed_blob(mesh: SyntheticMesh, n_axis: int = 6, twist: float = 0.9):
+    """(original mesh with `n_axis` normals snapped to coordinate axes, deformed mesh, snapped indices): the object twisted about z
+    by `twist` radians per unit height and stretched 5 % along z, normals carried by the inverse transpose Jacobian (they turn by
+    up to ~0.7 rad) -- except that the first three snapped vertices get their normal flipped EXACTLY (cos == -1: the branch of
+    render_geometry_editing.py:53,65 that negates the indicator) and the next three keep theirs (rotation vector 0: kornia's
+    first-order branch)."""
+    v = mesh.vertices.astype(np.float64)
+    n0 = mesh.vertex_normals.astype(np.float64).copy()
+    snap = np.arange(n_axis) * (mesh.num_vertices // n_axis)
+    for j, k in enumerate(snap):
+        e = np.zeros(3)
+        e[j % 3] = 1.0 if (j // 3) % 2 == 0 else -1.0
+        n0[k] = e
+    base = SyntheticMesh(mesh.vertices.copy(), n0.astype(np.float32))
+    a = twist * v[:, 2]
+    c, s_ = np.cos(a), np.sin(a)
+    dv = np.stack([c * v[:, 0] - s_ * v[:, 1], s_ * v[:, 0] + c * v[:, 1], 1.05 * v[:, 2]], -1)
+    J = np.zeros((v.shape[0], 3, 3))
+    J[:, 0, 0], J[:, 0, 1], J[:, 0, 2] = c, -s_, -twist * (s_ * v[:, 0] + c * v[:, 1])
+    J[:, 1, 0], J[:, 1, 1], J[:, 1, 2] = s_, c, twist * (c * v[:, 0] - s_ * v[:, 1])
+    J[:, 2, 2] = 1.05
+    dn = np.einsum("vji,vj->vi", np.linalg.inv(J), n0)        # J^-T n
+    dn = dn / np.linalg.norm(dn, axis=-1, keepdims=True)
+    dn[snap[:3]] = -n0[snap[:3]]
+    dn[snap[3:]] = n0[snap[3:]]
+    return base, SyntheticMesh(dv.astype(np.float32), dn.astype(np.float32)), snap

@@ -96,3 +96,25 @@ class StubTeacher:
     def __call__(self, xyz, dirs):
         import torch
         return torch.linalg.norm(xyz, dim=-1) - 0.75, torch.sigmoid(2.0 * dirs + xyz)
+
+
+def edit_oracle(mesh, state, n_ref: int, rotated: bool):
+    """oracle.editing.OracleTextureEdit of the texture_edit_v3000 scene (synthetic.edit_scene / reference_color_state)."""
+    from oracle import editing as oedit
+    masks, feats, T_list = synthetic.edit_scene(mesh.vertices, n_ref, rotated)
+    mlp = {k: v for k, v in golden("model_seed0").items()}
+    refs = [make_oracle(mesh, {**state, **synthetic.reference_color_state(mlp, i)}) for i in range(n_ref)]
+    return oedit.OracleTextureEdit(make_oracle(mesh, state), refs, masks, feats, T_list)
+
+
+def edit_model(mesh, state, n_ref: int, rotated: bool, device):
+    """neumesh_amd.editing.TextureEditableNeuMesh of the same scene on `device` (+ the main model)."""
+    import torch
+    from neumesh_amd.editing import TextureEditableNeuMesh
+    masks, feats, T_list = synthetic.edit_scene(mesh.vertices, n_ref, rotated)
+    mlp = {k: v for k, v in golden("model_seed0").items()}
+    main = make_model(mesh, state, device)
+    refs = [make_model(mesh, {**state, **synthetic.reference_color_state(mlp, i)}, device) for i in range(n_ref)]
+    T = None if T_list is None else [torch.from_numpy(t).to(device) for t in T_list]
+    wrap = TextureEditableNeuMesh(main, refs, torch.from_numpy(masks).to(device), torch.from_numpy(feats).to(device), T)
+    return wrap.eval(), main

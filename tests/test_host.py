@@ -280,7 +280,7 @@ def test_data_parallel_replicas_never_free_the_parents_field_handle(monkeypatch)
 
 def test_fused_chunk_policy_lower_bound_and_memory_guard(monkeypatch):
     """renderer._fused_chunk (host logic, no GPU): the caller's rayschunk is a lower bound, the library's own chunk (NEUMESH_RAYSCHUNK,
-    default 2^20) is halved while two workspaces would take more than half of the free device memory, never below the caller's value;
+    default 65 536) is halved while two workspaces would take more than half of the free device memory, never below the caller's value;
     NEUMESH_RAYSCHUNK=0 honours the caller exactly."""
     import ctypes as C
     import torch
@@ -294,7 +294,11 @@ def test_fused_chunk_policy_lower_bound_and_memory_guard(monkeypatch):
     free = [int(400e9)]
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (free[0], int(288e9)))
     monkeypatch.delenv("NEUMESH_RAYSCHUNK", raising=False)
-    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 640000            # render.py's 4096: whole frame in one call
+    assert renderer.DEFAULT_RAYSCHUNK == 1 << 16                                        # ~4 GB of workspace per lane, not 40
+    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 1 << 16            # render.py's 4096: the library's chunk
+    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0", extra_per_ray=int(400e9) // 640000) == 4096   # the call's own tensors count
+    monkeypatch.setenv("NEUMESH_RAYSCHUNK", str(1 << 20))
+    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 640000            # opt-in: whole frame in one call
     assert renderer._fused_chunk(lib, cfg, 1920000, 4096, "cuda:0") == 1 << 20          # config 4: two chunks of <= 2^20 rays
     assert renderer._fused_chunk(lib, cfg, 500, 4096, "cuda:0") == 500
     free[0] = int(16e9)                                                                 # a nearly full device: halve until two workspaces fit
@@ -305,6 +309,12 @@ def test_fused_chunk_policy_lower_bound_and_memory_guard(monkeypatch):
     monkeypatch.setenv("NEUMESH_RAYSCHUNK", "0")
     free[0] = int(400e9)
     assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 4096
+    ws = renderer._Workspace()
+    ws.buf = torch.empty(1000, dtype=torch.uint8)
+    ws.trim(2000)
+    assert ws.buf is not None
+    ws.trim(999)
+    assert ws.buf is None                                                               # oversized pooled workspaces go back after the call
     monkeypatch.setenv("NEUMESH_RAYSCHUNK", "100000")
     assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 100000
     assert renderer._fused_chunk(lib, cfg, 640000, 300000, "cuda:0") == 300000         # the caller's larger value wins
