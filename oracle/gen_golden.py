@@ -523,7 +523,7 @@ class StubTeacher:
         return torch.linalg.norm(xyz, dim=-1) - 0.75, torch.sigmoid(2.0 * dirs + xyz)
 
 
-def gen_train_step_fixture(tag="train_step_v3000", V=3000, mlp_state=None):
+def gen_train_step_fixture(tag="train_step_v3000", V=3000, mlp_state=None, s_value=200.0, n_rays=96, HW=40, kdtree=False):
     """One optimisation step's forward + backward through the REFERENCE's Trainer (models/trainer.py:50-117,174-285):
     random pixel selection, render with autograd (calc_normal on: eikonal weight > 0), per-sample outputs for the
     distillation terms (stub teacher), every loss term, and d total / d parameter.  perturb is switched off
@@ -532,12 +532,12 @@ def gen_train_step_fixture(tag="train_step_v3000", V=3000, mlp_state=None):
     print(f"[{tag}] reference Trainer.forward + backward, V={V}")
     mesh = synthetic.fibonacci_blob(V)
     lw = {"img": 1.0, "mask": 0.1, "eikonal": 0.1, "distill_density": 1.0, "distill_color": 1.0, "indicator_reg": 0.001}
-    model, kw_test, renderer, args = harness.build_reference(mesh, seed=0, mlp_state=mlp_state,
-                                                             overrides={"training:loss_weights": dict(lw), "data:N_rays": 96})
+    model, kw_test, renderer, args = harness.build_reference(mesh, seed=0, mlp_state=mlp_state, s_value=s_value,
+                                                             overrides={"training:loss_weights": dict(lw), "data:N_rays": n_rays})
     from models.trainer import Trainer  # reference
     trainer = Trainer(model, loss_weights=dict(lw), teacher_model=None, device_ids=["cpu"])
     trainer.teacher_model = StubTeacher()
-    H = W = 40
+    H = W = HW
     c2w, K = synthetic.orbit_pose(9), synthetic.pinhole_intrinsics(H, W, 1.0)
     rng = np.random.default_rng(31)
     gt_rgb = rng.uniform(0, 1, (1, H * W, 3)).astype(np.float32)
@@ -548,28 +548,56 @@ def gen_train_step_fixture(tag="train_step_v3000", V=3000, mlp_state=None):
     model_input = {"intrinsics": torch.from_numpy(K)[None], "c2w": torch.from_numpy(c2w)[None], "object_mask": torch.from_numpy(obj_mask)}
     ground_truth = {"rgb": torch.from_numpy(gt_rgb)}
     model.train()
-    torch.manual_seed(123)
-    ret = trainer.forward(args, None, model_input, ground_truth, kw, 0, device="cpu")
+    import contextlib
+
+    def step(pose):
+        """one Trainer.forward + backward; returns (ret, {loss.*, norm.*, rows.*, grad.*}, full gradients)"""
+        for p_ in model.parameters():
+            p_.grad = None
+        torch.manual_seed(123)
+        mi = dict(model_input, c2w=torch.from_numpy(pose)[None])
+        with (_kdtree_knn(mesh) if kdtree else contextlib.nullcontext()):
+            ret_ = trainer.forward(args, None, mi, ground_truth, kw, 0, device="cpu")
+            ret_["losses"]["total"].backward()
+        o = {"loss." + k: np.float32(v.item()) for k, v in ret_["losses"].items()}
+        full = {}
+        for name, p_ in model.named_parameters():
+            if p_.grad is None:
+                continue
+            g = p_.grad.detach().numpy().astype(np.float32).copy()
+            full[name] = g
+            o["norm." + name] = np.float32(np.linalg.norm(g.astype(np.float64)))
+            if g.ndim == 2 and g.size > 4096:
+                rows = np.sort(np.argsort(-np.linalg.norm(g, axis=1))[:48]).astype(np.int32)
+                o["rows." + name] = rows
+                g = g[rows]
+            o["grad." + name] = g
+        return ret_, o, full
+
+    ret, out, full = step(c2w)
     losses = ret["losses"]
-    losses["total"].backward()
-    out = {"loss." + k: np.float32(v.item()) for k, v in losses.items()}
-    for name, p in model.named_parameters():
-        if p.grad is None:
-            continue
-        g = p.grad.detach().numpy().astype(np.float32)
-        out["norm." + name] = np.float32(np.linalg.norm(g.astype(np.float64)))
-        if g.ndim == 2 and g.size > 4096:
-            rows = np.sort(np.argsort(-np.linalg.norm(g, axis=1))[:48]).astype(np.int32)
-            out["rows." + name] = rows
-            g = g[rows]
-        out["grad." + name] = g
+    if kdtree:
+        # the reference's own conditioning on a scene with a surface: the same step with the camera pose moved by 1 ulp (sample
+        # placement at a sharp crossing is sensitive to the last bit, as for the render fixtures): loss and gradient deltas recorded
+        _, out2, full2 = step(np.nextafter(c2w, np.float32(10), dtype=np.float32))
+        for k in [k for k in out if k.startswith("loss.")]:
+            out["self1ulp." + k] = np.float32(abs(float(out2[k]) - float(out[k])))
+        for name in full:
+            out["self1ulp.gradrel." + name] = np.float32(np.abs(full2[name] - full[name]).max() / max(np.abs(full[name]).max(), 1e-12))
+            out["self1ulp.normrel." + name] = np.float32(abs(float(out2["norm." + name]) - float(out["norm." + name])) / max(float(out["norm." + name]), 1e-12))
+        print("    reference vs itself (pose + 1 ulp): loss deltas", {k[14:]: float(v) for k, v in out.items() if k.startswith("self1ulp.loss.")})
+        print("    reference vs itself (pose + 1 ulp): largest relative gradient deltas",
+              sorted(((float(v), k[17:]) for k, v in out.items() if k.startswith("self1ulp.gradrel.")), reverse=True)[:5])
     print("    losses:", {k: round(float(v), 6) for k, v in out.items() if k.startswith("loss.")})
     print(f"    psnr {float(ret['extras']['psnr']):.3f}, 1/s {float(ret['extras']['scalars']['1/s']):.5f}, "
           f"|grad ln_s| {abs(float(out['grad.ln_s'])):.3e}")
     np.savez_compressed(os.path.join(GOLDEN, f"{tag}.npz"), V=np.int64(V), H=np.int64(H), W=np.int64(W), c2w=c2w, intrinsics=K,
                         gt_rgb=gt_rgb, object_mask=obj_mask, select_inds=ret["extras"]["select_inds"].numpy(),
                         psnr=np.float32(ret["extras"]["psnr"].item()), rgb=ret["extras"]["mask_volume_clipped"].detach().numpy(),
+                        N_rays=np.int64(n_rays), s=np.float32(model.forward_s().item()),
                         loss_weight_keys=np.array(sorted(lw)), loss_weight_vals=np.array([lw[k] for k in sorted(lw)], np.float32), **out)
+    if tag != "train_step_v3000":
+        return
     # compute_loss alone on fixed tensors, the three masking variants (CPU-side test of the product's Trainer)
     rng = np.random.default_rng(32)
     B, R, N = 1, 50, 12
@@ -751,6 +779,76 @@ def gen_deform_fixture(tag="deform_v3000", V=3000, mlp_state=None):
     np.savez_compressed(os.path.join(GOLDEN, f"{tag}.npz"), **out)
 
 
+class _NeuSLike:
+    """What the reference's surface_render expects of a model (models/ray_casting.py:268-288: `model.implicit_surface`,
+    `model.forward(pts, view_dirs) -> (radiance, sdf, nablas)` -- the NeuS-style interface; the reference NeuMesh returns two values,
+    which is why the module is dead code there), built from the reference NeuMesh's own methods."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def implicit_surface(self, pts):
+        import torch
+        with torch.no_grad():
+            return self.model.forward_density_only(pts).squeeze(-1)
+
+    def forward(self, pts, view_dirs):
+        sdf, nab = self.model.forward_with_nablas(pts)
+        _, rgb = self.model.forward(pts, view_dirs)
+        return rgb.detach(), sdf.detach(), nab.detach()
+
+
+def gen_surface_scale_fixture(tag="surface_v140k_surf", V=140_000, n_rays=512, H=800, W=800, mlp_state=None, s_value=400.0):
+    """Headline-scale pin of row a16 / f4: the reference's models/ray_casting.py -- root_finding_surface_points (256 proposals +
+    8 secant steps, level 0) and surface_render (colour / depth / nabla / normal at the first hit) -- on the reference NeuMesh field of
+    the SURFACE scene at V = 140 000, `n_rays` strided rays of bench frame 0.  Per ray the fixture also holds the smallest |sdf| among
+    the proposals up to (and including) the bracket of its first sign change: a ray can only change its mask / bracket under a field
+    difference larger than that margin."""
+    import torch
+    print(f"[{tag}] reference ray_casting.py on the surface scene, V={V}, rays={n_rays}")
+    mesh = synthetic.fibonacci_blob(V)
+    model, kw, renderer, _ = harness.build_reference(mesh, seed=0, mlp_state=mlp_state, s_value=s_value)
+    import models.ray_casting as rc  # reference
+    o_all, d_all_ = synthetic.camera_rays(synthetic.orbit_pose(0), synthetic.pinhole_intrinsics(H, W), H, W)
+    sel = np.linspace(0, H * W - 1, n_rays).astype(np.int64)
+    rays_o, rays_d = o_all[sel], d_all_[sel]
+    ro = torch.from_numpy(rays_o)[None]
+    rd = torch.nn.functional.normalize(torch.from_numpy(rays_d), dim=-1)[None]
+    near, far, tau = 1.2, 3.2, 0.0
+    adaptor = _NeuSLike(model)
+    calls = []
+
+    def sdf(p):
+        v = adaptor.implicit_surface(p)
+        calls.append(v.detach().clone())
+        return v
+
+    with _kdtree_knn(mesh):
+        d, pt, m, msc = rc.root_finding_surface_points(sdf, ro.clone(), rd.clone(), near=near, far=far, batched=True, N_steps=256,
+                                                       logit_tau=tau, method="secant", N_secant_steps=8, fill_inf=False)
+        val = (calls[0] - tau)[0].numpy()                       # [R, 256]: the proposal values (first query of the routine)
+        assert val.shape == (n_rays, 256)
+        col, dep, ex = rc.surface_render(ro.clone(), torch.from_numpy(rays_d)[None], adaptor, calc_normal=True, batched=True,
+                                         ray_casting_algo="root_finding",
+                                         ray_casting_cfgs=dict(near=near, far=far, logit_tau=tau, fill_inf=False, N_steps=256, N_secant_steps=8))
+        sdf_hit = np.abs(adaptor.implicit_surface(pt[m]).numpy())
+        residual_all = adaptor.implicit_surface(pt)
+    prod = val[:, :-1] * val[:, 1:]
+    first = np.where((prod < 0).any(1), (prod < 0).argmax(1), 254)
+    upto = np.arange(256)[None, :] <= (first[:, None] + 1)
+    margin = np.where(upto, np.abs(val), np.inf).min(1).astype(np.float32)
+    hit = m[0].numpy()
+    print(f"    {int(hit.sum())}/{n_rays} rays hit, {int(msc.sum())} with a sign change; depth of hits {float(d[m].min()):.3f}..{float(d[m].max()):.3f}; "
+          f"rays with margin < 1e-5: {int((margin < 1e-5).sum())}; |sdf| at the hits: median {float(np.median(sdf_hit)):.1e}, max {float(sdf_hit.max()):.1e}")
+    assert torch.equal(ex["mask_surface"], m) and torch.equal(dep, d)
+    np.savez_compressed(os.path.join(GOLDEN, f"{tag}.npz"), V=np.int64(V), H=np.int64(H), W=np.int64(W), sel=sel, rays_o=rays_o, rays_d=rays_d,
+                        near=np.float32(near), far=np.float32(far), tau=np.float32(tau), d=d[0].numpy(), pt=pt[0].numpy(), mask=hit,
+                        sign_change=msc[0].numpy(), margin=margin, first=first.astype(np.int32),
+                        color=col[0].numpy(), nablas=ex["implicit_nablas"][0].numpy(), normals=ex["normals_surface"][0].numpy(),
+                        residual=np.where(hit, np.abs(residual_all[0].numpy()), 0).astype(np.float32),   # |sdf| at the returned point
+                        s=np.float32(model.forward_s().item()), state_sha256=np.array(state_digest(mlp_state)))
+
+
 def gen_rays_fixture():
     """rend_util.get_rays of the reference (utils/rend_util.py:123-176) for a skewed pin-hole camera."""
     import torch
@@ -770,9 +868,14 @@ def gen_rays_fixture():
                         rays_o=ro[0].numpy(), rays_d=rd[0].numpy())
 
 
+KNOWN = ("scale", "train", "surface", "surf", "surf3", "trace", "paint", "edit", "deform", "surface140k", "train140k")
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
-    if len(sys.argv) > 1 and sys.argv[1] in ("scale", "train", "surface", "surf", "surf3", "trace", "paint", "edit", "deform"):   # only one of the later fixtures (the others are unchanged)
+    if len(sys.argv) > 1 and sys.argv[1] not in KNOWN:
+        raise SystemExit(f"unknown fixture group {sys.argv[1]!r}; one of {KNOWN}, or no argument for all (regenerates the pinned fixtures!)")
+    if len(sys.argv) > 1 and sys.argv[1] in KNOWN:   # only one of the later fixtures (the others are unchanged)
         sd = dict(np.load(os.path.join(GOLDEN, "model_seed0.npz")))
         if sys.argv[1] == "scale":
             gen_scale_fixture("render_v140k_dtu", mlp_state=sd)
@@ -783,6 +886,11 @@ def main():
                               n_samples=32, n_importance=32, white_bkgd=True)
         elif sys.argv[1] == "trace":
             gen_render_py_trace()
+        elif sys.argv[1] == "surface140k":
+            gen_surface_scale_fixture("surface_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd))
+        elif sys.argv[1] == "train140k":
+            gen_train_step_fixture("train_step_v140k_surf", V=140_000, mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0, n_rays=256, HW=64,
+                                   kdtree=True)
         elif sys.argv[1] == "edit":
             gen_texture_edit_fixture("texture_edit_v3000", V=3000, mlp_state=sd)
         elif sys.argv[1] == "deform":
@@ -819,6 +927,8 @@ def main():
     gen_painting_step_fixture("painting_step_v3000", V=3000, mlp_state=sd)
     gen_texture_edit_fixture("texture_edit_v3000", V=3000, mlp_state=sd)
     gen_deform_fixture("deform_v3000", V=3000, mlp_state=sd)
+    gen_surface_scale_fixture("surface_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd))
+    gen_train_step_fixture("train_step_v140k_surf", V=140_000, mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0, n_rays=256, HW=64, kdtree=True)
     with open(os.path.join(GOLDEN, "REPORT.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
     print("all oracle-vs-reference checks passed; fixtures written to", GOLDEN)
