@@ -451,7 +451,7 @@ def main():
     ap.add_argument("--V", type=int, default=140_000)
     ap.add_argument("--rayschunk", type=int, default=0,
                     help="rays per nm_render_rays call; 0 = the whole frame in one call (56 KB of workspace per ray: 36 GB for 800x800)")
-    ap.add_argument("--mlp-precision", choices=["f16x2", "f16", "fp32"], default="f16x2",
+    ap.add_argument("--mlp-precision", choices=["f16x2", "f16", "fp32", "f16x2+f16col", "f16x2s", "f16x2s+f16col"], default="f16x2",
                     help="MLP arithmetic: split-half f16 MFMA (default; 22-bit operands, fp32 accumulation), single-product f16 MFMA "
                          "(reduced precision, error-quantified) or fp32 MFMA")
     ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU-baseline sample (0 disables)")
@@ -596,7 +596,7 @@ def main():
         frames_per_step = 1 if one_frame else world
         value = frames_per_step * n_rays * args.steps / elapsed
         dom, p, alg, peak, split = mlp_summary(prof, args.mlp_precision)
-        products = 3.0 if args.mlp_precision == "f16x2" else 1.0
+        products = 3.0 if args.mlp_precision.startswith("f16x2") else 1.0   # (of the geometry kernels, which dominate; '+f16col': the colour kernel issues 1)
         mlp_flop = sum(prof[k]["points"] * prof[k]["flop_per_point"] for k in ("geo_mlp", "geo_mlp_tangent", "color_mlp"))
         mlp_ms = sum(prof[k]["ms"] for k in ("geo_mlp", "geo_mlp_tangent", "color_mlp"))
         kd = prof["knn_distance"]
@@ -621,7 +621,8 @@ def main():
         nabla_k, fixed_k = {"geo_mlp": "false", "geo_mlp_tangent": "true"}, "true"
         kname = ({"geo_mlp": "nm_geo_mlp_h2_kernel<false,true,NP>", "geo_mlp_tangent": "nm_geo_mlp_h2_kernel<true,true,NP>", "color_mlp": "nm_col_mlp_h2_kernel<true,NP>"} if split else
                  {"geo_mlp": "nm_geo_mlp_kernel<false>", "geo_mlp_tangent": "nm_geo_mlp_kernel<true>", "color_mlp": "nm_col_mlp_kernel"})[dom]
-        kname = kname.replace("NP", "3" if args.mlp_precision == "f16x2" else "1")
+        np_geo = "6" if args.mlp_precision.startswith("f16x2s") else "3" if args.mlp_precision.startswith("f16x2") else "1"
+        kname = kname.replace("NP", "1" if (dom == "color_mlp" and args.mlp_precision.endswith("+f16col")) else np_geo)
         searched_per_s = kd["points"] / (kd["ms"] * 1e-3) if kd["ms"] > 0 else 0.0
         n_frames = args.steps    # frames THIS rank's profile saw (its share of each under --shard frame)
         rays_here = (n_rays / world) if one_frame else n_rays
@@ -630,6 +631,9 @@ def main():
         strategy = ("every probe and every mid-point evaluated (data-independent work, as the reference)" if args.data_independent else
                     "probes between first/last hit and zero-weight mid-points skipped (bit-identical)")
         dtype = {"f16x2": "f16x2-split (22-bit operands, fp32 accumulate; K-NN and per-ray stages fp32)",
+                 "f16x2s": "f16x2-split, one accumulator (operands h1 + unscaled residual half: 2^-25 absolute, fp32 accumulate; K-NN and per-ray stages fp32)",
+                 "f16x2+f16col": "f16x2-split geometry network + f16 single-product colour network (error-quantified, see config.parity_*)",
+                 "f16x2s+f16col": "f16x2-split one-accumulator geometry network + f16 single-product colour network (error-quantified, see config.parity_*)",
                  "f16": "f16 single product (11-bit operands, fp32 accumulate): reduced precision, see config.f16_single_*", "fp32": "f32"}[args.mlp_precision]
         out = {
             "metric": f"rays/sec at {args.H}x{args.W}x{args.samples} samples (DTU scan63 shape, synthetic scene S-DTU, {'with a surface' if args.scene == 'surf' else 'default-init noise field'})",

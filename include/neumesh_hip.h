@@ -115,7 +115,10 @@ typedef struct nm_field_desc {
                                   value carried as two fp16 halves (22 bits), 3 f16 MFMAs per product,
                                   fp32 accumulation; |activations| must stay < 65504 (nm_field_overflow
                                   reports a violation); 4: the same kernels with ONE f16 product per fp32
-                                  product (11-bit operands: reduced precision, never a default) */
+                                  product (11-bit operands: reduced precision, never a default);
+                                  5: 2 for the geometry network, 4 for the colour network; 6: as 2 with the residual
+                                  halves unscaled and ONE accumulator for the three products (absolute operand
+                                  precision 2^-25); 7: 6 for the geometry network, 4 for the colour network */
     const float* geo_weight[8];   /* device; layer 0: [W, in_geo], others [W,W] */
     const float* geo_bias[8];     /* device [W] */
     const float* density_weight;  /* device [1,W] */

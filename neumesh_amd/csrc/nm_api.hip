@@ -114,8 +114,10 @@ struct nm_field_s {
     NmColParams col;
     float* blob = nullptr;  // packed weights
     size_t blob_floats = 0;
-    int precision = 0;       // 0 fp32 MFMA (nm_mlp.h), 2 f16 MFMA (nm_mlp_h2.h); mlp_precision 4 = 2 + single
-    bool single = false;     // f16 MFMA with ONE product per fp32 product (plain fp16 operands): error-quantified mode, never the default
+    int precision = 0;       // 0 fp32 MFMA (nm_mlp.h), 2 f16 MFMA (nm_mlp_h2.h); mlp_precision 4 / 5 / 6 / 7 = 2 with other product counts
+    bool single = false;     // f16 MFMA with ONE product per fp32 product in BOTH networks (plain fp16 operands): error-quantified mode, never the default
+    int geo_np = 3, col_np = 3;  // NP template argument of the f16 kernels per network: 3 = three products / two accumulators, 6 = three products /
+                                 // one accumulator (unscaled residual halves), 1 = one product
     NmGeoParamsH2 geo_h2;
     NmColParamsH2 col_h2;
     bool geo_fixed = false, col_fixed = false;  // reference configuration: kernels with constant embedding trip counts
@@ -346,8 +348,9 @@ static int nm_field_validate(const nm_field_desc* d) {
     if (d->multires_d < 0 || d->multires_fg < 0 || d->multires_ft < 0 || d->multires_view < 0) return nm_fail("nm_field: negative multires (identity embedders) unsupported");
     if (d->multires_d > 16 || d->multires_view > 16) return nm_fail("nm_field: multires too large");
     if (!d->use_view_dirs) return nm_fail("nm_field: use_view_dirs=0 unsupported");
-    if (d->mlp_precision != 0 && d->mlp_precision != 2 && d->mlp_precision != 4)
-        return nm_fail("nm_field: mlp_precision=%d (0 = fp32 MFMA, 2 = split-half f16 MFMA [default], 4 = single-product f16 MFMA)", d->mlp_precision);
+    if (d->mlp_precision != 0 && d->mlp_precision != 2 && (d->mlp_precision < 4 || d->mlp_precision > 7))
+        return nm_fail("nm_field: mlp_precision=%d (0 = fp32 MFMA, 2 = split-half f16 MFMA, 4 = single-product f16 MFMA, 5 = split-half geometry + "
+                       "single-product colour, 6 = split-half with one accumulator, 7 = 6 with single-product colour)", d->mlp_precision);
     const int in_geo = 1 + 2 * d->multires_d + d->geometry_dim * (1 + 2 * d->multires_fg);
     const int in_col = (d->enable_nablas_input ? 3 : 0) + 1 + 2 * d->multires_d + 3 * (1 + 2 * d->multires_view) + d->color_dim * (1 + 2 * d->multires_ft);
     if (in_geo > 256 || in_col > 256) return nm_fail("nm_field: MLP input width %d/%d exceeds the 256-column LDS tile", in_geo, in_col);
@@ -417,8 +420,10 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
     f->col.d_emb = 1 + 2 * d->multires_d;
     f->col.in_dim = in_col;
     f->desc = *d;
-    f->precision = d->mlp_precision == 4 ? 2 : d->mlp_precision;
+    f->precision = d->mlp_precision >= 4 ? 2 : d->mlp_precision;
     f->single = d->mlp_precision == 4;
+    f->geo_np = d->mlp_precision == 4 ? 1 : (d->mlp_precision >= 6 ? 6 : 3);
+    f->col_np = (d->mlp_precision == 4 || d->mlp_precision == 5 || d->mlp_precision == 7) ? 1 : (d->mlp_precision == 6 ? 6 : 3);
     if (d->mlp_precision >= 1) {
         size_t need_h = 0;
         for (int l = 0; l < d->D_density; ++l) need_h += (size_t)NM_W * nm_round16(l == 0 ? in_geo : NM_W) * 2;
@@ -439,11 +444,11 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
         _Float16* ph = f->blob_h;
         memset(&f->geo_h2, 0, sizeof(f->geo_h2));
         memset(&f->col_h2, 0, sizeof(f->col_h2));
-        auto pack_h2 = [&](const float* src, int in_dim, const NmColSeg& seg, NmLayerH& L, const float* packed_bias, float scale) {
+        auto pack_h2 = [&](const float* src, int in_dim, const NmColSeg& seg, NmLayerH& L, const float* packed_bias, float scale, int np) {
             L.Kpad = nm_round16(in_dim);
             L.W = ph;
             L.b = packed_bias;
-            hipLaunchKernelGGL(nm_pack_weight_h2_kernel, dim3(nm_blocks((long long)NM_W * L.Kpad, 256)), dim3(256), 0, stream, src, in_dim, L.Kpad, seg, scale, ph);
+            hipLaunchKernelGGL(nm_pack_weight_h2_kernel, dim3(nm_blocks((long long)NM_W * L.Kpad, 256)), dim3(256), 0, stream, src, in_dim, L.Kpad, seg, scale, np == 6 ? 1.0f : 2048.0f, ph);
             ph += (size_t)NM_W * L.Kpad * 2;
         };
         // geometry MLP in log2 units: biases x S, density weights x 1/S (fp32 copies behind the unscaled ones), layer-0 weights x S
@@ -481,8 +486,8 @@ static int nm_field_pack(nm_field_s* f, const nm_field_desc* d, hipStream_t stre
         sc.len[4] = nb;  sc.src[4] = 0;
         sc.len[5] = 1;   sc.src[5] = lo_d;
         for (int l = 0; l < d->D_density; ++l)
-            pack_h2(d->geo_weight[l], l == 0 ? in_geo : NM_W, l == 0 ? sg : ident, f->geo_h2.layer[l], scaled(f->geo.layer[l].b, NM_H2_S), l == 0 ? NM_H2_S : 1.0f);
-        for (int l = 0; l < d->D_color; ++l) pack_h2(d->col_weight[l], l == 0 ? in_col : NM_W, l == 0 ? sc : ident, f->col_h2.layer[l], f->col.layer[l].b, 1.0f);
+            pack_h2(d->geo_weight[l], l == 0 ? in_geo : NM_W, l == 0 ? sg : ident, f->geo_h2.layer[l], scaled(f->geo.layer[l].b, NM_H2_S), l == 0 ? NM_H2_S : 1.0f, f->geo_np);
+        for (int l = 0; l < d->D_color; ++l) pack_h2(d->col_weight[l], l == 0 ? in_col : NM_W, l == 0 ? sc : ident, f->col_h2.layer[l], f->col.layer[l].b, 1.0f, f->col_np);
         f->geo_h2.wd = scaled(f->geo.wd, 1.0f / NM_H2_S);
         NM_LAUNCH_CHECK();
         NM_HIP(hipStreamSynchronize(stream));
@@ -581,11 +586,16 @@ static int nm_launch_geo(nm_field_t f, const float* fg, const float* ds, const f
     if (f->precision == 2) {
         const dim3 gr(nm_blocks(P, nabla ? 32 : 64)), bl(NM_H_THREADS);
 #define NM_GEO_H2(NB, FX, NP) hipLaunchKernelGGL((nm_geo_mlp_h2_kernel<NB, FX, NP>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow)
-        if (!f->single) {
+        if (f->geo_np == 3) {
             if (nabla && f->geo_fixed) NM_GEO_H2(true, true, 3);
             else if (nabla) NM_GEO_H2(true, false, 3);
             else if (f->geo_fixed) NM_GEO_H2(false, true, 3);
             else NM_GEO_H2(false, false, 3);
+        } else if (f->geo_np == 6) {
+            if (nabla && f->geo_fixed) NM_GEO_H2(true, true, 6);
+            else if (nabla) NM_GEO_H2(true, false, 6);
+            else if (f->geo_fixed) NM_GEO_H2(false, true, 6);
+            else NM_GEO_H2(false, false, 6);
         } else {
             if (nabla && f->geo_fixed) NM_GEO_H2(true, true, 1);
             else if (nabla) NM_GEO_H2(true, false, 1);
@@ -613,9 +623,12 @@ static int nm_launch_col(nm_field_t f, const float* ft, const float* ds, const f
     NmProfScope prof(NM_K_COLOR, counted ? 0 : P, stream, counted ? NM_CNT_MID : NM_CNT_NONE);
     if (f->precision == 2) {
 #define NM_COL_H2(FX, NP) hipLaunchKernelGGL((nm_col_mlp_h2_kernel<FX, NP>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h2, ft, ds, nabla, dirs, dir_div, P, rgb, smap, f->overflow)
-        if (!f->single) {
+        if (f->col_np == 3) {
             if (f->col_fixed) NM_COL_H2(true, 3);
             else NM_COL_H2(false, 3);
+        } else if (f->col_np == 6) {
+            if (f->col_fixed) NM_COL_H2(true, 6);
+            else NM_COL_H2(false, 6);
         } else {
             if (f->col_fixed) NM_COL_H2(true, 1);
             else NM_COL_H2(false, 1);

@@ -11,6 +11,14 @@
 // columns) and the packed weights keep their size; activations are split ONCE, by the epilogue that produces them.
 // Range: |values| must stay below 65504 (fp16); fp16 subnormals are exact on the matrix pipe (tools/mfma_denorm.hip).
 //
+// One accumulator (NP = 6, mlp_precision 6): the same three products with the residual halves stored UNSCALED,
+// h2 = rne16(a - h1) (fp16 subnormals, quantum 2^-24, are exact on the matrix pipe), so that all three accumulate into ONE
+// fp32 accumulator: 64 instead of 128 accumulator registers per wave, no recombination and no 2^11 scaling in the epilogue
+// (5.5 instead of 7 vector instructions per activation).  What it gives up: an operand keeps an ABSOLUTE precision of 2^-25
+// instead of a relative 2^-22, so small operands lose bits -- harmless for the value rows (tools/mlp_error_budget.py: sdf error
+// 6e-8 against 5e-8), but the tangent rows must enter at 2^-8 instead of 2^-15 to stay above it (d sdf / d ds error 2e-6
+// against 5e-7; gate 5e-6).
+//
 // Single product (NP = 1, mlp_precision 4, never the default): only h1a*h1b -- plain fp16 operands (11 significant
 // bits) with fp32 accumulation, one MFMA per product.  This is the "bf16 MLP"-class mode BASELINE configs[1] names
 // (fp16 keeps 3 more mantissa bits than bf16 at the same matrix rate); it does NOT meet the 1e-4 RGB bound and is
@@ -98,7 +106,7 @@ struct NmColSeg {
 // weights: fp32 [256][in_dim] (PyTorch layout, logical columns) -> split halves in MFMA A-operand
 // fragment order [column tile 8][k-step Kpad/16][plane 2][lane 64][8 halves]; lane = (row i of the
 // tile) | (k-half << 5) with row i = 4h + 8g + e holding output column 16h + 4g + e (header comment).
-__global__ void nm_pack_weight_h2_kernel(const float* __restrict__ src, int in_dim, int Kpad, NmColSeg seg, float scale, _Float16* __restrict__ dst) {
+__global__ void nm_pack_weight_h2_kernel(const float* __restrict__ src, int in_dim, int Kpad, NmColSeg seg, float scale, float res_scale, _Float16* __restrict__ dst) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;  // one thread per (n, k)
     if (e >= NM_W * Kpad) return;
     const int n = e / Kpad, k = e - n * Kpad;
@@ -108,8 +116,8 @@ __global__ void nm_pack_weight_h2_kernel(const float* __restrict__ src, int in_d
         base += seg.len[s];
     }
     const float w = (kl >= 0 && kl < in_dim) ? src[(size_t)n * in_dim + kl] * scale : 0.f;
-    _Float16 h1, h2;
-    nm_split_half(w, &h1, &h2);
+    const _Float16 h1 = (_Float16)w;
+    const _Float16 h2 = (_Float16)((w - (float)h1) * res_scale);   // res_scale: 2048 (two accumulators) or 1 (one accumulator)
     const int ct = n >> 5, c = n & 31;
     const int i = 4 * (c >> 4) + 8 * ((c >> 2) & 3) + (c & 3);
     const int lane = i | (((k >> 3) & 1) << 5), ks = k >> 4, el = k & 7;
@@ -145,55 +153,57 @@ struct NmColParamsH2 {
 // ------------------------------------------------------------------------- split + store helpers
 // a -> (h1, h2), a ~= h1 + h2 / 2048 as nm_split_half, with the residual formed by ONE mixed-precision fma
 // on the f16 value: (a - h1) * 2048 == fma(h1, -2048, a * 2048) exactly (every term is exact in fp32).
+template <bool US = false>
 __device__ __forceinline__ void nm_h2_split(float a, _Float16& h1, _Float16& h2) {
     h1 = (_Float16)a;
-    h2 = (_Float16)fmaf((float)h1, -2048.0f, a * 2048.0f);
+    h2 = US ? (_Float16)(a - (float)h1) : (_Float16)fmaf((float)h1, -2048.0f, a * 2048.0f);
 }
 // Two values at once, as packed pairs (low half = a): h1 = one v_cvt_pk_f16_f32, the residuals by v_fma_mix{lo,hi}_f16,
 // which read their f16 operand straight from the packed pair and round the fp32 fma result to f16 once -- the same
 // arithmetic as nm_h2_split, 4 instructions per pair instead of 6 (the compiler only finds the mix form now and then).
+template <bool US = false>
 __device__ __forceinline__ void nm_h2_split2(float a, float b, unsigned& p1, unsigned& p2) {
     p1 = __builtin_bit_cast(unsigned, nm_h2{(_Float16)a, (_Float16)b});
-    const float a2 = a * 2048.0f, b2 = b * 2048.0f, m = -2048.0f;
+    const float a2 = US ? a : a * 2048.0f, b2 = US ? b : b * 2048.0f, m = US ? -1.0f : -2048.0f;   // (US: the residual as it is, one fma_mix per value)
     unsigned r;
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(p1), "s"(m), "v"(a2));
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(p1), "s"(m), "v"(b2));
     p2 = r;
 }
 // (mx: running max of |value| for the fp16-range check; pairs go through one max3)
-template <int PLANE = NM_H_PLANE>
+template <int PLANE = NM_H_PLANE, bool US = false>
 __device__ __forceinline__ void nm_h2_store1(_Float16* p, float a, float& mx) {
     _Float16 h1, h2;
-    nm_h2_split(a, h1, h2);
+    nm_h2_split<US>(a, h1, h2);
     p[0] = h1;
     p[PLANE] = h2;
     mx = fmaxf(mx, fabsf(a));
 }
-template <int PLANE = NM_H_PLANE>
+template <int PLANE = NM_H_PLANE, bool US = false>
 __device__ __forceinline__ void nm_h2_store2(_Float16* p, float a, float b, float& mx) {  // p 4-byte aligned
     unsigned p1, p2;
-    nm_h2_split2(a, b, p1, p2);
+    nm_h2_split2<US>(a, b, p1, p2);
     *reinterpret_cast<unsigned*>(p) = p1;
     *reinterpret_cast<unsigned*>(p + PLANE) = p2;
     mx = fmaxf(mx, fmaxf(fabsf(a), fabsf(b)));
 }
-template <int PLANE = NM_H_PLANE>
+template <int PLANE = NM_H_PLANE, bool US = false>
 __device__ __forceinline__ void nm_h2_store4(_Float16* p, const float (&v)[4], float& mx) {  // p 8-byte aligned
     uint2 a, b;
-    nm_h2_split2(v[0], v[1], a.x, b.x);
-    nm_h2_split2(v[2], v[3], a.y, b.y);
+    nm_h2_split2<US>(v[0], v[1], a.x, b.x);
+    nm_h2_split2<US>(v[2], v[3], a.y, b.y);
     mx = fmaxf(mx, fmaxf(fabsf(v[0]), fabsf(v[1])));
     mx = fmaxf(mx, fmaxf(fabsf(v[2]), fabsf(v[3])));
     *reinterpret_cast<uint2*>(p) = a;
     *reinterpret_cast<uint2*>(p + PLANE) = b;
 }
-template <int PLANE = NM_H_PLANE>
+template <int PLANE = NM_H_PLANE, bool US = false>
 __device__ __forceinline__ void nm_h2_store8(_Float16* p, const float (&v)[8], float& mx) {  // p 16-byte aligned
     uint4 a, b;
-    nm_h2_split2(v[0], v[1], a.x, b.x);
-    nm_h2_split2(v[2], v[3], a.y, b.y);
-    nm_h2_split2(v[4], v[5], a.z, b.z);
-    nm_h2_split2(v[6], v[7], a.w, b.w);
+    nm_h2_split2<US>(v[0], v[1], a.x, b.x);
+    nm_h2_split2<US>(v[2], v[3], a.y, b.y);
+    nm_h2_split2<US>(v[4], v[5], a.z, b.z);
+    nm_h2_split2<US>(v[6], v[7], a.w, b.w);
 #pragma unroll
     for (int e = 0; e < 8; e += 2) mx = fmaxf(fmaxf(mx, fabsf(v[e])), fabsf(v[e + 1]));
     *reinterpret_cast<uint4*>(p) = a;
@@ -227,9 +237,9 @@ __device__ __forceinline__ void nm_h2_zero_cols(_Float16* row, int c0, int c1, i
 // x and its sin/cos bands for 4 consecutive dims of a `dim`-wide code vector, into an embedding block
 // that starts at blk[0]: 8-byte stores (dim is a multiple of 4).  Odd bands from the even band below
 // by the double-angle identities, as nm_embed4_h.
-template <bool FAST, int PLANE = NM_H_PLANE>
+template <bool FAST, int PLANE = NM_H_PLANE, bool US = false>
 __device__ __forceinline__ void nm_h2_embed_chunk_t(_Float16* blk, int dim, int bands, int chunk, const float (&xs)[4], float& mx) {
-    nm_h2_store4<PLANE>(blk + 4 * chunk, xs, mx);
+    nm_h2_store4<PLANE, US>(blk + 4 * chunk, xs, mx);
     float f = 1.0f;
     for (int b = 0; b < bands; b += 2) {
         float s[4], c[4];
@@ -238,8 +248,8 @@ __device__ __forceinline__ void nm_h2_embed_chunk_t(_Float16* blk, int dim, int 
             if (FAST) nm_sincos_fast(xs[e] * f, &s[e], &c[e]);
             else nm_sincos(xs[e] * f, &s[e], &c[e]);
         }
-        nm_h2_store4<PLANE>(blk + dim * (1 + 2 * b) + 4 * chunk, s, mx);
-        nm_h2_store4<PLANE>(blk + dim * (2 + 2 * b) + 4 * chunk, c, mx);
+        nm_h2_store4<PLANE, US>(blk + dim * (1 + 2 * b) + 4 * chunk, s, mx);
+        nm_h2_store4<PLANE, US>(blk + dim * (2 + 2 * b) + 4 * chunk, c, mx);
         if (b + 1 < bands) {
             float s2[4], c2[4];
 #pragma unroll
@@ -247,20 +257,20 @@ __device__ __forceinline__ void nm_h2_embed_chunk_t(_Float16* blk, int dim, int 
                 s2[e] = 2.0f * s[e] * c[e];
                 c2[e] = (c[e] - s[e]) * (c[e] + s[e]);
             }
-            nm_h2_store4<PLANE>(blk + dim * (3 + 2 * b) + 4 * chunk, s2, mx);
-            nm_h2_store4<PLANE>(blk + dim * (4 + 2 * b) + 4 * chunk, c2, mx);
+            nm_h2_store4<PLANE, US>(blk + dim * (3 + 2 * b) + 4 * chunk, s2, mx);
+            nm_h2_store4<PLANE, US>(blk + dim * (4 + 2 * b) + 4 * chunk, c2, mx);
         }
         f *= 4.0f;
     }
 }
 // One range test per chunk instead of one per sincos: the straight-line fast path (every argument within the polynomial
 // reduction's range -- always, for trained codes) lets the four evaluations of a band overlap; same values either way.
-template <int PLANE = NM_H_PLANE>
+template <int PLANE = NM_H_PLANE, bool US = false>
 __device__ __forceinline__ void nm_h2_embed_chunk(_Float16* blk, int dim, int bands, int chunk, float4 x, float& mx) {
     const float xs[4] = {x.x, x.y, x.z, x.w};
     const float top = fmaxf(fmaxf(fabsf(xs[0]), fabsf(xs[1])), fmaxf(fabsf(xs[2]), fabsf(xs[3]))) * (float)(1 << ((bands > 0 ? bands - 1 : 0) & ~1));  // (largest frequency evaluated directly: the highest even band)
-    if (top <= NM_SINCOS_FAST_MAX) nm_h2_embed_chunk_t<true, PLANE>(blk, dim, bands, chunk, xs, mx);
-    else nm_h2_embed_chunk_t<false, PLANE>(blk, dim, bands, chunk, xs, mx);
+    if (top <= NM_SINCOS_FAST_MAX) nm_h2_embed_chunk_t<true, PLANE, US>(blk, dim, bands, chunk, xs, mx);
+    else nm_h2_embed_chunk_t<false, PLANE, US>(blk, dim, bands, chunk, xs, mx);
 }
 
 // Softplus(beta = 100) in "log2 units".  With S = 100 / ln 2 the reference's y = softplus(z) = log2(1 + 2^(S z)) / S, so
@@ -280,6 +290,11 @@ __device__ __forceinline__ float nm_softplus_l2(float zp, float* grad) {
 }
 // tangent rows enter layer 0 scaled by 2^-15 (~ 2^-8 / S: the same fp16 head room as the unscaled kernels' 2^-8)
 #define NM_H2_TANGENT_SCALE 3.0517578125e-05f
+// one-accumulator mode: 2^-8 -- the unscaled residual halves resolve 2^-25 absolute, so the tangent operands must not be small
+// (largest tangent operand on the fixture scenes at this scale: 3; fp16 range 65504)
+#define NM_H2_TANGENT_SCALE_1ACC 3.90625e-03f
+template <int NP>
+__device__ __forceinline__ constexpr float nm_h2_tscale() { return NP == 6 ? NM_H2_TANGENT_SCALE_1ACC : NM_H2_TANGENT_SCALE; }
 
 // --------------------------------------------------------------------------------- K loop
 // As nm_kloop_h (B fragments two k-steps ahead in three rotating register sets, A fragments one step
@@ -294,6 +309,12 @@ __device__ __forceinline__ float nm_softplus_l2(float zp, float* grad) {
         c.lo[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.b[c_], A[rt_][0], c.lo[rt_][c_], 0, 0, 0);   \
     _Pragma("unroll") for (int rt_ = 0; rt_ < (R1); ++rt_) _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_)  \
         c.lo[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[c_], A[rt_][1], c.lo[rt_][c_], 0, 0, 0);   \
+    }                                                                                                             \
+    if (NP == 6) { /* one accumulator: the cross products (unscaled residual halves) go where the main product went */ \
+    _Pragma("unroll") for (int rt_ = 0; rt_ < (R1); ++rt_) _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_)  \
+        c.hi[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.b[c_], A[rt_][0], c.hi[rt_][c_], 0, 0, 0);   \
+    _Pragma("unroll") for (int rt_ = 0; rt_ < (R1); ++rt_) _Pragma("unroll") for (int c_ = 0; c_ < CT; ++c_)  \
+        c.hi[rt_][c_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.a[c_], A[rt_][1], c.hi[rt_][c_], 0, 0, 0);   \
     }
 
 // B (weight) fragments are fetched with raw buffer loads: the (layer, column tile) block is a buffer
@@ -312,7 +333,7 @@ __device__ __forceinline__ NmBFrag<CT> nm_ld_bu(const nm_rsrc (&ub)[CT], int lan
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         f.a[c] = __builtin_bit_cast(nm_h8, __builtin_amdgcn_raw_buffer_load_b128(ub[c], lane * 16, ks * 2048, 0));
-        if (NP == 3) f.b[c] = __builtin_bit_cast(nm_h8, __builtin_amdgcn_raw_buffer_load_b128(ub[c], lane * 16, ks * 2048 + 1024, 0));
+        if (NP != 1) f.b[c] = __builtin_bit_cast(nm_h8, __builtin_amdgcn_raw_buffer_load_b128(ub[c], lane * 16, ks * 2048 + 1024, 0));
         else f.b[c] = nm_h8{0, 0, 0, 0, 0, 0, 0, 0};   // (single-product mode: the residual plane is never read)
     }
     return f;
@@ -333,10 +354,10 @@ __device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16*
     for (int i = 0; i < DEPTH; ++i) f[i] = pre.s[i];
     nm_h8 a[2][2][2];  // [buffer][row tile][plane]
     a[0][0][0] = *reinterpret_cast<const nm_h8*>(a0p);
-    if (NP == 3) a[0][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
+    if (NP != 1) a[0][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE);
     if (KT0 == 0) {
         a[0][1][0] = *reinterpret_cast<const nm_h8*>(a1p);
-        if (NP == 3) a[0][1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE);
+        if (NP != 1) a[0][1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE);
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -349,10 +370,10 @@ __device__ __forceinline__ void nm_kloop_h2(const _Float16* a0p, const _Float16*
         if (ks + 1 < KS) {
             const int oa = (ks + 1) * 16;
             a[(ks + 1) & 1][0][0] = *reinterpret_cast<const nm_h8*>(a0p + oa);
-            if (NP == 3) a[(ks + 1) & 1][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
+            if (NP != 1) a[(ks + 1) & 1][0][1] = *reinterpret_cast<const nm_h8*>(a0p + NM_H_PLANE + oa);
             if (ks + 1 >= KT0) {
                 a[(ks + 1) & 1][1][0] = *reinterpret_cast<const nm_h8*>(a1p + oa);
-                if (NP == 3) a[(ks + 1) & 1][1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE + oa);
+                if (NP != 1) a[(ks + 1) & 1][1][1] = *reinterpret_cast<const nm_h8*>(a1p + NM_H_PLANE + oa);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -484,7 +505,7 @@ __device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const float z0 = NP == 3 ? fmaf(c.lo[0][ct][8 * hf + r], sc, c.hi[0][ct][8 * hf + r]) : c.hi[0][ct][8 * hf + r];  // (bias: in the accumulator)
-                const float z1 = NP == 3 ? fmaf(c.lo[1][ct][8 * hf + r], sc, c.hi[1][ct][8 * hf + r]) : c.hi[1][ct][8 * hf + r];
+                const float z1 = NP == 3 ? fmaf(c.lo[1][ct][8 * hf + r], sc, c.hi[1][ct][8 * hf + r]) : c.hi[1][ct][8 * hf + r];  // (NP 6: one accumulator holds all three products)
                 if (TANGENT) {
                     float g0;
                     if (ACT == 0) {
@@ -508,6 +529,9 @@ __device__ __forceinline__ void nm_mlp_layer_h2(_Float16* tile, const NmLayerH L
                 if (NP == 3) {
                     nm_h2_store8(tile + li * NM_H_STRIDE + col0, y0, mx);
                     nm_h2_store8(tile + (32 + li) * NM_H_STRIDE + col0, y1, mx);
+                } else if (NP == 6) {   // one accumulator: unscaled residual halves
+                    nm_h2_store8<NM_H_PLANE, true>(tile + li * NM_H_STRIDE + col0, y0, mx);
+                    nm_h2_store8<NM_H_PLANE, true>(tile + (32 + li) * NM_H_STRIDE + col0, y1, mx);
                 } else {   // single product: the main halves only
                     nm_h1_store8(tile + li * NM_H_STRIDE + col0, y0, mx);
                     nm_h1_store8(tile + (32 + li) * NM_H_STRIDE + col0, y1, mx);
@@ -638,18 +662,20 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
             continue;
         }
         const float dsv = in_ds[rd];
-        if (j < nchunk) nm_h2_embed_chunk(vrow, gdim, mfg, j, in_fg[rd][0], mx);
-        if (j + 8 < nchunk) nm_h2_embed_chunk(vrow, gdim, mfg, j + 8, in_fg[rd][1], mx);
+        constexpr bool US = NP == 6;                      // residual halves unscaled (one-accumulator mode)
+        constexpr float TS = nm_h2_tscale<NP>();
+        if (j < nchunk) nm_h2_embed_chunk<NM_H_PLANE, US>(vrow, gdim, mfg, j, in_fg[rd][0], mx);
+        if (j + 8 < nchunk) nm_h2_embed_chunk<NM_H_PLANE, US>(vrow, gdim, mfg, j + 8, in_fg[rd][1], mx);
         for (int b = j; b < md; b += 8) {  // ds block: (sin, cos) pairs, then ds itself
             const float f = (float)(1 << b);
             float s, co;
             nm_sincos(dsv * f, &s, &co);
-            nm_h2_store2(vrow + FG + 2 * b, s, co, mx);
-            if (NABLA) nm_h2_store2(trow + FG + 2 * b, (NM_H2_TANGENT_SCALE * f) * co, -(NM_H2_TANGENT_SCALE * f) * s, mx);
+            nm_h2_store2<NM_H_PLANE, US>(vrow + FG + 2 * b, s, co, mx);
+            if (NABLA) nm_h2_store2<NM_H_PLANE, US>(trow + FG + 2 * b, (TS * f) * co, -(TS * f) * s, mx);
         }
         if (j == 0) {
-            nm_h2_store1(vrow + FG + 2 * md, dsv, mx);
-            if (NABLA) nm_h2_store1(trow + FG + 2 * md, NM_H2_TANGENT_SCALE, mx);
+            nm_h2_store1<NM_H_PLANE, US>(vrow + FG + 2 * md, dsv, mx);
+            if (NABLA) nm_h2_store1<NM_H_PLANE, US>(trow + FG + 2 * md, TS, mx);
         }
         for (int c = in_dim + j; c < Kpad0; c += 8) {  // padding columns
             vrow[c] = (_Float16)0.0f;
@@ -694,7 +720,7 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
             locate(t, rq, oidx);
             if (sdf_out) sdf_out[oidx] = sdf;
             if (NABLA && nabla_out) {
-                const float dsdf = ((red[32 + t] + red[NM_ROWS + 32 + t]) + (red[2 * NM_ROWS + 32 + t] + red[3 * NM_ROWS + 32 + t])) * (1.0f / NM_H2_TANGENT_SCALE);
+                const float dsdf = ((red[32 + t] + red[NM_ROWS + 32 + t]) + (red[2 * NM_ROWS + 32 + t] + red[3 * NM_ROWS + 32 + t])) * (1.0f / nm_h2_tscale<NP>());
                 const long long no = nabla_slotted ? oidx : q;
                 nabla_out[no * 3 + 0] = dsdf * grad[rq * 3 + 0];
                 nabla_out[no * 3 + 1] = dsdf * grad[rq * 3 + 1];
@@ -782,23 +808,24 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_
         }
         const float dsv = in_ds[rd];
         const float dv[3] = {in_dv[rd][0], in_dv[rd][1], in_dv[rd][2]};
-        if (j < nchunk) nm_h2_embed_chunk(vrow, cdim, mft, j, in_ft[rd][0], mx);
-        if (j + 8 < nchunk) nm_h2_embed_chunk(vrow, cdim, mft, j + 8, in_ft[rd][1], mx);
+        constexpr bool US = NP == 6;
+        if (j < nchunk) nm_h2_embed_chunk<NM_H_PLANE, US>(vrow, cdim, mft, j, in_ft[rd][0], mx);
+        if (j + 8 < nchunk) nm_h2_embed_chunk<NM_H_PLANE, US>(vrow, cdim, mft, j + 8, in_ft[rd][1], mx);
         for (int b = j; b < md; b += 8) {
             float s, co;
             nm_sincos(dsv * (float)(1 << b), &s, &co);
-            nm_h2_store2(vrow + o_d + 2 * b, s, co, mx);
+            nm_h2_store2<NM_H_PLANE, US>(vrow + o_d + 2 * b, s, co, mx);
         }
         for (int e = j; e < 3 * mv; e += 8) {  // view bands: [sin(v f_b) (3) | cos(v f_b) (3)] per band
             const int b = e / 3, dim = e - 3 * b;
             float s, co;
             nm_sincos((dim == 0 ? dv[0] : dim == 1 ? dv[1] : dv[2]) * (float)(1 << b), &s, &co);
-            nm_h2_store1(vrow + o_vb + 6 * b + dim, s, mx);
-            nm_h2_store1(vrow + o_vb + 6 * b + 3 + dim, co, mx);
+            nm_h2_store1<NM_H_PLANE, US>(vrow + o_vb + 6 * b + dim, s, mx);
+            nm_h2_store1<NM_H_PLANE, US>(vrow + o_vb + 6 * b + 3 + dim, co, mx);
         }
-        if (j < 3) nm_h2_store1(vrow + o_v + j, j == 0 ? dv[0] : j == 1 ? dv[1] : dv[2], mx);
-        else if (j < 6 && use_nabla) nm_h2_store1(vrow + o_n + (j - 3), in_x[rd], mx);
-        else if (j == 6) nm_h2_store1(vrow + o_ds, dsv, mx);
+        if (j < 3) nm_h2_store1<NM_H_PLANE, US>(vrow + o_v + j, j == 0 ? dv[0] : j == 1 ? dv[1] : dv[2], mx);
+        else if (j < 6 && use_nabla) nm_h2_store1<NM_H_PLANE, US>(vrow + o_n + (j - 3), in_x[rd], mx);
+        else if (j == 6) nm_h2_store1<NM_H_PLANE, US>(vrow + o_ds, dsv, mx);
         for (int c = in_dim + j; c < Kpad0; c += 8) {
             vrow[c] = (_Float16)0.0f;
             vrow[NM_H_PLANE + c] = (_Float16)0.0f;

@@ -53,7 +53,7 @@ class TextureEditableNeuMesh(nn.Module):
     def _main_query(self, xyz, view_dirs, need_nablas):
         """(sdf, nabla, ds, indices, weights, main colour): texture_neumesh.py:64-78."""
         m = self.main_model
-        if not torch.is_grad_enabled() and need_nablas and hasattr(m, "_fused_forward"):
+        if not torch.is_grad_enabled() and need_nablas and hasattr(m, "_fused_forward") and m.fused_supported():
             sdf, rgb, nabla, ds, idx, w = m._fused_forward(xyz, view_dirs, True)   # one fused HIP call
             return sdf, nabla, ds, idx, w, rgb
         sdf, nabla, ds, idx, w = m.forward(xyz, view_dirs, need_nablas=need_nablas, nablas_only=True, return_ds=True)

@@ -55,7 +55,10 @@ def get_embedder(multires: int, input_dim: int = 3):
 
 # mlp_precision -> nm_field_desc.mlp_precision.  "f16" = ONE f16 MFMA per product (plain fp16 operands, fp32 accumulation):
 # the reduced-precision mode BASELINE configs[1] calls "bf16 MLP"; it misses the 1e-4 RGB bound and is never a default
-_PRECISION_CODES = {"fp32": 0, "f16x2": 2, "f16": 4}
+# "f16x2+f16col": split-half geometry network (whose error the s = 400 sigmoid amplifies) + single-product colour network (not
+# amplified: |d rgb| <= 1/4 |d z|); "f16x2s": the three products in ONE accumulator (unscaled residual halves, nm_mlp_h2.h);
+# "f16x2s+f16col": both.  Their errors against the reference are in every bench line and gated in tests/test_gpu_parity.py.
+_PRECISION_CODES = {"fp32": 0, "f16x2": 2, "f16": 4, "f16x2+f16col": 5, "f16x2s": 6, "f16x2s+f16col": 7}
 
 
 def interpolation(features, indices, weights):
@@ -157,6 +160,10 @@ class _HipField(autograd.Function):
                                             _lib.ptr(rgb), _lib.ptr(ws), _lib.current_stream(dev)), "nm_train_forward")
         ctx.model, ctx.mode, ctx.ws, ctx.tile, ctx.P = model, mode, ws, tile, P
         ctx.desc, ctx.tables, ctx.keep = desc, t, (keep, gf, cf, iv, tensors)
+        # backward re-reads the weights / tables through the pointers of `desc` and `t` (nothing is copied): remember the version counters
+        # so that an in-place change in between (an optimizer step between two backward passes, weight clipping) is an error, as it is
+        # for tensors autograd saves itself
+        ctx.versions = [x._version for x in tensors]
         ctx.grid = grid
         ctx.shapes = [tuple(x.shape) for x in tensors]
         lead = xyz.shape[:-1]
@@ -172,6 +179,13 @@ class _HipField(autograd.Function):
     def backward(ctx, *cot):
         lib = _lib.load()
         model, mode, tile, P = ctx.model, ctx.mode, ctx.tile, ctx.P
+        if ctx.ws is None:
+            raise RuntimeError("_HipField: backward through the same field query a second time -- its workspace is released by the first "
+                               "backward pass (retain_graph is not supported on the HIP training path; use autograd_backend='torch')")
+        changed = [i for i, (x, v) in enumerate(zip(ctx.keep[4], ctx.versions)) if x._version != v]
+        if changed:
+            raise RuntimeError(f"_HipField: {len(changed)} of the field's parameter tensors were modified in place between forward and backward "
+                               "(the backward pass reads them where they are); run backward before the optimizer step")
         dev = ctx.ws.device
 
         def fwd(g, w_):
@@ -399,10 +413,14 @@ class NeuMesh(nn.Module):
             _lib.check(lib.nm_field_overflow(self._field.h, C.byref(flag), _lib.current_stream(self._field_dev)), "nm_field_overflow")
         self._range_checked = True
         if not flag.value:
+            self._range_last_read = self._range_calls
             return True
         import warnings
+        late = self._range_calls - getattr(self, "_range_last_read", 0)
         warnings.warn("NeuMesh: an MLP activation or input left the fp16 range (|v| >= 65504) in the split-half f16 mode; "
-                      "switching this model to mlp_precision='fp32' and re-running", RuntimeWarning)
+                      "switching this model to mlp_precision='fp32' and re-running this call"
+                      + (f" -- the flag is polled every {every} point-wise calls, so up to {late - 1} EARLIER calls since the last poll may hold "
+                         "Inf / NaN-affected values: repeat the enclosing render / ray-casting call" if late > 1 else ""), RuntimeWarning)
         self.mlp_precision = "fp32"
         return False
 
@@ -438,6 +456,76 @@ class NeuMesh(nn.Module):
                     self._scalars = (0.1, float(self.forward_s()))
             self._scalars_key = key
         return self._scalars
+
+    # ------------------------------------------------------------------ which kernels can serve this configuration
+    def fused_supported(self) -> bool:
+        """The fused inference kernels (nm_field_* / nm_render_rays: LDS tiles of 256 columns, csrc/nm_api.hip:nm_field_validate) are
+        built for hidden width 256 -- the reference's value (models/frameworks/neumesh/__init__.py:26) -- code widths <= 64 and
+        MLP inputs <= 256 columns."""
+        c = self._cfg
+        in_geo = 1 + 2 * c["multires_d"] + c["geometry_dim"] * (1 + 2 * c["multires_fg"])
+        in_col = (3 if self.enable_nablas_input else 0) + 1 + 2 * c["multires_d"] + 3 * (1 + 2 * c["multires_view"]) + c["color_dim"] * (1 + 2 * c["multires_ft"])
+        return (c["W"] == 256 and all(4 <= c[k] <= 64 and c[k] % 4 == 0 for k in ("geometry_dim", "color_dim"))
+                and all(c[k] >= 0 for k in ("multires_d", "multires_fg", "multires_ft", "multires_view")) and c["multires_d"] <= 16
+                and c["multires_view"] <= 16 and in_geo <= 256 and in_col <= 256 and 1 <= c["D_density"] <= 8 and 1 <= c["D_color"] <= 8)
+
+    def train_kernels_supported(self) -> bool:
+        """The any-width kernels of the training path (nm_train_forward / nm_train_backward, csrc/nm_api.hip:nm_train_validate):
+        hidden width a multiple of 16, code widths multiples of 4, <= 8 layers, 0..15 embedder bands."""
+        c = self._cfg
+        return (c["W"] >= 16 and c["W"] % 16 == 0 and 1 <= c["D_density"] <= 8 and 1 <= c["D_color"] <= 8
+                and all(c[k] >= 4 and c[k] % 4 == 0 for k in ("geometry_dim", "color_dim"))
+                and all(0 <= c[k] <= 15 for k in ("multires_d", "multires_fg", "multires_ft", "multires_view")))
+
+    def inference_route(self) -> str:
+        """'fused' (the inference kernels), 'general' (a configuration they refuse -- any other hidden width, wider codes: the
+        reference takes W as a free constructor argument, neumesh.py:16-36 -- served by nm_train_forward, forward only, its workspace
+        dropped after the call; the renderer then takes its staged form), or 'torch' (neither kernel set: device torch ops around the
+        HIP K-NN).  One warning per model when the route is not 'fused'."""
+        route = "fused" if self.fused_supported() else ("general" if self.train_kernels_supported() else "torch")
+        if route != "fused" and not getattr(self, "_route_warned", False):
+            import warnings
+            c = self._cfg
+            warnings.warn(f"NeuMesh(W={c['W']}, geometry_dim={c['geometry_dim']}, color_dim={c['color_dim']}, ...): outside the fused inference "
+                          f"kernels' configuration (W = 256, codes <= 64, inputs <= 256 columns); inference runs on the "
+                          + ("any-width kernels of the training path (nm_train_forward) and the staged renderer" if route == "general"
+                             else "torch-op form of the field"), RuntimeWarning)
+            self._route_warned = True
+        return route
+
+    def _general_query(self, mode, xyz, view_dirs=None, want_ds=False):
+        """forward-only nm_train_forward for configurations the fused kernels refuse.  mode: 'density' | 'density_nabla' | 'forward'."""
+        lib = _lib.load()
+        q = xyz.detach().float().reshape(-1, 3).contiguous()
+        dev = q.device
+        tile = self._tile_order(xyz.shape, dev)
+        v = view_dirs.detach().float().expand_as(xyz).reshape(-1, 3).contiguous() if mode == "forward" else None
+        if tile is not None:
+            q = q[tile[0]]
+            v = None if v is None else v[tile[0]]
+        P = q.shape[0]
+        with torch.no_grad():
+            tensors = self._train_tensors()
+        desc, keep = self._train_desc(tensors)
+        t, keep_t = self.field_tables()
+        f32 = dict(dtype=torch.float32, device=dev)
+        with_nabla = 0 if mode == "density" else 1
+        sdf = torch.empty((P,), **f32)
+        nab = torch.empty((P, 3), **f32) if with_nabla else None
+        rgb = torch.empty((P, 3), **f32) if mode == "forward" else None
+        ws = torch.empty((int(lib.nm_train_workspace_bytes(C.byref(desc), P)),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nm_train_forward(C.byref(desc), self.grid_for(dev).grid.handle, C.byref(t), _lib.ptr(q), _lib.ptr(v), P, with_nabla,
+                                            _lib.ptr(sdf), _lib.ptr(nab), _lib.ptr(rgb), _lib.ptr(ws), _lib.current_stream(dev)), "nm_train_forward")
+        del ws, keep, keep_t
+        lead = xyz.shape[:-1]
+
+        def back(a, w_):
+            return None if a is None else (a if tile is None else a[tile[1]]).reshape(*lead, w_)
+        out = (back(sdf, 1), back(rgb, 3), back(nab, 3))
+        if want_ds:   # (the K-NN lists as the reference returns them: one more search, on the plain distance kernel)
+            out = out + self.compute_distance(xyz.detach())
+        return out
 
     # ------------------------------------------------------------------ fused (no-grad) paths
     _tile_cache = {}
@@ -572,35 +660,61 @@ class NeuMesh(nn.Module):
     def forward_density_only(self, xyz):
         """neumesh.py:140-145."""
         if not torch.is_grad_enabled():
-            return self._fused_density(xyz, False)[0]
-        if self.autograd_backend == "hip" and not xyz.requires_grad:
+            route = self.inference_route()
+            if route == "fused":
+                return self._fused_density(xyz, False)[0]
+            if route == "general":
+                return self._general_query("density", xyz)[0]
+            return self._density_autograd(xyz, False)[0]
+        if self._autograd_backend() == "hip" and not xyz.requires_grad:
             return _HipField.apply(self, "density", xyz, None, *self._train_tensors())
-        if self.autograd_backend == "recompute":
+        if self._autograd_backend() == "recompute":
             return _FusedField.apply(self, "density", xyz, None, *self._trainable())
         return self._density_autograd(xyz, False)[0]
 
     def forward_with_nablas(self, xyz):
         """neumesh.py:147-154."""
         if not torch.is_grad_enabled():
-            return self._fused_density(xyz, True)
-        if self.autograd_backend == "hip" and not xyz.requires_grad:
+            route = self.inference_route()
+            if route == "fused":
+                return self._fused_density(xyz, True)
+            if route == "general":
+                sdf, _, nab = self._general_query("density_nabla", xyz)
+                return sdf, nab
+            return self._density_autograd(xyz, True)[:2]
+        if self._autograd_backend() == "hip" and not xyz.requires_grad:
             return _HipField.apply(self, "density_nabla", xyz, None, *self._train_tensors())
-        if self.autograd_backend == "recompute":
+        if self._autograd_backend() == "recompute":
             return _FusedField.apply(self, "density_nabla", xyz, None, *self._trainable())
         return self._density_autograd(xyz, True)[:2]
 
     def forward(self, xyz, view_dirs, need_nablas=True, nablas_only=False, return_ds=False):
         """neumesh.py:113-138."""
-        if not torch.is_grad_enabled() and need_nablas:
-            sdf, rgb, nab, *rest = self._fused_forward(xyz, view_dirs, return_ds)
+        if not torch.is_grad_enabled() and need_nablas and self.inference_route() != "torch":
+            query = self._fused_forward if self.inference_route() == "fused" else (lambda x, v, ds_: self._general_query("forward", x, v, ds_))
+            sdf, rgb, nab, *rest = query(xyz, view_dirs, return_ds)
             out = (sdf, nab) if nablas_only else (sdf, rgb)
             return out + tuple(rest)
         if torch.is_grad_enabled() and need_nablas and not nablas_only and not return_ds:
-            if self.autograd_backend == "hip" and not xyz.requires_grad and not view_dirs.requires_grad:
+            if self._autograd_backend() == "hip" and not xyz.requires_grad and not view_dirs.requires_grad:
                 return _HipField.apply(self, "forward", xyz, view_dirs, *self._train_tensors())
-            if self.autograd_backend == "recompute":
+            if self._autograd_backend() == "recompute":
                 return _FusedField.apply(self, "forward", xyz, view_dirs.expand_as(xyz), *self._trainable())
         return self._forward_autograd(xyz, view_dirs, need_nablas, nablas_only, return_ds)
+
+    def _autograd_backend(self) -> str:
+        """`autograd_backend`, except that a configuration nm_train_validate refuses (hidden width not a multiple of 16, code widths
+        not multiples of 4, > 8 layers, > 15 bands) trains on the torch-op form instead of raising inside a query."""
+        if self.autograd_backend == "hip" and not self.train_kernels_supported():
+            if not getattr(self, "_backend_warned", False):
+                import warnings
+                warnings.warn("NeuMesh: this configuration is outside the HIP training kernels (nm_train_validate); autograd runs on the "
+                              "torch-op form of the field (autograd_backend='torch')", RuntimeWarning)
+                self._backend_warned = True
+            return "torch"
+        if self.autograd_backend == "recompute" and not self.fused_supported():
+            return "torch"
+        return self.autograd_backend
 
     # ------------------------------------------------------------------ torch-op (autograd) forms of the queries
     def _trainable(self):
@@ -629,7 +743,7 @@ class NeuMesh(nn.Module):
 
     def forward_color(self, d, view_dirs, color_features, indices=None, weights=None, nabla=None):
         """neumesh.py:156-168."""
-        if not torch.is_grad_enabled():
+        if not torch.is_grad_enabled() and self.fused_supported():
             lib = _lib.load()
             lead = d.shape[:-1]
             dd = d.detach().float().reshape(-1).contiguous()

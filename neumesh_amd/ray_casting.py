@@ -133,6 +133,7 @@ def root_finding_surface_points(surface_query_fn, rays_o: torch.Tensor, rays_d: 
             far = far.unsqueeze(0) if isinstance(far, torch.Tensor) else far
         B, N_rays = rays_o.shape[0], rays_o.shape[-2]
         native = (early_exit and isinstance(surface_query_fn, _NeuMeshSurface) and hasattr(surface_query_fn.model, "field_handle")
+                  and getattr(surface_query_fn.model, "fused_supported", lambda: True)()
                   and rays_o.is_cuda and not os.environ.get("NEUMESH_NO_SURFACE_KERNEL"))
         if native:   # the whole routine as one C call (nm_surface_hits); same outputs as the torch-op form below
             d_pred_out, pt_pred, mask, mask_sign_change = (x.reshape(B, N_rays, *x.shape[1:]) for x in _native_root_finding(
@@ -211,7 +212,7 @@ class _NeuMeshSurface:
 
     def shade(self, pts, view_dirs):
         m = self.model
-        if hasattr(m, "_fused_forward") and not torch.is_grad_enabled():
+        if hasattr(m, "_fused_forward") and not torch.is_grad_enabled() and m.fused_supported():
             sdf, rgb, nab = m._fused_forward(pts, view_dirs, False)[:3]   # one fused HIP call
             return rgb, sdf, nab
         sdf, nab = m.forward_with_nablas(pts)

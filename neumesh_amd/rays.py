@@ -72,14 +72,13 @@ def _to_device_async(t: torch.Tensor, device) -> torch.Tensor:
     return t.pin_memory().to(device, non_blocking=True)
 
 
-_LAST_SELECTION = [0, None]
-
-
 def host_selection(select_inds: torch.Tensor) -> torch.Tensor:
-    """Host copy of the pixel list get_rays returned last (it was drawn on the host: no device round trip), else .cpu()."""
-    if select_inds.device.type == "cuda" and _LAST_SELECTION[1] is not None and select_inds.data_ptr() == _LAST_SELECTION[0] \
-            and _LAST_SELECTION[1].shape == select_inds.shape:
-        return _LAST_SELECTION[1]
+    """Host copy of a pixel list get_rays returned: the fast path draws it on the host and hangs that copy on the very tensor it
+    returns (`_nm_host`; no device round trip).  Any other tensor -- the general path's, a caller's own -- is copied back.  (ADVICE r3:
+    the copy used to sit in a module global keyed by the device pointer, which the caching allocator can hand to another tensor.)"""
+    host = getattr(select_inds, "_nm_host", None)
+    if host is not None and host.shape == select_inds.shape:
+        return host
     return select_inds.cpu()
 
 
@@ -109,9 +108,10 @@ def get_rays(c2w, intrinsics, H, W, N_rays=-1, device=None):
         wsel = torch.randint(0, W, size=[N_rays])
         sel_host = hs * W + wsel
         sel = _to_device_async(sel_host, device)
-        _LAST_SELECTION[:] = [sel.data_ptr(), sel_host.expand([*prefix, N_rays])]
         ro, rd = make_rays_indexed(p.reshape(4, 4), intrinsics.reshape(4, 4), H, W, sel)
-        return ro.reshape(*prefix, N_rays, 3), rd.reshape(*prefix, N_rays, 3), sel.expand([*prefix, N_rays])
+        sel_out = sel.expand([*prefix, N_rays])
+        sel_out._nm_host = sel_host.expand([*prefix, N_rays])      # (read by host_selection; travels with this tensor object only)
+        return ro.reshape(*prefix, N_rays, 3), rd.reshape(*prefix, N_rays, 3), sel_out
     p, intrinsics = p.to(device), intrinsics.to(device)
     # general case in torch ops (same arithmetic as the reference)
     cam_loc = p[..., :3, 3]

@@ -709,6 +709,8 @@ def volume_render(rays_o, rays_d, model, obj_bounding_radius=1.0, batched=False,
     # plain NeuMesh field, inference, the rays' own directions: one C call per chunk.  Per-sample outputs and random
     # colour directions (training-side options, trainer.py:70-79,139-146) go through the staged form.
     fused = (isinstance(model, NeuMesh) or fusable_edit_model(model)) and not training and not samples_output and not random_color_direction
+    if fused and not (model if isinstance(model, NeuMesh) else model.main_model).fused_supported():
+        fused = False   # a configuration the fused kernels refuse (W != 256, ...): staged renderer over the model's methods (inference_route)
     cfg = make_render_cfg(obj_bounding_radius, N_samples, N_importance, N_upsample_iters, bounded_near_far, calc_normal,
                           white_bkgd, near_bypass, far_bypass)
     progress = None

@@ -187,7 +187,7 @@ def render_rays(field, rays_o, rays_d, cfg: RenderConfig = RenderConfig(), detai
     sdf = field.forward_density_only(pts)[..., 0]                            # :202-207
     out["d_coarse"], out["sdf_coarse"] = d, sdf
     n_new = cfg.N_importance // cfg.N_upsample_iters
-    for it in range(cfg.N_upsample_iters):                                   # :208-258
+    for it in range(cfg.N_upsample_iters if n_new > 0 else 0):               # :208-258 (no new samples: every iteration cats nothing and re-sorts sorted depths)
         d_fine, _ = upsample_step(d, sdf, it, n_new)
         pts_f = (rays_o[:, None, :] + d_fine[..., None] * rays_d[:, None, :]).astype(F32)
         sdf_f = field.forward_density_only(pts_f)[..., 0]
