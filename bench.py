@@ -53,6 +53,7 @@ FLOP_GEO = 353_280          # geometry MLP forward, per point (BASELINE.md secti
 FLOP_TANGENT = 271_360      # + forward-mode tangent (nabla)
 FLOP_COL = 500_736          # colour MLP
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+DEFAULT_PRECISION = "f16x2s"    # the library's default MLP arithmetic (neumesh_amd/neumesh.py); rows of other modes are labelled
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 PEAK_HBM_GBS = 8000.0
 KNN_BYTES_PER_QUERY = 76    # 12 in + 8*4 idx + 8*4 w  
@@ -159,6 +160,8 @@ def cpu_baseline(mesh, model, H, W, n_rays, rays0, samples=128, white_bkgd=False
     out = orender.render_rays(orc, o[sel], d[sel], cfg)
     dt = time.perf_counter() - t
     res = {"value": n_rays / dt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+           # the imported REFERENCE itself, timed where its tree exists (the build container; oracle/gen_golden.py surf, tests/golden/REPORT.json)
+           "reference_rays_per_s_build_container": 103.0, "reference_cores_build_container": 8,
            "sample": f"{n_rays} rays strided over frame 0 of the same {H}x{W}x{samples} workload, {dt:.1f} s; numpy fp32 oracle + "
                      f"scipy cKDTree candidates re-ranked with the declared fp32 arithmetic (BLAS/OpenMP threads = all cores; the same oracle as one "
                      f"single-threaded process per core reached 298 rays/s on 256 x 256 rays and 47 rays/s on 256 x 22 rays on this box type: it does not scale, so the one-process figure stands); "
@@ -392,6 +395,27 @@ def stress5_run(args, dev, world, rank, steps, warmup):
                              "measured HBM traffic (`traffic`) is far below it and the kernel is not HBM-bound in practice"}}
 
 
+# The driver keeps the first 24 keys of `config`: scalars first, in the order a reader needs them; the
+# descriptive strings (scene, work strategy, reference work per ray, parallelism ...) behind.
+CONFIG_KEY_ORDER = [
+    "workload",
+    "parity_max_abs_rgb_vs_reference", "parity_median_abs_rgb_vs_reference", "parity_frac_rays_within_1e-4", "reference_self_1ulp_frac_rays_within_1e-4",
+    "data_independent_rays_per_s", "data_independent_ms_per_frame",
+    "fp32_rays_per_s", "fp32_ms_per_frame", "fp32_mlp_tflops", "fp32_frac_of_fp32_mfma_peak",
+    "two_accumulator_f16x2_rays_per_s", "two_accumulator_f16x2_max_abs_rgb_vs_reference",
+    "f16col_rays_per_s", "f16col_max_abs_rgb_vs_reference", "f16col_frac_rays_within_1e-4",
+    "f16_single_rays_per_s", "f16_single_max_abs_rgb_vs_reference", "f16_single_frac_rays_within_1e-4",
+    "config5_frac_algorithmic_of_hbm_peak", "config5_frac_measured_hbm_of_peak", "config5_queries_per_s",
+    "train_step_ms_512_rays", "noise_scene_rays_per_s",
+]
+
+
+def order_config(cfg: dict) -> dict:
+    head = {k: cfg[k] for k in CONFIG_KEY_ORDER if k in cfg}
+    head.update({k: v for k, v in cfg.items() if k not in head})
+    return head
+
+
 def line_guard(out, extra, budget_s):
     """(emit, timer) for the ONE line of the contract.  emit(note=None) prints `out` (+ `extra` as out["extra"]) exactly once; timer is an
     unstarted threading.Timer that, when it fires after budget_s seconds, emits the line with the rows finished so far and ends the process
@@ -403,6 +427,8 @@ def line_guard(out, extra, budget_s):
             return False
         for _attempt in range(5):       # (the main thread may be adding a row at this very moment)
             try:
+                if isinstance(out.get("config"), dict):
+                    out["config"] = order_config(out["config"])
                 snap = dict(extra)
                 if note:
                     snap["_watchdog"] = note
@@ -451,8 +477,8 @@ def main():
     ap.add_argument("--V", type=int, default=140_000)
     ap.add_argument("--rayschunk", type=int, default=0,
                     help="rays per nm_render_rays call; 0 = the whole frame in one call (56 KB of workspace per ray: 36 GB for 800x800)")
-    ap.add_argument("--mlp-precision", choices=["f16x2", "f16", "fp32", "f16x2+f16col", "f16x2s", "f16x2s+f16col"], default="f16x2",
-                    help="MLP arithmetic: split-half f16 MFMA (default; 22-bit operands, fp32 accumulation), single-product f16 MFMA "
+    ap.add_argument("--mlp-precision", choices=["f16x2", "f16", "fp32", "f16x2+f16col", "f16x2s", "f16x2s+f16col"], default=DEFAULT_PRECISION,
+                    help="MLP arithmetic: split-half f16 MFMA (default 'f16x2s': one accumulator; 'f16x2': two), single-product f16 MFMA "
                          "(reduced precision, error-quantified) or fp32 MFMA")
     ap.add_argument("--cpu-rays", type=int, default=1536, help="rays of the CPU-baseline sample (0 disables)")
     ap.add_argument("--samples", type=int, default=128, help="samples per ray, half coarse / half importance (BASELINE configs[2], lego: 64)")
@@ -520,12 +546,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(steps, warmup, precision="f16x2", samples=128, normals=True, white=False, flags=0, keep_frame0=False, gather=True, hw=None,
+    def run(steps, warmup, precision=None, samples=128, normals=True, white=False, flags=0, keep_frame0=False, gather=True, hw=None,
             weight_eps=0.0, chunk=None, mdl=None):
         """warmup + `steps` timed frames of one variant; returns (elapsed s [max over ranks], profile dict, rgb of frame 0 or None,
         rays of frame 0 or None, per-rank seconds up to the end of the rank's own work)."""
         m = mdl or model
-        m.mlp_precision = precision
+        m.mlp_precision = precision or args.mlp_precision
         cfg = make_render_cfg(calc_normal=normals, N_samples=samples // 2, N_importance=samples // 2, white_bkgd=white, flags=flags, weight_eps=weight_eps)
         total = warmup + steps
         H, W = hw or (args.H, args.W)
@@ -694,11 +720,11 @@ def main():
             fixture = np.load(fx_path)
             if not (int(fixture["V"]) == args.V and int(fixture["H"]) == args.H and int(fixture["W"]) == args.W):
                 fixture = None
-        if world == 1 and not args.no_extras and not args.data_independent and args.samples == 128 and not args.no_normals and not args.white_bkgd and args.mlp_precision == "f16x2":
+        if world == 1 and not args.no_extras and not args.data_independent and args.samples == 128 and not args.no_normals and not args.white_bkgd and args.mlp_precision == DEFAULT_PRECISION:
             def short(name, **kw):
                 try:
                     e, pr, img, _, _ = run(2, 1, **kw)
-                    d, pp, a, pk, sp = mlp_summary(pr, kw.get("precision", "f16x2"))
+                    d, pp, a, pk, sp = mlp_summary(pr, kw.get("precision", args.mlp_precision))
                     nr = kw["hw"][0] * kw["hw"][1] if "hw" in kw else n_rays
                     extra[name] = {"value": nr * 2 / e, "unit": "rays/s", "ms_per_frame": e / 2 * 1e3, "steps": 2,
                                    "dominant_kernel": d, "achieved_tflops_algorithmic": a, "frac_of_pipe_peak": a / pk,
@@ -721,6 +747,19 @@ def main():
             r = short("mlp_precision_fp32 (fp32-input MFMA)", precision="fp32")
             cfgd["fp32_rays_per_s"], cfgd["fp32_ms_per_frame"] = r.get("value"), r.get("ms_per_frame")
             cfgd["fp32_mlp_tflops"], cfgd["fp32_frac_of_fp32_mfma_peak"] = r.get("achieved_tflops_algorithmic"), r.get("frac_of_pipe_peak")
+            other_acc = "f16x2" if args.mlp_precision == "f16x2s" else "f16x2s"
+            r = short(f"mlp_precision_{other_acc} (split-half operands with {'two accumulators, residual halves scaled by 2^11: the default of rounds 1-3' if other_acc == 'f16x2' else 'one accumulator'})",
+                      precision=other_acc, keep_frame0=True)
+            if other_acc == "f16x2":
+                cfgd["two_accumulator_f16x2_rays_per_s"] = r.get("value")
+                cfgd["two_accumulator_f16x2_max_abs_rgb_vs_reference"] = r.get("vs_reference_fixture", {}).get("max_abs_rgb")
+            r = short("mlp_precision_" + args.mlp_precision.split("+")[0] + "+f16col (split-half geometry network, whose error the s = 400 sigmoid amplifies, + ONE f16 product in the "
+                      "colour network, whose error is damped by the sigmoid's slope <= 1/4: error-quantified, not the default)",
+                      precision=args.mlp_precision.split("+")[0] + "+f16col", keep_frame0=True)
+            fxr = r.get("vs_reference_fixture", {})
+            cfgd["f16col_rays_per_s"], cfgd["f16col_ms_per_frame"] = r.get("value"), r.get("ms_per_frame")
+            cfgd["f16col_max_abs_rgb_vs_reference"], cfgd["f16col_frac_rays_within_1e-4"] = fxr.get("max_abs_rgb"), fxr.get("frac_rays_within_1e-4")
+            cfgd["f16col_max_abs_rgb_vs_headline_frame"] = r.get("max_abs_rgb_vs_headline_frame")
             r = short("mlp_precision_f16 (ONE f16 MFMA per product, 11-bit operands: the 'bf16 MLP'-class mode of BASELINE configs[1]; misses the 1e-4 bound, never a default)",
                       precision="f16", keep_frame0=True)
             cfgd["f16_single_rays_per_s"], cfgd["f16_single_ms_per_frame"] = r.get("value"), r.get("ms_per_frame")

@@ -283,11 +283,12 @@ class NeuMesh(nn.Module):
         self._cfg = dict(W=W, D_density=D_density, D_color=D_color, geometry_dim=geometry_dim, color_dim=color_dim,
                          multires_d=multires_d, multires_fg=multires_fg, multires_ft=multires_ft,
                          multires_view=multires_view)
-        # MLP arithmetic of the fused HIP path: "f16x2" (default: split-half f16 MFMA -- every operand
-        # carried as two fp16 halves = 22 bits, fp32 accumulation; measured as accurate as the fp32
-        # form against the reference, 2.1-2.4x faster; needs |activations| < 65504), "fp32"
-        # (fp32-input MFMA) or "f16" (single f16 product: reduced precision, error-quantified in bench.py).
-        self.mlp_precision = os.environ.get("NEUMESH_MLP_PRECISION", "f16x2")
+        # MLP arithmetic of the fused HIP path: "f16x2s" (default: split-half f16 MFMA -- every operand carried as an fp16 value plus
+        # an fp16 residual, three products into one fp32 accumulator; as accurate as the fp32 form against the reference, 2.2-2.5x
+        # faster; needs |activations| < 65504), "f16x2" (the same with the residual halves scaled by 2^11 and a second accumulator: the
+        # default of rounds 1-3, 3-7 % slower per kernel), "fp32" (fp32-input MFMA), "f16" (single f16 product: reduced precision,
+        # error-quantified in bench.py) or "...+f16col" (single product in the colour network only).
+        self.mlp_precision = os.environ.get("NEUMESH_MLP_PRECISION", "f16x2s")
         self._field = None        # FieldHandle (owner of the nm_field_t)
         self._field_key = None    # parameter versions / device / precision the packed weights were built from
         self._field_dev = None

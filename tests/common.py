@@ -7,6 +7,7 @@ import numpy as np
 
 from neumesh_amd import synthetic
 
+DEFAULT_PRECISION = os.environ.get("NEUMESH_MLP_PRECISION", "f16x2s")   # the library default (neumesh_amd/neumesh.py)
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 MODEL_CFG = dict(D_density=3, D_color=4, W=256, geometry_dim=32, color_dim=32, multires_view=4, multires_d=8,
