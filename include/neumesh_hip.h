@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 8
+#define NM_ABI_VERSION 9
 #define NM_MAX_K 32
 
 typedef struct nm_grid_s* nm_grid_t;    /* spatial index over the mesh vertices */
@@ -200,6 +200,9 @@ typedef struct nm_render_cfg {
     const float* edit_color_features; /* device [V, color_dim]  (main_editing_colorfeats) */
     int32_t edit_use_rot[4];     /* != 0: reference i lives in another frame (T_r_m_list): its colour call takes the view    */
     float edit_rot[4][9];        /* direction and the nabla rotated by this row-major 3x3 matrix (transform_direction)      */
+    const float* u_rand;         /* NULL: deterministic importance samples (sample_pdf(det=True), perturb=False).  Else device
+                                    [N_upsample_iters][R][N_importance / N_upsample_iters] uniform numbers in [0,1): the stratum
+                                    positions of sample_pdf(det=False) (rend_util.py:300-302), rows in the CALLER's ray order */
 } nm_render_cfg;
 #define NM_MAX_EDIT 4
 
@@ -217,6 +220,10 @@ typedef struct nm_render_cfg {
 #define NM_RENDER_NO_RAY_SORT 4u
 #define NM_RENDER_NO_MID_ORDER 8u
 #define NM_RENDER_EAGER_NABLAS 16u
+/*   SAMPLE_ONLY   stop after the sample placement (renderer.py:162-259, the part the reference runs under no_grad): only
+ *                 dbg->d_all (required), dbg->near_far and dbg->sdf_all are written; rgb / depth / acc / normals may be NULL.
+ *                 The training renderer places its samples with this call and queries the field with autograd afterwards. */
+#define NM_RENDER_SAMPLE_ONLY 32u
 
 int64_t nm_render_workspace_bytes(const nm_render_cfg* cfg, int64_t R);
 

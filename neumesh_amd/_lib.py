@@ -11,7 +11,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_K = 32
 
 
@@ -46,11 +46,11 @@ class RenderCfg(C.Structure):
                 ("mid_group_rays", C.c_int32), ("weight_eps", C.c_float),
                 ("n_edit", C.c_int32), ("code_dims", C.c_int32), ("edit_field", C.c_void_p * 4),
                 ("edit_mask", C.c_void_p * 4), ("edit_color_features", C.c_void_p),
-                ("edit_use_rot", C.c_int32 * 4), ("edit_rot", (C.c_float * 9) * 4)]
+                ("edit_use_rot", C.c_int32 * 4), ("edit_rot", (C.c_float * 9) * 4), ("u_rand", C.c_void_p)]
 
 
 # nm_render_cfg.flags (include/neumesh_hip.h)
-RENDER_FULL_PROBES, RENDER_NO_ZERO_SKIP, RENDER_NO_RAY_SORT, RENDER_NO_MID_ORDER, RENDER_EAGER_NABLAS = 1, 2, 4, 8, 16
+RENDER_FULL_PROBES, RENDER_NO_ZERO_SKIP, RENDER_NO_RAY_SORT, RENDER_NO_MID_ORDER, RENDER_EAGER_NABLAS, RENDER_SAMPLE_ONLY = 1, 2, 4, 8, 16, 32
 
 
 class Camera(C.Structure):

@@ -1049,8 +1049,14 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
                    void* workspace, nm_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (nm_check_field_args(f, g, t, "nm_render_rays") || nm_check_cfg(c)) return 1;
-    if (R < 0 || (R > 0 && (!rays_o || !rays_d || !rgb || !depth || !acc || !workspace))) return nm_fail("nm_render_rays: bad arguments");
-    if (c->calc_normal && !normals) return nm_fail("nm_render_rays: calc_normal set but normals is NULL");
+    const bool sample_only = (c->flags & NM_RENDER_SAMPLE_ONLY) != 0;
+    if (R < 0 || (R > 0 && (!rays_o || !rays_d || !workspace))) return nm_fail("nm_render_rays: bad arguments");
+    if (sample_only) {
+        if (R > 0 && (!dbg || !dbg->d_all)) return nm_fail("nm_render_rays: NM_RENDER_SAMPLE_ONLY needs dbg->d_all");
+    } else {
+        if (R > 0 && (!rgb || !depth || !acc)) return nm_fail("nm_render_rays: bad arguments");
+        if (c->calc_normal && !normals) return nm_fail("nm_render_rays: calc_normal set but normals is NULL");
+    }
     if (R == 0) return 0;
     if (c->code_dims) {   // the workspace was sized for these code widths: the fields rendered through it must fit
         const int gd = c->code_dims & 0xffff, cd = (c->code_dims >> 16) & 0xffff;
@@ -1061,6 +1067,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     const NmWorkspace ws = nm_carve_ws(workspace, c, R);
     const int N = c->N_samples + c->N_importance, cap = N;
     const dim3 rgrid(nm_blocks(R, 64)), rblock(64);
+    const dim3 rblock_io(NM_RAY_IO_THREADS);   // upsample / finalize: 64 rays per workgroup, every thread moves rows between HBM and LDS
 
     // processing order: rays sorted by the Morton code of their closest approach to the scene centre (see
     // nm_ray_keys_kernel); per-ray outputs (pixels, debug arrays) go back to the caller's order through perm
@@ -1123,7 +1130,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     // records through the sort permutation instead of searching a second time (same input, same
     // deterministic kernel => bit-identical record), and every later search is warm-started with
     // the cached K-th-neighbour radius of the neighbouring sample on its ray.
-    const bool want_grad = c->calc_normal != 0;
+    const bool want_grad = c->calc_normal != 0 && !sample_only;   // (the sample placement itself never needs a nabla)
     // (decided further down; needed here already) zero-weight skip active => the nablas of the N sample points are
     // evaluated AFTER the sampling passes, and only where the visibility weight is not zero (see below)
     const bool lazy_nabla_possible = want_grad && f->precision == 2 && !(dbg && (dbg->nablas_all || dbg->radiance)) &&
@@ -1165,7 +1172,8 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     if (c->N_importance > 0) {
         const int n_new = c->N_importance / c->N_upsample_iters;
         for (int it = 0; it < c->N_upsample_iters; ++it) {
-            hipLaunchKernelGGL(nm_rays_upsample_kernel, rgrid, rblock, ray_lds, stream, ws.d, ws.sdf, ws.slot, ws.radius, ws.bound, (long long)R, cap, n, pending, it, n_new, (const float*)nullptr);
+            hipLaunchKernelGGL(nm_rays_upsample_kernel, rgrid, rblock_io, ray_lds, stream, ws.d, ws.sdf, ws.slot, ws.radius, ws.bound, (long long)R, cap, n, pending, it, n_new,
+                               c->u_rand ? c->u_rand + (size_t)it * R * n_new : (const float*)nullptr, perm);
             NM_LAUNCH_CHECK();
             src.mode = 1;
             src.P = n_new;
@@ -1192,8 +1200,18 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
             pending = n_new;
         }
     }
-    hipLaunchKernelGGL(nm_rays_finalize_kernel, rgrid, rblock, ray_lds, stream, ws.d, ws.sdf, ws.slot, ws.radius, (long long)R, cap, n, pending, ws.dmid, ws.bound_mid, t->s, skip_zero ? ws.bound : (float*)nullptr, c->weight_eps > 0.f ? c->weight_eps : 0.f);
+    hipLaunchKernelGGL(nm_rays_finalize_kernel, rgrid, rblock_io, ray_lds, stream, ws.d, ws.sdf, ws.slot, ws.radius, (long long)R, cap, n, pending, ws.dmid, ws.bound_mid, t->s, skip_zero ? ws.bound : (float*)nullptr, c->weight_eps > 0.f ? c->weight_eps : 0.f);
     NM_LAUNCH_CHECK();
+    if (sample_only) {   // the caller continues from the sorted depths (training: field queries with autograd)
+        auto rows_out = [&](const float* src_, int n_, int src_stride, float* dst) {
+            hipLaunchKernelGGL(nm_rows_out_kernel, dim3(nm_blocks(R * n_, 256)), dim3(256), 0, stream, src_, (long long)R, n_, src_stride, perm, dst);
+        };
+        if (dbg->near_far) rows_out(nf, 2, 2, dbg->near_far);
+        rows_out(ws.d, N, cap, dbg->d_all);
+        if (dbg->sdf_all) rows_out(ws.sdf, N, cap, dbg->sdf_all);
+        NM_LAUNCH_CHECK();
+        return 0;
+    }
     // SDF (+ nablas) at all N sample points (renderer.py:264, 271-276): no new search and no new
     // MLP pass -- the SDF values merged above ARE forward_with_nablas(pts)[0] (same points, same
     // arithmetic), the nablas are brought into sorted order through the slot permutation.

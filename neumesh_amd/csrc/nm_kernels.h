@@ -705,6 +705,9 @@ __device__ __forceinline__ NmRayLds nm_ray_lds(float* base, int cap) {
 }
 static inline size_t nm_ray_lds_bytes(int cap) { return (size_t)2 * 64 * (cap + 1) * 4 + (size_t)64 * (cap + 4); }
 
+#ifndef NM_RAY_IO_THREADS
+#define NM_RAY_IO_THREADS 256   // threads per 64-ray workgroup of the upsample / finalize kernels (64 = the one-wave form of rounds 1-3)
+#endif
 // rows [0, n) of 64 rays: global -> LDS (slot == nullptr or first == true: identity slots).
 // The (ray, sample) elements are walked as one flat range, eight per lane in flight: written as a row loop, every
 // iteration waited for its own two loads (s_waitcnt vmcnt(0) before the LDS store) -- 128 dependent memory round trips
@@ -712,16 +715,16 @@ static inline size_t nm_ray_lds_bytes(int cap) { return (size_t)2 * 64 * (cap + 
 __device__ __forceinline__ void nm_ray_rows_load(const NmRayLds& l, const float* __restrict__ d, const float* __restrict__ sdf,
                                                  const int* __restrict__ slot, bool identity, long long r0, long long R,
                                                  int cap, int n) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, T = blockDim.x;   // (every thread of the workgroup moves data; threads 0..63 own the rays)
     const int rows = (int)((R - r0) < 64 ? (R - r0) : 64);
     const int total = rows * n;
     constexpr int U = 8;
-    for (int e0 = 0; e0 < total; e0 += 64 * U) {
+    for (int e0 = 0; e0 < total; e0 += T * U) {
         float dv[U], sv[U];
         int sl[U], rr[U], jj[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int e = e0 + u * 64 + lane;
+            const int e = e0 + u * T + lane;
             const bool ok = e < total;
             rr[u] = ok ? e / n : 0;
             jj[u] = ok ? e - rr[u] * n : -1;
@@ -743,16 +746,16 @@ __device__ __forceinline__ void nm_ray_rows_load(const NmRayLds& l, const float*
 __device__ __forceinline__ void nm_ray_rows_store(const NmRayLds& l, float* __restrict__ d, float* __restrict__ sdf,
                                                   int* __restrict__ slot, long long r0, long long R, int cap, int j0, int j1,
                                                   bool with_sdf) {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, T = blockDim.x;
     __syncthreads();
-    for (int rr = 0; rr < 64 && r0 + rr < R; ++rr) {
+    const int rows = (int)((R - r0) < 64 ? (R - r0) : 64), w = j1 - j0;
+    for (int e = lane; e < rows * w; e += T) {   // flat (ray, sample) range: a 16-sample tail still fills every lane of the workgroup
+        const int rr = e / w, j = j0 + (e - rr * w);
         const long long g = (r0 + rr) * cap;
-        for (int j = j0 + lane; j < j1; j += 64) {
-            d[g + j] = l.d[rr * l.S + j];
-            if (with_sdf) {
-                sdf[g + j] = l.s[rr * l.S + j];
-                if (slot) slot[g + j] = (int)l.slot[rr * l.SB + j];
-            }
+        d[g + j] = l.d[rr * l.S + j];
+        if (with_sdf) {
+            sdf[g + j] = l.s[rr * l.S + j];
+            if (slot) slot[g + j] = (int)l.slot[rr * l.SB + j];
         }
     }
 }
@@ -804,30 +807,36 @@ __device__ __forceinline__ bool nm_ray_merge_sorted_tail(float* d, float* sdf, i
 
 // merge the m samples appended by the previous iteration, then draw n_new new ones (+ their
 // warm-start bounds from the cached K-th-neighbour radius of the neighbouring samples).
-// Launch: 64 threads per block, nm_ray_lds_bytes(cap) dynamic LDS.
-__global__ __launch_bounds__(64) void nm_rays_upsample_kernel(float* __restrict__ d, float* __restrict__ sdf, int* __restrict__ slot,
+// Launch: 64 rays per block with 64 ... 256 threads (thread t < 64 owns ray t through the serial stages; ALL threads move the rows
+// between HBM and LDS: these kernels are bound by the few loads two 1-wave workgroups per CU keep in flight -- 3.8 GB per launch at
+// 1.75 TB/s in round 3), nm_ray_lds_bytes(cap) dynamic LDS.
+__global__ __launch_bounds__(256) void nm_rays_upsample_kernel(float* __restrict__ d, float* __restrict__ sdf, int* __restrict__ slot,
                                                               const float* __restrict__ radius, float* __restrict__ bound, long long R,
                                                               int cap, int n, int m, int it, int n_new,
-                                                              const float* __restrict__ u_rand) {
+                                                              const float* __restrict__ u_rand, const int* __restrict__ u_perm = nullptr) {
     extern __shared__ float nm_ray_smem[];
     const NmRayLds l = nm_ray_lds(nm_ray_smem, cap);
     const long long r0 = (long long)blockIdx.x * 64;
     const long long r = r0 + threadIdx.x;
     nm_ray_rows_load(l, d, sdf, slot, m == 0, r0, R, cap, n);
-    float* dr = l.d + threadIdx.x * l.S;
-    float* sr = l.s + threadIdx.x * l.S;
-    unsigned char* sl = slot ? l.slot + threadIdx.x * l.SB : nullptr;
-    if (r < R && m > 0 && !nm_ray_merge_sorted_tail<16>(dr, sr, n - m, m, sl)) nm_ray_merge(dr, sr, n - m, m, sl);
+    const bool owner = threadIdx.x < 64 && r < R;      // this thread runs a ray's serial stages
+    const int row = threadIdx.x & 63;
+    float* dr = l.d + row * l.S;
+    float* sr = l.s + row * l.S;
+    unsigned char* sl = slot ? l.slot + row * l.SB : nullptr;
+    __syncthreads();                                    // (rows loaded by other waves)
+    if (owner && m > 0 && !nm_ray_merge_sorted_tail<16>(dr, sr, n - m, m, sl)) nm_ray_merge(dr, sr, n - m, m, sl);
     if (m > 0 || slot) nm_ray_rows_store(l, d, sdf, slot, r0, R, cap, 0, n, true);  // merged rows (+ identity slots)
     __syncthreads();
-    if (r < R)
+    if (owner)
         nm_ray_upsample(dr, sr, n, it, n_new, dr + n, sr, sr, sl, (sl && radius) ? radius + r * cap : nullptr,
-                        bound ? bound + r * cap + n : nullptr, u_rand ? u_rand + r * n_new : nullptr);
+                        bound ? bound + r * cap + n : nullptr,
+                        u_rand ? u_rand + (u_perm ? (long long)u_perm[r] : r) * n_new : nullptr);   // (u_perm: the caller's index of sorted ray r)
     nm_ray_rows_store(l, d, sdf, nullptr, r0, R, cap, n, n + n_new, false);  // the new depths
 }
 
 // final merge + mid-point depths (renderer.py:255-258, :266) + warm-start bounds of the mid-points
-__global__ __launch_bounds__(64) void nm_rays_finalize_kernel(float* __restrict__ d, float* __restrict__ sdf, int* __restrict__ slot,
+__global__ __launch_bounds__(256) void nm_rays_finalize_kernel(float* __restrict__ d, float* __restrict__ sdf, int* __restrict__ slot,
                                                               const float* __restrict__ radius, long long R, int cap, int n, int m,
                                                               float* __restrict__ d_mid, float* __restrict__ bound_mid,
                                                               float s_val, float* __restrict__ w_mid, float w_eps) {
@@ -836,19 +845,22 @@ __global__ __launch_bounds__(64) void nm_rays_finalize_kernel(float* __restrict_
     const long long r0 = (long long)blockIdx.x * 64;
     const long long r = r0 + threadIdx.x;
     nm_ray_rows_load(l, d, sdf, slot, m == 0, r0, R, cap, n);
-    unsigned char* sl = slot ? l.slot + threadIdx.x * l.SB : nullptr;
-    if (r < R && m > 0 && !nm_ray_merge_sorted_tail<16>(l.d + threadIdx.x * l.S, l.s + threadIdx.x * l.S, n - m, m, sl))
-        nm_ray_merge(l.d + threadIdx.x * l.S, l.s + threadIdx.x * l.S, n - m, m, sl);
+    const bool owner = threadIdx.x < 64 && r < R;
+    const int row = threadIdx.x & 63;
+    unsigned char* sl = slot ? l.slot + row * l.SB : nullptr;
+    __syncthreads();
+    if (owner && m > 0 && !nm_ray_merge_sorted_tail<16>(l.d + row * l.S, l.s + row * l.S, n - m, m, sl))
+        nm_ray_merge(l.d + row * l.S, l.s + row * l.S, n - m, m, sl);
     if (m > 0 || slot) nm_ray_rows_store(l, d, sdf, slot, r0, R, cap, 0, n, true);
     __syncthreads();
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, T = blockDim.x;
     // visibility weights of the mid-points (in place of the sdf row), for the zero-weight skip of the
     // mid-point pass: the SAME function the compositing kernel evaluates later
     if (w_mid) {
-        if (r < R) nm_ray_weights(l.s + threadIdx.x * l.S, n, s_val, l.s + threadIdx.x * l.S);
+        if (owner) nm_ray_weights(l.s + row * l.S, n, s_val, l.s + row * l.S);
         __syncthreads();
         for (int rr = 0; rr < 64 && r0 + rr < R; ++rr)
-            for (int j = lane; j + 1 < n; j += 64) {  // (w_eps = 0: the weights themselves; else weights below it count as 0)
+            for (int j = lane; j + 1 < n; j += T) {  // (w_eps = 0: the weights themselves; else weights below it count as 0)
                 const float wv = l.s[rr * l.S + j];
                 w_mid[(r0 + rr) * cap + j] = wv < w_eps ? 0.0f : wv;
             }
@@ -858,7 +870,7 @@ __global__ __launch_bounds__(64) void nm_rays_finalize_kernel(float* __restrict_
     const bool warm = slot && radius && bound_mid;
     if (warm) {
         for (int rr = 0; rr < 64 && r0 + rr < R; ++rr)
-            for (int j = lane; j < n; j += 64) l.s[rr * l.S + j] = radius[(r0 + rr) * cap + j];
+            for (int j = lane; j < n; j += T) l.s[rr * l.S + j] = radius[(r0 + rr) * cap + j];
         __syncthreads();
     }
     for (int rr = 0; rr < 64 && r0 + rr < R; ++rr) {
@@ -866,7 +878,7 @@ __global__ __launch_bounds__(64) void nm_rays_finalize_kernel(float* __restrict_
         const float* rad = l.s + rr * l.S;
         const unsigned char* sr = l.slot + rr * l.SB;
         const long long g = (r0 + rr) * cap;
-        for (int j = lane; j + 1 < n; j += 64) {
+        for (int j = lane; j + 1 < n; j += T) {
             const float dm = nm_mul(0.5f, nm_add(dr[j + 1], dr[j]));
             d_mid[g + j] = dm;
             if (warm) bound_mid[g + j] = fminf(rad[sr[j]] + fabsf(dm - dr[j]), rad[sr[j + 1]] + fabsf(dr[j + 1] - dm));

@@ -287,7 +287,7 @@ def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed,
                 C.byref(dbg) if dbg is not None else None, _lib.ptr(ws), stream), "nm_render_rays")
         for st in side:  # join
             main.wait_stream(st)
-        del wss, ws
+        wss = ws = None   # (drop this call's references before the pools decide what to keep)
         for lane in lanes:   # (after the join: the block is handed back in the caller's stream order)
             lane.trim(WS_KEEP_BYTES)
     del keep
@@ -318,6 +318,35 @@ class _RestoreGradMode:
     def __exit__(self, *exc):
         torch.set_grad_enabled(self.mode)
         return False
+
+
+def _fused_sample(lib, model, ro, rd, cfg, perturb: bool, st):
+    """Sample placement of one ray chunk by nm_render_rays(NM_RENDER_SAMPLE_ONLY): (sorted depths d [R,N], near/far [R,2])."""
+    dev = ro.device
+    R, N = ro.shape[0], cfg.N_samples + cfg.N_importance
+    c = _lib.RenderCfg()
+    C.memmove(C.byref(c), C.byref(cfg), C.sizeof(_lib.RenderCfg))
+    c.flags = int(cfg.flags) | _lib.RENDER_SAMPLE_ONLY
+    c.n_edit = 0
+    c.code_dims = int(model._cfg["geometry_dim"]) | (int(model._cfg["color_dim"]) << 16)
+    u = None
+    if perturb and cfg.N_importance > 0:   # sample_pdf(det=False): one uniform number per new sample, per iteration (rend_util.py:300-302)
+        u = torch.rand((cfg.N_upsample_iters, R, cfg.N_importance // cfg.N_upsample_iters), dtype=torch.float32, device=dev)
+        c.u_rand = u.data_ptr()
+    d = torch.empty((R, N), dtype=torch.float32, device=dev)
+    nf = torch.empty((R, 2), dtype=torch.float32, device=dev)
+    dbg = _lib.RenderDebug()
+    dbg.d_all, dbg.near_far = d.data_ptr(), nf.data_ptr()
+    ws_bytes = int(lib.nm_render_workspace_bytes(C.byref(c), R))
+    if ws_bytes < 0:
+        _lib.check(1, "nm_render_workspace_bytes")
+    lane = _lanes_for(dev, torch.cuda.current_stream(dev).cuda_stream)[0]
+    ws = lane.get(ws_bytes, dev)
+    t, keep = model.field_tables()
+    _lib.check(lib.nm_render_rays(model.field_handle(), model.grid_for(dev).grid.handle, C.byref(t), _lib.ptr(ro), _lib.ptr(rd), R, C.byref(c),
+                                  None, None, None, None, C.byref(dbg), _lib.ptr(ws), st), "nm_render_rays(sample only)")
+    del keep, u
+    return d, nf
 
 
 def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int, netchunk: int, detailed: bool = False,
@@ -415,6 +444,12 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
             cols = [c[tp[1]] for c in cols]
         return [c.reshape(pts.shape[0], pts.shape[1], *c.shape[1:]) for c in cols]
 
+    # (fused sampler: below ~4096 rays a call is a training batch of random pixels, for which the fused kernels' 16-ray tiles and
+    #  serial probe walk are the wrong shape -- measured on a 512-ray step: 27.1 ms against 16.4 ms with the stages below, the probe
+    #  walk alone 8.3 ms -- so only dense calls take it; NEUMESH_FUSED_SAMPLER=1 / =0 force it on / off)
+    fs_env = os.environ.get("NEUMESH_FUSED_SAMPLER")
+    fused_sampler = (differentiable and trace is None and isinstance(model, NeuMesh) and model.fused_supported()
+                     and (fs_env == "1" or (fs_env != "0" and min(Rall, max(1, int(rayschunk))) >= 4096)))
     chunks = []
     rng = range(0, Rall, max(1, int(rayschunk)))
     with torch.cuda.device(dev), _RestoreGradMode():
@@ -427,6 +462,19 @@ def render_rays_staged(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: in
             torch.set_grad_enabled(False)   # sample placement never carries gradients (renderer.py:200)
             dirn, nf0 = torch.empty((R, 3), **f32), torch.empty((R, 2), **f32)
             _lib.check(lib.nm_rays_setup(_lib.ptr(ro), _lib.ptr(rd), R, cfg.obj_bounding_radius, _lib.ptr(dirn), _lib.ptr(nf0), st), "nm_rays_setup")
+            if fused_sampler:
+                # Training step of a plain NeuMesh field: the whole sample placement (renderer.py:162-259, no_grad in the reference too)
+                # is ONE C call -- nm_render_rays with NM_RENDER_SAMPLE_ONLY: first / last-hit probe walk instead of 256 searched probes
+                # per ray, chained coarse tiles, slot records, depth-bucket lists, ~25 launches instead of ~60 kernels + torch glue --
+                # returning the sorted depths (bit-identical to the stages below: the fused = staged tests) for the differentiable tail.
+                d, nf = _fused_sample(lib, model, ro, rd, cfg, perturb, st)
+                dmid = torch.zeros((R, N), **f32)
+                dmid[:, :N - 1] = 0.5 * (d[:, 1:] + d[:, :-1])       # (renderer.py:266; the arithmetic of nm_rays_finalize)
+                pts = torch.empty((R, N, 3), **f32)
+                _lib.check(lib.nm_rays_points(_lib.ptr(ro), _lib.ptr(dirn), R, N, 1, None, _lib.ptr(d), N, 0, None, _lib.ptr(pts), st), "nm_rays_points")
+                torch.set_grad_enabled(grad_was)
+                chunks.append(_composite_autograd(model, query, cfg, ro, dirn, d, dmid, pts, detailed, nf, samples_output, random_color_direction))
+                continue
             nf = nf0
             if cfg.bounded_near_far:
                 G = cfg.probe_grid

@@ -225,3 +225,38 @@ def test_painting_step_matches_reference_trainer(cuda_device, torch_mod, backend
         assert np.abs(g - f["grad." + name]).max() <= 1e-2 * max(np.abs(f["grad." + name]).max(), 1e-8) + 1e-6, name
         checked += 1
     assert checked >= 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("perturb", [False, True])
+def test_fused_sampler_of_the_training_renderer_equals_the_staged_sampler(cuda_device, torch_mod, monkeypatch, perturb):
+    """Training renderer (renderer.render_rays_staged(differentiable=True)): dense calls (>= 4096 rays) place their samples with ONE C
+    call -- nm_render_rays(NM_RENDER_SAMPLE_ONLY, ABI v9) -- instead of the stage-by-stage form.  Same depths bit for bit, hence the
+    same outputs and the same gradients to the summation order of the atomics; with perturb the uniform numbers reach the kernel
+    through nm_render_cfg.u_rand (deterministic under a fixed seed)."""
+    torch = torch_mod
+    from neumesh_amd.renderer import volume_render
+    mesh = common.scene_mesh(3000)
+    rf = common.golden("render_v3000_dtu")
+    o, d = torch.from_numpy(rf["rays_o"]).to(cuda_device), torch.from_numpy(rf["rays_d"]).to(cuda_device)
+    kw = dict(calc_normal=True, N_samples=64, N_importance=64, perturb=perturb, detailed_output=True, rayschunk=4096)
+    outs = {}
+    for name, env in (("staged", "0"), ("fused", "1"), ("fused2", "1")):
+        monkeypatch.setenv("NEUMESH_FUSED_SAMPLER", env)
+        model = common.make_model(mesh, common.scene_state(mesh), cuda_device)
+        model.train()
+        torch.manual_seed(7)
+        rgb, depth, ex = volume_render(o, d, model, **kw)
+        (rgb.sum() + 0.3 * depth.sum() + 0.1 * ex["normals_volume"].sum()).backward()
+        outs[name] = (rgb.detach(), depth.detach(), ex["d_final"].detach(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    a, b, b2 = outs["staged"], outs["fused"], outs["fused2"]
+    assert torch.equal(b[0], b2[0]) and torch.equal(b[2], b2[2])               # deterministic (same seed => same uniform numbers)
+    if not perturb:
+        assert torch.equal(a[2], b[2])                                          # the same mid-point depths, bit for bit
+        assert float((a[0] - b[0]).abs().max()) <= 1e-6 and float((a[1] - b[1]).abs().max()) <= 1e-6
+        for k in a[3]:
+            ref = a[3][k].abs().max().clamp_min(1e-12)
+            assert float((a[3][k] - b[3][k]).abs().max() / ref) <= 2e-3, k
+    else:   # other uniform numbers than the staged form draws (one [iters, R, n] block instead of per-iteration blocks): same estimator
+        assert float((a[0] - b[0]).abs().mean()) < 0.05 and bool(torch.isfinite(b[0]).all())
+        assert not torch.equal(a[2], b[2])
