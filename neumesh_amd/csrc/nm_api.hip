@@ -942,6 +942,7 @@ static int nm_ray_lds_prepare(int cap, size_t* bytes) {
     if (dev < 0 || dev >= 64 || *bytes > granted[dev]) {
         NM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nm_rays_upsample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)*bytes));
         NM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nm_rays_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)*bytes));
+        NM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nm_rays_composite_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)*bytes));
         if (dev >= 0 && dev < 64) granted[dev] = *bytes;
     }
     return 0;
@@ -1290,7 +1291,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
         NM_LAUNCH_CHECK();
     }
     // alpha + compositing (renderer.py:278, 302-333)
-    hipLaunchKernelGGL(nm_rays_composite_kernel, rgrid, rblock, 0, stream, ws.sdf, ws.d, (long long)R, cap, N, t->s, ws.rgb_mid,
+    hipLaunchKernelGGL(nm_rays_composite_kernel, rgrid, rblock_io, ray_lds, stream, ws.sdf, ws.d, (long long)R, cap, N, t->s, ws.rgb_mid,
                        c->calc_normal ? ws.nab_pts : (const float*)nullptr, c->white_bkgd, rgb, depth, acc, c->calc_normal ? normals : (float*)nullptr,
                        skip_zero ? (const float*)ws.bound : (const float*)nullptr, perm);
     NM_LAUNCH_CHECK();
@@ -1499,7 +1500,7 @@ int nm_rays_upsample(float* d, float* sdf, int64_t R, int cap, int n, int m, int
     if (R == 0) return 0;
     size_t ray_lds = 0;
     if (nm_ray_lds_prepare(cap, &ray_lds)) return 1;
-    hipLaunchKernelGGL(nm_rays_upsample_kernel, dim3(nm_blocks(R, 64)), dim3(64), ray_lds, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (float*)nullptr, (long long)R, cap, n, m, it, n_new, u);
+    hipLaunchKernelGGL(nm_rays_upsample_kernel, dim3(nm_blocks(R, 64)), dim3(NM_RAY_IO_THREADS), ray_lds, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (float*)nullptr, (long long)R, cap, n, m, it, n_new, u);
     NM_LAUNCH_CHECK();
     return 0;
 }
@@ -1509,7 +1510,7 @@ int nm_rays_finalize(float* d, float* sdf, int64_t R, int cap, int n, int m, flo
     if (R == 0) return 0;
     size_t ray_lds = 0;
     if (nm_ray_lds_prepare(cap, &ray_lds)) return 1;
-    hipLaunchKernelGGL(nm_rays_finalize_kernel, dim3(nm_blocks(R, 64)), dim3(64), ray_lds, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (long long)R, cap, n, m, d_mid, (float*)nullptr, 0.f, (float*)nullptr, 0.f);
+    hipLaunchKernelGGL(nm_rays_finalize_kernel, dim3(nm_blocks(R, 64)), dim3(NM_RAY_IO_THREADS), ray_lds, (hipStream_t)stream_, d, sdf, (int*)nullptr, (const float*)nullptr, (long long)R, cap, n, m, d_mid, (float*)nullptr, 0.f, (float*)nullptr, 0.f);
     NM_LAUNCH_CHECK();
     return 0;
 }
@@ -1518,7 +1519,9 @@ int nm_rays_composite(const float* sdf, const float* d, int64_t R, int cap, int 
                       int white_bkgd, float* rgb, float* depth, float* acc, float* normals, nm_stream_t stream_) {
     if (R < 0 || N < 2 || N > cap || N > NM_MAX_SAMPLES || (R > 0 && (!sdf || !d || !rgb_mid || !rgb || !depth || !acc))) return nm_fail("nm_rays_composite: bad arguments");
     if (R == 0) return 0;
-    hipLaunchKernelGGL(nm_rays_composite_kernel, dim3(nm_blocks(R, 64)), dim3(64), 0, (hipStream_t)stream_, sdf, d, (long long)R, cap, N, s, rgb_mid, nablas, white_bkgd, rgb, depth, acc, normals, (const float*)nullptr, (const int*)nullptr);
+    size_t ray_lds = 0;
+    if (nm_ray_lds_prepare(cap, &ray_lds)) return 1;
+    hipLaunchKernelGGL(nm_rays_composite_kernel, dim3(nm_blocks(R, 64)), dim3(NM_RAY_IO_THREADS), ray_lds, (hipStream_t)stream_, sdf, d, (long long)R, cap, N, s, rgb_mid, nablas, white_bkgd, rgb, depth, acc, normals, (const float*)nullptr, (const int*)nullptr);
     NM_LAUNCH_CHECK();
     return 0;
 }

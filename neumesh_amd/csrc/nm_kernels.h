@@ -1002,19 +1002,27 @@ __global__ void nm_rays_points_kernel(NmPointSrc src, long long Q, float* __rest
     xyz[3 * q + 2] = z;
 }
 
-__global__ void nm_rays_composite_kernel(const float* __restrict__ sdf, const float* __restrict__ d, long long R,
+__global__ __launch_bounds__(256) void nm_rays_composite_kernel(const float* __restrict__ sdf, const float* __restrict__ d, long long R,
                                          int cap, int N, float s, const float* __restrict__ rgb_mid,
                                          const float* __restrict__ nablas, int white_bkgd, float* __restrict__ rgb,
                                          float* __restrict__ depth, float* __restrict__ acc,
                                          float* __restrict__ normals, const float* __restrict__ evaluated_w,
                                          const int* __restrict__ perm) {
-    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
+    // 64 rays per workgroup; the sdf / depth rows come into LDS through every thread of the workgroup (as in the up-sampling kernels;
+    // rounds 1-3: one lane per ray reading its rows from global memory with a 256-float weight array in scratch), the weights replace
+    // the sdf row in place, thread t < 64 runs ray t's serial sums.  Launch: 64 ... 256 threads, nm_ray_lds_bytes(cap) dynamic LDS.
+    extern __shared__ float nm_ray_smem[];
+    const NmRayLds l = nm_ray_lds(nm_ray_smem, cap);
+    const long long r0 = (long long)blockIdx.x * 64;
+    const long long r = r0 + threadIdx.x;
+    nm_ray_rows_load(l, d, sdf, nullptr, true, r0, R, cap, N);
+    __syncthreads();
+    if (threadIdx.x >= 64 || r >= R) return;
     const long long ro = perm ? perm[r] : r;  // rays were processed in spatial order: results go back to the caller's order
-    float w[NM_MAX_SAMPLES];
-    nm_ray_composite(sdf + r * cap, d + r * cap, N, s, rgb_mid + r * (long long)(N - 1) * 3,
+    float* wrow = l.s + threadIdx.x * l.S;
+    nm_ray_composite(wrow, l.d + threadIdx.x * l.S, N, s, rgb_mid + r * (long long)(N - 1) * 3,
                      nablas ? nablas + r * (long long)N * 3 : nullptr, white_bkgd, rgb + 3 * ro, depth + ro, acc + ro,
-                     normals ? normals + 3 * ro : nullptr, w, evaluated_w ? evaluated_w + r * cap : nullptr);
+                     normals ? normals + 3 * ro : nullptr, wrow, evaluated_w ? evaluated_w + r * cap : nullptr);
 }
 
 // ---------------------------------------------------------- spatial processing order of the rays
