@@ -1187,9 +1187,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
             src.order = nullptr;
             const int fine_g = nm_fine_group_rays(c, n_new);
             if (fine_g > 0) {
-                int np2 = 64;
-                while (np2 < fine_g * n_new) np2 <<= 1;
-                hipLaunchKernelGGL(nm_rays_order_kernel, dim3((unsigned)((R + fine_g - 1) / fine_g)), dim3(256), (size_t)np2 * 8, stream, ws.d, (long long)R, cap, n, n_new, fine_g, np2, ws.order, (const float*)nullptr, (unsigned long long*)nullptr);
+                hipLaunchKernelGGL(nm_rays_order_kernel, dim3((unsigned)((R + fine_g - 1) / fine_g)), dim3(256), nm_order_lds_bytes(fine_g * n_new), stream, ws.d, (long long)R, cap, n, n_new, fine_g, ws.order, (const float*)nullptr, (unsigned long long*)nullptr);
                 NM_LAUNCH_CHECK();
                 src.order = ws.order;
                 src.order_rays = fine_g;
@@ -1232,9 +1230,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     NmSlotMap smap = NM_NO_SLOTS;
     long long mid_pts = (long long)R * (N - 1);
     if (use_order) {
-        int np2 = 64;
-        while (np2 < mid_g * (N - 1)) np2 <<= 1;
-        hipLaunchKernelGGL(nm_rays_order_kernel, dim3((unsigned)((R + mid_g - 1) / mid_g)), dim3(256), (size_t)np2 * 8, stream, ws.dmid, (long long)R, cap, 0, N - 1, mid_g, np2, ws.order,
+        hipLaunchKernelGGL(nm_rays_order_kernel, dim3((unsigned)((R + mid_g - 1) / mid_g)), dim3(256), nm_order_lds_bytes(mid_g * (N - 1)), stream, ws.dmid, (long long)R, cap, 0, N - 1, mid_g, ws.order,
                            skip_zero ? (const float*)ws.bound : (const float*)nullptr, skip_zero ? nm_prof_counter(NM_CNT_MID) : (unsigned long long*)nullptr);
         NM_LAUNCH_CHECK();
         src.order = ws.order;

@@ -889,103 +889,116 @@ __global__ __launch_bounds__(256) void nm_rays_finalize_kernel(float* __restrict
 // Depth-bucket assignment of the importance samples to waves.  The P new samples of a ray follow
 // the ray's own density profile, so a (16 rays x 4 samples) tile of them can stretch over the whole
 // depth range and its cooperative K-NN traversal has to cover the union of 64 far-apart searches
-// (measured on the benchmark scene: 1778 node tests + 3609 vertex visits per wave).  Sorting the
-// 64*P samples of 64 adjacent rays by depth and cutting the list into P waves gives compact
+// (measured on the benchmark scene: 1778 node tests + 3609 vertex visits per wave).  Ordering the
+// 64*P samples of 64 adjacent rays by depth and cutting the list into waves gives compact
 // footprints again (840 + 1289).  The same holds, less dramatically, for the N-1 mid-points of the
 // final sorted samples (16 rays x 4 consecutive ones: 828 + 1452; the 2032 mid-points of 16 rays
-// sorted by depth: 559 + 856).  One workgroup per group of G rays, bitonic sort in LDS on
-// (order-preserving depth key << 32 | id); which lane evaluates which sample changes no value.
-// wgt (optional, [R][cap]): samples with wgt == 0 are dropped (they sort behind the valid ones and come
-// out as padding); counter (optional): += number of kept samples.
+// ordered by depth: 559 + 856).  One workgroup per group of G rays; which lane evaluates which sample
+// changes no value.
+// Rounds 1-3 sorted the keys exactly (bitonic network in LDS, ~80 passes over up to 8192 keys: 6.5 ms per frame, the
+// largest per-ray kernel after round 4's other changes).  A wave only needs its 64 samples to be NEAR each other in depth, so
+// round 4 orders by BUCKET: 1024 depth buckets between the group's smallest and largest kept depth (finer than the vertex
+// spacing on the benchmark scene), histogram + scan + scatter, ids ascending inside a bucket (deterministic list).
+// wgt (optional, [R][cap]): samples with wgt == 0 are dropped (padding behind the kept ones); counter (optional): += kept.
+#define NM_ORDER_BUCKETS 1024
+static inline size_t nm_order_lds_bytes(int n) { return (size_t)((n + 63) & ~63) * (4 + 2) + 64; }   // depth + id per list entry
 __global__ __launch_bounds__(256) void nm_rays_order_kernel(const float* __restrict__ d, long long R, int cap, int off,
-                                                            int P, int G, int Npow2, unsigned short* __restrict__ order,
+                                                            int P, int G, unsigned short* __restrict__ order,
                                                             const float* __restrict__ wgt, unsigned long long* __restrict__ counter) {
-    extern __shared__ unsigned long long nm_sort_keys[];
-    __shared__ int nm_cnt_total;
+    extern __shared__ float nm_order_smem[];
+    __shared__ unsigned nm_hist[NM_ORDER_BUCKETS];    // counts, then running scatter positions
+    __shared__ unsigned nm_start[NM_ORDER_BUCKETS];   // first list position of each bucket
+    __shared__ unsigned nm_lo, nm_hi;                 // order-preserving keys of the smallest / largest kept depth
+    __shared__ unsigned nm_wsum[4];
     const long long grp = blockIdx.x;
     const int n = G * P, E = (n + 63) & ~63;
-    for (int i = threadIdx.x; i < Npow2; i += 256) {
+    float* dep = nm_order_smem;                                              // [E] depth of entry i (NaN bit pattern = dropped)
+    unsigned short* ids = reinterpret_cast<unsigned short*>(dep + E);        // [E] the list
+    const int t = threadIdx.x;
+    for (int b = t; b < NM_ORDER_BUCKETS; b += 256) nm_hist[b] = 0u;
+    if (t == 0) { nm_lo = 0xffffffffu; nm_hi = 0u; }
+    __syncthreads();
+    unsigned lo = 0xffffffffu, hi = 0u;
+    for (int i = t; i < E; i += 256) {
         const int rl = i / P;
         const long long r = grp * G + rl;
-        uint32_t key = 0xffffffffu;
-        unsigned id = (unsigned)i;
+        float v = __int_as_float(0x7fc00000);
         if (i < n && r < R) {
-            key = nm_float_key(d[r * cap + off + (i - rl * P)]);
-            if (wgt && wgt[r * cap + off + (i - rl * P)] == 0.0f) {  // dropped: behind every valid key, id out of range
-                key = 0xffffffffu;
-                id = 0xffffu;
+            const long long g = r * cap + off + (i - rl * P);
+            if (!(wgt && wgt[g] == 0.0f)) {
+                v = d[g];
+                if (v != v) v = 3.0e38f;                                     // (a NaN depth still gets a place: last bucket)
+                const unsigned k = nm_float_key(v);
+                lo = k < lo ? k : lo;
+                hi = k > hi ? k : hi;
             }
         }
-        nm_sort_keys[i] = ((unsigned long long)key << 32) | id;
+        dep[i] = v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned l2 = (unsigned)__shfl_xor((int)lo, o), h2 = (unsigned)__shfl_xor((int)hi, o);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((t & 63) == 0) { atomicMin(&nm_lo, lo); atomicMax(&nm_hi, hi); }
+    __syncthreads();
+    const unsigned klo = nm_lo, khi = nm_hi;
+    // bucket of a depth: linear in the order-preserving key space would follow the float spacing, so go through the values
+    const unsigned ulo = klo ^ ((klo >> 31) ? 0x80000000u : 0xffffffffu), uhi = khi ^ ((khi >> 31) ? 0x80000000u : 0xffffffffu);
+    const float dlo = __uint_as_float(ulo), dhi = klo <= khi ? __uint_as_float(uhi) : dlo;
+    const float scale = (float)NM_ORDER_BUCKETS / fmaxf(dhi - dlo, 1e-30f);
+    auto bucket = [&](float v) -> int {
+        const float x = (v - dlo) * scale;
+        return x >= (float)(NM_ORDER_BUCKETS - 1) ? NM_ORDER_BUCKETS - 1 : (x > 0.f ? (int)x : 0);
+    };
+    for (int i = t; i < E; i += 256) {
+        const float v = dep[i];
+        if (v == v) atomicAdd(&nm_hist[bucket(v)], 1u);
     }
     __syncthreads();
-    // Dropped samples (zero weight: often most of them) would only be sorted to the tail: compact the kept keys to the
-    // front first and sort just the next power of two above their number (bitonic cost ~ n log^2 n).
-    int nsort = Npow2;
-    if (wgt) {
-        __shared__ int nm_cnt[256];
-        const int per = Npow2 / 256;           // Npow2 >= 256 for every group size the callers use with a weight array
-        if (per >= 1 && per <= 32) {
-            unsigned long long mine[32];   // this thread's contiguous chunk, in registers (static indices only)
-            int c = 0;
+    {   // exclusive scan of the bucket counts: 4 buckets per thread, wave scan, 4 wave totals
+        unsigned c[4], tot = 0;
 #pragma unroll
-            for (int u = 0; u < 32; ++u) {
-                mine[u] = u < per ? nm_sort_keys[threadIdx.x * per + u] : ~0ull;
-                c += (mine[u] >> 32) != 0xffffffffull ? 1 : 0;
-            }
-            nm_cnt[threadIdx.x] = c;
-            __syncthreads();
-            if (threadIdx.x < 64) {  // exclusive scan of the 256 counts by one wave
-                int v[4], tot = 0;
-                for (int u = 0; u < 4; ++u) { v[u] = nm_cnt[threadIdx.x * 4 + u]; tot += v[u]; }
-                int incl = tot;
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int up = __shfl_up(incl, o);
-                    if ((int)threadIdx.x >= o) incl += up;
-                }
-                int run = incl - tot;
-                for (int u = 0; u < 4; ++u) { nm_cnt[threadIdx.x * 4 + u] = run; run += v[u]; }
-                if (threadIdx.x == 63) nm_cnt_total = incl;
-            }
-            __syncthreads();
-            const int kept_all = nm_cnt_total;
-            int pos = nm_cnt[threadIdx.x];     // (every chunk has been read: in-place compaction is safe)
+        for (int u = 0; u < 4; ++u) { c[u] = nm_hist[4 * t + u]; tot += c[u]; }
+        unsigned incl = tot;
 #pragma unroll
-            for (int u = 0; u < 32; ++u)
-                if ((mine[u] >> 32) != 0xffffffffull) nm_sort_keys[pos++] = mine[u];
-            nsort = 64;
-            while (nsort < kept_all) nsort <<= 1;
-            __syncthreads();
-            for (int i = kept_all + threadIdx.x; i < Npow2; i += 256) nm_sort_keys[i] = 0xffffffff0000ffffull;   // padding: behind every kept key
-            __syncthreads();
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned up = (unsigned)__shfl_up((int)incl, o);
+            if ((t & 63) >= o) incl += up;
+        }
+        if ((t & 63) == 63) nm_wsum[t >> 6] = incl;
+        __syncthreads();
+        unsigned base = incl - tot;
+        for (int w = 0; w < (t >> 6); ++w) base += nm_wsum[w];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            nm_start[4 * t + u] = base;
+            nm_hist[4 * t + u] = base;
+            base += c[u];
         }
     }
-    for (int k = 2; k <= nsort; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < nsort; i += 256) {
-                const int x = i ^ j;
-                if (x > i) {
-                    const unsigned long long a = nm_sort_keys[i], b = nm_sort_keys[x];
-                    if ((a > b) == ((i & k) == 0)) {
-                        nm_sort_keys[i] = b;
-                        nm_sort_keys[x] = a;
-                    }
-                }
+    __syncthreads();
+    const unsigned kept = nm_wsum[0] + nm_wsum[1] + nm_wsum[2] + nm_wsum[3];
+    for (int i = t; i < E; i += 256) {
+        const float v = dep[i];
+        if (v == v) ids[atomicAdd(&nm_hist[bucket(v)], 1u)] = (unsigned short)i;
+    }
+    __syncthreads();
+    // ids ascending inside a bucket (the scatter above lands in atomic order): buckets hold a handful of entries
+    for (int b = t; b < NM_ORDER_BUCKETS; b += 256) {
+        const unsigned s0 = nm_start[b], s1 = nm_hist[b];
+        if (s1 - s0 > 1u && s1 - s0 <= 64u)
+            for (unsigned a = s0 + 1; a < s1; ++a) {
+                const unsigned short x = ids[a];
+                unsigned q = a;
+                while (q > s0 && ids[q - 1] > x) { ids[q] = ids[q - 1]; --q; }
+                ids[q] = x;
             }
-            __syncthreads();
-        }
     }
-    int kept = 0;
-    for (int i = threadIdx.x; i < E; i += 256) {
-        const unsigned id = (unsigned)(nm_sort_keys[i] & 0xffffffffu);  // valid ids sort before the padding (key ties break by id)
-        const bool ok = id < (unsigned)n && (nm_sort_keys[i] >> 32) != 0xffffffffull;
-        order[grp * E + i] = ok ? (unsigned short)id : (unsigned short)0xffffu;
-        kept += ok ? 1 : 0;
-    }
-    if (counter) {
-        for (int o = 32; o > 0; o >>= 1) kept += __shfl_xor(kept, o);
-        if ((threadIdx.x & 63) == 0 && kept) atomicAdd(counter, (unsigned long long)kept);
-    }
+    __syncthreads();
+    for (int i = t; i < E; i += 256) order[grp * E + i] = (unsigned)i < kept ? ids[i] : (unsigned short)0xffffu;
+    if (counter && t == 0 && kept) atomicAdd(counter, (unsigned long long)kept);
 }
 
 // sample points of a ray batch as an explicit [R,P,3] array (staged renderer: the field is queried
