@@ -57,7 +57,7 @@ DEFAULT_PRECISION = "f16x2s"    # the library's default MLP arithmetic (neumesh_
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 PEAK_HBM_GBS = 8000.0
 KNN_BYTES_PER_QUERY = 76    # 12 in + 8*4 idx + 8*4 w  
-PROFILE_TAG = "r03"         # profiles/<tag>_pmc_*.json: rocprofv3 --pmc passes of this command (tools/pmc_*.py)
+PROFILE_TAG = "r04"         # profiles/<tag>_pmc_*.json: rocprofv3 --pmc passes of this command (tools/pmc_*.py)
 
 MODEL_CFG = dict(D_density=3, D_color=4, W=256, geometry_dim=32, color_dim=32, multires_view=4, multires_d=8,
                  multires_fg=2, multires_ft=2, enable_nablas_input=True, speed_factor=10.0, learn_indicator_weight=False)
@@ -268,7 +268,7 @@ def consumer_rows(mesh, model, dev, H, W):
     return out
 
 
-def parity_blocks(gpu_rgb_frame0, H, W, V, oracle_rgb, sel, scene="surf"):
+def parity_blocks(gpu_rgb_frame0, H, W, V, oracle_rgb, sel, scene="surf", model=None):
     """(a) vs the committed REFERENCE output of the very same rays (fixture, 1536 rays of frame 0);
     (b) vs the oracle sample rendered for the CPU baseline."""
     out = {}
@@ -285,6 +285,23 @@ def parity_blocks(gpu_rgb_frame0, H, W, V, oracle_rgb, sel, scene="surf"):
                 "rays": int(len(err)), "psnr_db": _psnr(g, f["rgb"]), "max_abs_rgb": float(err.max()),
                 "median_abs_rgb": float(np.median(err)), "frac_rays_within_1e-4": float((err <= 1e-4).mean()),
                 "reference_self_sensitivity_1ulp": {"max_abs_rgb": float(se.max()), "frac_rays_within_1e-4": float((se <= 1e-4).mean())}}
+            if model is not None and "d_all" in f.files:
+                # everything behind the sampler on the REFERENCE's own sample depths (no last-bit sensitivity of the sample placement
+                # involved): field + nablas + radiance + compositing of these 1536 rays against the reference's pixels
+                try:
+                    import torch
+                    from neumesh_amd.renderer import make_render_cfg, render_at_depths
+                    dev = next(model.parameters()).device
+                    with torch.no_grad():
+                        tail = render_at_depths(model, torch.from_numpy(f["rays_o"]).to(dev), torch.from_numpy(f["rays_d"]).to(dev),
+                                                torch.from_numpy(f["d_all"]).to(dev), make_render_cfg(calc_normal=True))
+                    et = np.abs(tail["rgb"].cpu().numpy() - f["rgb"]).max(-1)
+                    out["parity_vs_reference"]["on_reference_depths"] = {
+                        "max_abs_rgb": float(et.max()), "frac_rays_within_1e-4": float((et <= 1e-4).mean()),
+                        "max_abs_depth": float(np.abs(tail["depth_volume"].cpu().numpy() - f["depth_volume"]).max()),
+                        "max_abs_normals": float(np.abs(tail["normals_volume"].cpu().numpy() - f["normals_volume"]).max())}
+                except Exception as ex:
+                    out["parity_vs_reference"]["on_reference_depths"] = {"error": str(ex)}
     if gpu_rgb_frame0 is not None and oracle_rgb is not None:
         g = gpu_rgb_frame0[sel]
         err = np.abs(g - oracle_rgb).max(-1)
@@ -399,9 +416,10 @@ def stress5_run(args, dev, world, rank, steps, warmup):
 # descriptive strings (scene, work strategy, reference work per ray, parallelism ...) behind.
 CONFIG_KEY_ORDER = [
     "workload",
-    "parity_max_abs_rgb_vs_reference", "parity_median_abs_rgb_vs_reference", "parity_frac_rays_within_1e-4", "reference_self_1ulp_frac_rays_within_1e-4",
+    "parity_on_reference_depths_max_abs_rgb", "parity_max_abs_rgb_vs_reference", "parity_median_abs_rgb_vs_reference", "parity_frac_rays_within_1e-4",
+    "reference_self_1ulp_frac_rays_within_1e-4",
     "data_independent_rays_per_s", "data_independent_ms_per_frame",
-    "fp32_rays_per_s", "fp32_ms_per_frame", "fp32_mlp_tflops", "fp32_frac_of_fp32_mfma_peak",
+    "fp32_rays_per_s", "fp32_ms_per_frame", "fp32_frac_of_fp32_mfma_peak",
     "two_accumulator_f16x2_rays_per_s", "two_accumulator_f16x2_max_abs_rgb_vs_reference",
     "f16col_rays_per_s", "f16col_max_abs_rgb_vs_reference", "f16col_frac_rays_within_1e-4",
     "f16_single_rays_per_s", "f16_single_max_abs_rgb_vs_reference", "f16_single_frac_rays_within_1e-4",
@@ -803,15 +821,16 @@ def main():
                                                    white_bkgd=args.white_bkgd, calc_normal=not args.no_normals)
                 out["cpu_baseline"] = base
                 out["speedup_vs_cpu_baseline"] = value / base["value"]
-                out.update(parity_blocks(rgb0, args.H, args.W, args.V, orgb, sel, args.scene))
+                out.update(parity_blocks(rgb0, args.H, args.W, args.V, orgb, sel, args.scene, model=model if args.samples == 128 and not args.white_bkgd else None))
             except Exception as e:  # the baseline must never sink the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         elif world == 1:
-            out.update(parity_blocks(rgb0, args.H, args.W, args.V, None, None, args.scene))
+            out.update(parity_blocks(rgb0, args.H, args.W, args.V, None, None, args.scene, model=model if args.samples == 128 and not args.white_bkgd else None))
         if "parity_vs_reference" in out:
             pr = out["parity_vs_reference"]
             cfgd["parity_max_abs_rgb_vs_reference"], cfgd["parity_median_abs_rgb_vs_reference"] = pr["max_abs_rgb"], pr["median_abs_rgb"]
             cfgd["parity_frac_rays_within_1e-4"] = pr["frac_rays_within_1e-4"]
+            cfgd["parity_on_reference_depths_max_abs_rgb"] = pr.get("on_reference_depths", {}).get("max_abs_rgb")
             cfgd["reference_self_1ulp_frac_rays_within_1e-4"] = pr["reference_self_sensitivity_1ulp"]["frac_rays_within_1e-4"]
         if world == 1 and not args.no_extras and extra:
             try:   # BASELINE config 5 (HBM-stress of the K-NN + gather kernel), 2 steps
