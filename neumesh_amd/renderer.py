@@ -166,9 +166,11 @@ def fusable_edit_model(model) -> bool:
 
 
 def render_rays_fused(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int, detailed: bool = False,
-                      tables=None, progress=None):
+                      tables=None, progress=None, perturb: bool = False):
     """rays_o / rays_d: [R,3] device tensors.  Returns dict of [R,...] tensors.  model: a NeuMesh, or a
-    TextureEditableNeuMesh that fusable_edit_model() accepts (its blend then runs inside nm_render_rays)."""
+    TextureEditableNeuMesh that fusable_edit_model() accepts (its blend then runs inside nm_render_rays).
+    perturb: importance samples by sample_pdf(det=False) -- one torch.rand block [iterations, rays, new samples] per ray chunk, handed
+    to the kernels through nm_render_cfg.u_rand (ABI v9)."""
     main, keep = model, []
     mine = _lib.RenderCfg()   # (the edit_* pointers below are only valid during this call: the caller's struct stays untouched)
     C.memmove(C.byref(mine), C.byref(cfg), C.sizeof(_lib.RenderCfg))
@@ -193,11 +195,13 @@ def render_rays_fused(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int
     else:
         cfg.n_edit = 0
     models = [main] + (keep[2] if keep else [])
-    out = _render_rays_fused(main, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress)
+    u_blocks = {} if (perturb and cfg.N_importance > 0) else None   # (chunk start -> its numbers: drawn once, so that the fp32 re-run
+                                                                     #  below, should it happen, places the same samples)
+    out = _render_rays_fused(main, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress, u_blocks)
     if not all([m.check_fp16_range() for m in models]):   # a value left the fp16 range during this call (sticky device flag): fp32 kernels, once more
         for i, r in enumerate(keep[2] if keep else []):
             cfg.edit_field[i] = getattr(r.field_handle(), "value", r.field_handle())
-        out = _render_rays_fused(main, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress)
+        out = _render_rays_fused(main, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress, u_blocks)
     del keep
     return out
 
@@ -229,7 +233,7 @@ def _fused_chunk(lib, cfg, R: int, rayschunk: int, dev, extra_per_ray: int = 0) 
     return chunk
 
 
-def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress):
+def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress, u_blocks=None):
     lib = _lib.load()
     dev = rays_o.device
     if dev.type != "cuda":
@@ -255,6 +259,11 @@ def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed,
     if ws_bytes < 0:
         _lib.check(1, "nm_render_workspace_bytes")
     starts = list(range(0, R, chunk))
+    if u_blocks is not None:   # sample_pdf(det=False): drawn on the caller's stream BEFORE the chunk streams fork from it
+        n_new = cfg.N_importance // cfg.N_upsample_iters
+        for i in starts:
+            if i not in u_blocks:
+                u_blocks[i] = torch.rand((cfg.N_upsample_iters, min(chunk, R - i), n_new), dtype=torch.float32, device=dev)
     field, grid = model.field_handle(), model.grid_for(dev).grid.handle
     t, keep = tables if tables is not None else model.field_tables()
     with torch.cuda.device(dev):
@@ -280,6 +289,7 @@ def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed,
                 dbg.radiance = dbg_t["radiance"][i:].data_ptr()
                 dbg.nablas_all = dbg_t["nablas_all"][i:].data_ptr() if cfg.calc_normal else None
                 dbg.sdf_coarse = None
+            cfg.u_rand = u_blocks[i].data_ptr() if u_blocks is not None else None
             _lib.check(lib.nm_render_rays(
                 field, grid, C.byref(t), _lib.ptr(rays_o[i:]), _lib.ptr(rays_d[i:]), n, C.byref(cfg),
                 _lib.ptr(out["rgb"][i:]), _lib.ptr(out["depth_volume"][i:]), _lib.ptr(out["mask_volume"][i:]),
@@ -753,7 +763,7 @@ def volume_render(rays_o, rays_d, model, obj_bounding_radius=1.0, batched=False,
     if not use_view_dirs:
         raise NotImplementedError("neumesh_amd.volume_render: use_view_dirs=False (the NeuMesh colour branch always takes view "
                                   "directions: models/frameworks/neumesh/neumesh.py:239-260)")
-    training = torch.is_grad_enabled() or perturb   # trainer.py:75-81: autograd through the field + compositing
+    training = torch.is_grad_enabled()   # trainer.py:75-81: autograd through the field + compositing (perturb alone: fused, cfg.u_rand)
     # plain NeuMesh field, inference, the rays' own directions: one C call per chunk.  Per-sample outputs and random
     # colour directions (training-side options, trainer.py:70-79,139-146) go through the staged form.
     fused = (isinstance(model, NeuMesh) or fusable_edit_model(model)) and not training and not samples_output and not random_color_direction
@@ -771,7 +781,7 @@ def volume_render(rays_o, rays_d, model, obj_bounding_radius=1.0, batched=False,
     flat_o = torch.reshape(rays_o, [-1, 3]).float()
     flat_d = torch.reshape(rays_d, [-1, 3]).float()
     if fused:
-        ret = render_rays_fused(model, flat_o, flat_d, cfg, rayschunk, detailed=detailed_output, progress=progress)
+        ret = render_rays_fused(model, flat_o, flat_d, cfg, rayschunk, detailed=detailed_output, progress=progress, perturb=perturb)
     else:   # wrapper model (editing tools): per-ray stages on HIP, field through the wrapper's methods
         ret = render_rays_staged(model, flat_o, flat_d, cfg, rayschunk, netchunk, detailed=detailed_output, progress=progress,
                                  differentiable=torch.is_grad_enabled(), perturb=perturb, samples_output=samples_output,

@@ -191,6 +191,57 @@ def gen_render_fixture(tag, V, H, W, frame, seed=0, white_bkgd=False, n_samples=
     return model
 
 
+def gen_perturb_fixture(tag="render_v3000_perturb", V=3000, mlp_state=None, seed=91):
+    """The stochastic sampler pinned to the reference: renderer(..., perturb=True) draws the stratum positions of sample_pdf(det=False)
+    with torch.rand (utils/rend_util.py:298-302; nothing else depends on `perturb`, models/renderer.py:245-247).  The reference is run on the
+    render fixture's rays with torch.rand replaced by a recorded sequence of uniform numbers (numpy, seeded); the fixture holds that sequence
+    (one [R, 16] block per up-sampling iteration), the sorted depths and the rendered outputs.  The product is fed the same numbers."""
+    import torch
+    print(f"[{tag}] reference renderer with perturb=True and recorded uniform numbers, V={V}")
+    mesh = synthetic.fibonacci_blob(V)
+    model, kw, renderer, _ = harness.build_reference(mesh, seed=0, mlp_state=mlp_state)
+    rf = np.load(os.path.join(GOLDEN, "render_v3000_dtu.npz"))
+    ro, rd = torch.from_numpy(rf["rays_o"])[None], torch.from_numpy(rf["rays_d"])[None]
+    R = ro.shape[1]
+    rng = np.random.default_rng(seed)
+    drawn = []
+    orig_rand, orig_sort = torch.rand, torch.sort
+
+    def fake_rand(*size, **kwargs):
+        shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (list, tuple, torch.Size)) else tuple(size)
+        u = rng.random(shape, dtype=np.float32)
+        drawn.append(u.reshape(R, -1))
+        return torch.from_numpy(u)
+
+    sorted_d = []
+
+    def spy_sort(x, *a, **k):
+        out = orig_sort(x, *a, **k)
+        sorted_d.append(out[0].detach().clone())
+        return out
+
+    kw = dict(kw)
+    kw.update(rayschunk=R, calc_normal=True, N_samples=64, N_importance=64, perturb=True, white_bkgd=False)
+    torch.rand, torch.sort = fake_rand, spy_sort
+    try:
+        with torch.no_grad():
+            rgb, depth, ex = renderer(ro, rd, detailed_output=True, **kw)
+    finally:
+        torch.rand, torch.sort = orig_rand, orig_sort
+    assert len(drawn) == 4 and all(u.shape == (R, 16) for u in drawn) and len(sorted_d) == 4
+    # the oracle's sampler with the same numbers
+    orc = oracle_from_reference(model, mesh)
+    out = orender.render_rays(orc, rf["rays_o"], rf["rays_d"], orender.RenderConfig(calc_normal=True), detailed=True, u_rand=drawn)
+    same = np.all(out["d_all"] == sorted_d[-1][0].numpy(), axis=1)
+    e = np.abs(out["rgb"] - rgb[0].numpy()).max(-1)
+    print(f"    oracle with the recorded numbers: {int(same.sum())}/{R} rays with bit-identical depths, max |rgb| error {e.max():.2e}; "
+          f"change against the deterministic sampler: {np.abs(rgb[0].numpy() - rf['rgb']).max():.2e}")
+    _check(f"{tag}.rgb", out["rgb"], rgb[0].numpy(), 1e-4)
+    assert same.sum() >= 0.3 * R   # (the rest differ in the last bit of a few depths: the oracle's cdf is a float64 running sum rounded per element)
+    np.savez_compressed(os.path.join(GOLDEN, f"{tag}.npz"), V=np.int64(V), u=np.stack(drawn), d_all=sorted_d[-1][0].numpy(), rgb=rgb[0].numpy(),
+                        depth_volume=depth[0].numpy(), mask_volume=ex["mask_volume"][0].numpy(), normals_volume=ex["normals_volume"][0].numpy())
+
+
 def gen_grad_fixture(tag, render_tag, V, mlp_state):
     """Training-side parity: the reference renderer WITH autograd on the rays of an
     existing render fixture, a fixed scalar loss, and d loss / d parameter for every model parameter."""
@@ -868,7 +919,7 @@ def gen_rays_fixture():
                         rays_o=ro[0].numpy(), rays_d=rd[0].numpy())
 
 
-KNOWN = ("scale", "train", "surface", "surf", "surf3", "trace", "paint", "edit", "deform", "surface140k", "train140k")
+KNOWN = ("scale", "train", "surface", "surf", "surf3", "trace", "paint", "edit", "deform", "surface140k", "train140k", "perturb")
 
 
 def main():
@@ -891,6 +942,8 @@ def main():
         elif sys.argv[1] == "train140k":
             gen_train_step_fixture("train_step_v140k_surf", V=140_000, mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0, n_rays=256, HW=64,
                                    kdtree=True)
+        elif sys.argv[1] == "perturb":
+            gen_perturb_fixture("render_v3000_perturb", V=3000, mlp_state=sd)
         elif sys.argv[1] == "edit":
             gen_texture_edit_fixture("texture_edit_v3000", V=3000, mlp_state=sd)
         elif sys.argv[1] == "deform":
@@ -927,6 +980,7 @@ def main():
     gen_painting_step_fixture("painting_step_v3000", V=3000, mlp_state=sd)
     gen_texture_edit_fixture("texture_edit_v3000", V=3000, mlp_state=sd)
     gen_deform_fixture("deform_v3000", V=3000, mlp_state=sd)
+    gen_perturb_fixture("render_v3000_perturb", V=3000, mlp_state=sd)
     gen_surface_scale_fixture("surface_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd))
     gen_train_step_fixture("train_step_v140k_surf", V=140_000, mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0, n_rays=256, HW=64, kdtree=True)
     with open(os.path.join(GOLDEN, "REPORT.json"), "w") as f:

@@ -164,8 +164,10 @@ def upsample_step(d, sdf, it: int, n_new: int, u=None):
     return sample_pdf_det(d, w, n_new, u=u), w
 
 
-def render_rays(field, rays_o, rays_d, cfg: RenderConfig = RenderConfig(), detailed: bool = False) -> Dict[str, np.ndarray]:
-    """models/renderer.py:150-153 + render_rayschunk :162-350 for one chunk of R rays (B squeezed)."""
+def render_rays(field, rays_o, rays_d, cfg: RenderConfig = RenderConfig(), detailed: bool = False, u_rand=None) -> Dict[str, np.ndarray]:
+    """models/renderer.py:150-153 + render_rayschunk :162-350 for one chunk of R rays (B squeezed).
+    u_rand (optional): one [R, N_importance / N_upsample_iters] array of uniform numbers per up-sampling iteration = perturb=True with the
+    caller's numbers in place of torch.rand (sample_pdf(det=False), utils/rend_util.py:298-302)."""
     rays_o = np.ascontiguousarray(rays_o, dtype=F32).reshape(-1, 3)
     rays_d = normalize(np.ascontiguousarray(rays_d, dtype=F32).reshape(-1, 3))  # :153
     near, far = near_far_from_sphere(rays_o, rays_d, cfg.obj_bounding_radius)
@@ -188,7 +190,7 @@ def render_rays(field, rays_o, rays_d, cfg: RenderConfig = RenderConfig(), detai
     out["d_coarse"], out["sdf_coarse"] = d, sdf
     n_new = cfg.N_importance // cfg.N_upsample_iters
     for it in range(cfg.N_upsample_iters if n_new > 0 else 0):               # :208-258 (no new samples: every iteration cats nothing and re-sorts sorted depths)
-        d_fine, _ = upsample_step(d, sdf, it, n_new)
+        d_fine, _ = upsample_step(d, sdf, it, n_new, u=None if u_rand is None else u_rand[it])
         pts_f = (rays_o[:, None, :] + d_fine[..., None] * rays_d[:, None, :]).astype(F32)
         sdf_f = field.forward_density_only(pts_f)[..., 0]
         d = np.concatenate([d, d_fine], axis=-1)

@@ -1450,3 +1450,59 @@ def test_inference_for_configurations_outside_the_fused_kernels(cuda_device, tor
     for key, got, tol in (("rgb", img, 1e-4), ("depth_volume", depth, 1e-4), ("mask_volume", ex["mask_volume"], 1e-4), ("normals_volume", ex["normals_volume"], 2e-4)):
         e = np.abs(got.cpu().numpy() - out[key]).reshape(n, -1).max(-1)
         assert np.median(e) <= 2e-6 and (e > tol).sum() <= 1, (key, float(e.max()), int((e > tol).sum()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["fused", "staged", "autograd", "fused_sampler"])
+def test_stochastic_sampler_matches_reference_fixture(small, cuda_device, torch_mod, monkeypatch, path):
+    """perturb=True pinned to the reference (tests/golden/render_v3000_perturb.npz: the reference renderer fed a RECORDED sequence of
+    uniform numbers in place of torch.rand): the product gets the same numbers -- through nm_render_cfg.u_rand in the fused renderer
+    (ABI v9) and the one-call training sampler, through nm_rays_upsample in the staged renderer, with and without autograd -- and must
+    place the same samples (sample_pdf(det=False): searchsorted(right=False) on the fp32 CDF, the 1e-5 guards) and render the same frame."""
+    torch = torch_mod
+    from neumesh_amd import renderer as rmod
+    mesh, state, _ = small
+    model = common.make_model(mesh, state, cuda_device)
+    f, rf = common.golden("render_v3000_perturb"), common.golden("render_v3000_dtu")
+    u = torch.from_numpy(f["u"]).to(cuda_device)            # [4, R, 16]
+    calls = []
+
+    class FakeTorch:
+        """neumesh_amd.renderer's `torch` with rand() replaced: a [R, n] request is the next iteration's block, a [iters, R, n] request all"""
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+        def rand(self, shape, **kw):
+            shape = tuple(shape)
+            if len(shape) == 3:
+                calls.append(shape)
+                return u.clone()
+            blk = u[len(calls) % u.shape[0]].clone()
+            calls.append(shape)
+            assert tuple(blk.shape) == shape
+            return blk
+    monkeypatch.setattr(rmod, "torch", FakeTorch())
+    ro, rd = _t(rf["rays_o"], cuda_device), _t(rf["rays_d"], cuda_device)
+    kw = dict(calc_normal=True, N_samples=64, N_importance=64, perturb=True, detailed_output=True, rayschunk=4096)
+    if path == "fused":
+        with torch.no_grad():
+            rgb, depth, ex = rmod.volume_render(ro, rd, model, **kw)
+    elif path == "staged":
+        with torch.no_grad():
+            ex = rmod.render_rays_staged(model, ro, rd, rmod.make_render_cfg(calc_normal=True), 4096, 1 << 20, detailed=True, perturb=True)
+            rgb, depth = ex["rgb"], ex["depth_volume"]
+    else:
+        monkeypatch.setenv("NEUMESH_FUSED_SAMPLER", "1" if path == "fused_sampler" else "0")
+        model.train()
+        rgb, depth, ex = rmod.volume_render(ro, rd, model, **kw)
+        assert rgb.requires_grad
+    assert len(calls) == (1 if path in ("fused", "fused_sampler") else 4)
+    g = {k: v.detach().cpu().numpy() for k, v in ex.items() if torch.is_tensor(v)}
+    np.testing.assert_allclose(rgb.detach().cpu().numpy(), f["rgb"], atol=1e-4)
+    np.testing.assert_allclose(depth.detach().cpu().numpy(), f["depth_volume"], atol=1e-4)
+    np.testing.assert_allclose(g["mask_volume"], f["mask_volume"], atol=1e-4)
+    np.testing.assert_allclose(g["normals_volume"], f["normals_volume"], atol=2e-4 if path in ("autograd", "fused_sampler") else 1e-4)
+    d_mid_ref = 0.5 * (f["d_all"][:, 1:] + f["d_all"][:, :-1])
+    dd = np.abs(g["d_final"] - d_mid_ref)                                          # the reference's sample placement (a uniform number within an
+    assert (dd <= 2e-6).mean() >= 0.995 and dd.max() < 5e-3, (float(dd.max()), float((dd > 2e-6).mean()))   # ulp of a CDF edge may change bins)
+    assert np.abs(f["d_all"] - rf["d_all"]).max() > 1e-3                           # ... which is not the deterministic one
