@@ -787,6 +787,41 @@ def gen_texture_edit_fixture(tag="texture_edit_v3000", V=3000, mlp_state=None):
     np.savez_compressed(os.path.join(GOLDEN, f"{tag}.npz"), **out)
 
 
+def gen_texture_edit_scale_fixture(tag="texture_edit_v140k_surf", V=140_000, n_rays=384, mlp_state=None, s_value=400.0):
+    """Row f2 at the scale and on the scene the bench times it on: the reference's TextureEditableNeuMesh (two references with overlapping
+    painted caps and rigid transforms) over reference NeuMesh models of the SURFACE scene at V = 140 000, rendered by the reference's
+    SingleRenderer on the first `n_rays` rays of tests/golden/render_v140k_surf.npz (so that fixture's main-model pixels and 1-ulp
+    self-sensitivity of the same rays are at hand)."""
+    import torch
+    print(f"[{tag}] reference TextureEditableNeuMesh on the surface scene, V={V}, rays={n_rays}")
+    mesh = synthetic.fibonacci_blob(V)
+    main, kw, _renderer, _ = harness.build_reference(mesh, seed=0, mlp_state=mlp_state, s_value=s_value)
+    from editing.texture_neumesh.texture_neumesh import TextureEditableNeuMesh  # reference
+    from models.renderer import SingleRenderer  # reference
+    base = np.load(os.path.join(GOLDEN, "render_v140k_surf.npz"))
+    rays_o, rays_d = base["rays_o"][:n_rays], base["rays_d"][:n_rays]
+    ro, rd = torch.from_numpy(rays_o)[None], torch.from_numpy(rays_d)[None]
+    kw = dict(kw)
+    kw.update(rayschunk=n_rays, calc_normal=True, N_samples=64, N_importance=64, perturb=False, white_bkgd=False)
+    refs = []
+    for i in range(2):
+        m, *_ = harness.build_reference(mesh, seed=0, mlp_state=synthetic.reference_color_state(mlp_state, i, gain=1.5), s_value=s_value)
+        refs.append(m)
+    masks, feats, T_list = synthetic.edit_scene(mesh.vertices, 2, True)
+    wrap = TextureEditableNeuMesh(main, refs, torch.from_numpy(masks), torch.from_numpy(feats), torch.FloatTensor(np.stack(T_list)))
+    wrap.eval()
+    with _kdtree_knn(mesh), torch.no_grad():
+        img, dep, ex = SingleRenderer(wrap)(ro, rd, detailed_output=False, **kw)
+    d_main = np.abs(img[0].numpy() - base["rgb"][:n_rays]).max(-1)
+    acc = ex["mask_volume"][0].numpy()
+    print(f"    edited frame against the reference's main-model frame of the same rays: {int((d_main > 1e-2).sum())}/{n_rays} rays moved by > 1e-2 "
+          f"(max {d_main.max():.3f}); depth identical: {bool(np.array_equal(dep[0].numpy(), base['depth_volume'][:n_rays]))}; opaque rays {int((acc > 0.999).sum())}")
+    assert (d_main > 1e-2).sum() >= 0.1 * n_rays and np.array_equal(dep[0].numpy(), base["depth_volume"][:n_rays])
+    np.savez_compressed(os.path.join(GOLDEN, f"{tag}.npz"), V=np.int64(V), n_rays=np.int64(n_rays), rgb=img[0].numpy(), depth_volume=dep[0].numpy(),
+                        mask_volume=acc, normals_volume=ex["normals_volume"][0].numpy(), mask_sum=masks.sum(1).astype(np.int64),
+                        state_sha256=np.array(state_digest(mlp_state)), s=np.float32(main.forward_s().item()))
+
+
 def gen_deform_fixture(tag="deform_v3000", V=3000, mlp_state=None):
     """SURVEY 8f-2, geometry editing: the reference's deform_model (editing/render_geometry_editing.py:37-67, with kornia's
     angle_axis_to_rotation_matrix restated in oracle/refimport/stubs/kornia) run on a stretched + sheared mesh: the rotated
@@ -919,7 +954,7 @@ def gen_rays_fixture():
                         rays_o=ro[0].numpy(), rays_d=rd[0].numpy())
 
 
-KNOWN = ("scale", "train", "surface", "surf", "surf3", "trace", "paint", "edit", "deform", "surface140k", "train140k", "perturb")
+KNOWN = ("scale", "train", "surface", "surf", "surf3", "trace", "paint", "edit", "deform", "surface140k", "train140k", "perturb", "edit140k")
 
 
 def main():
@@ -942,6 +977,8 @@ def main():
         elif sys.argv[1] == "train140k":
             gen_train_step_fixture("train_step_v140k_surf", V=140_000, mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0, n_rays=256, HW=64,
                                    kdtree=True)
+        elif sys.argv[1] == "edit140k":
+            gen_texture_edit_scale_fixture("texture_edit_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd))
         elif sys.argv[1] == "perturb":
             gen_perturb_fixture("render_v3000_perturb", V=3000, mlp_state=sd)
         elif sys.argv[1] == "edit":
@@ -981,6 +1018,7 @@ def main():
     gen_texture_edit_fixture("texture_edit_v3000", V=3000, mlp_state=sd)
     gen_deform_fixture("deform_v3000", V=3000, mlp_state=sd)
     gen_perturb_fixture("render_v3000_perturb", V=3000, mlp_state=sd)
+    gen_texture_edit_scale_fixture("texture_edit_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd))
     gen_surface_scale_fixture("surface_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd))
     gen_train_step_fixture("train_step_v140k_surf", V=140_000, mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0, n_rays=256, HW=64, kdtree=True)
     with open(os.path.join(GOLDEN, "REPORT.json"), "w") as f:
