@@ -821,11 +821,11 @@ def main():
                                                    white_bkgd=args.white_bkgd, calc_normal=not args.no_normals)
                 out["cpu_baseline"] = base
                 out["speedup_vs_cpu_baseline"] = value / base["value"]
-                out.update(parity_blocks(rgb0, args.H, args.W, args.V, orgb, sel, args.scene, model=model if args.samples == 128 and not args.white_bkgd else None))
+                out.update(parity_blocks(rgb0, args.H, args.W, args.V, orgb, sel, args.scene, model=model if (args.samples == 128 and not args.white_bkgd and not args.no_extras) else None))
             except Exception as e:  # the baseline must never sink the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         elif world == 1:
-            out.update(parity_blocks(rgb0, args.H, args.W, args.V, None, None, args.scene, model=model if args.samples == 128 and not args.white_bkgd else None))
+            out.update(parity_blocks(rgb0, args.H, args.W, args.V, None, None, args.scene, model=model if (args.samples == 128 and not args.white_bkgd and not args.no_extras) else None))
         if "parity_vs_reference" in out:
             pr = out["parity_vs_reference"]
             cfgd["parity_max_abs_rgb_vs_reference"], cfgd["parity_median_abs_rgb_vs_reference"] = pr["max_abs_rgb"], pr["median_abs_rgb"]
