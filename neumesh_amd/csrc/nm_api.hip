@@ -902,7 +902,7 @@ int nm_train_backward(const nm_field_desc* d, nm_grid_t g, const nm_field_tables
 static int nm_chain_tiles(const nm_render_cfg* c, long long R, int P) {
     int vmax = c->chain_tiles > 0 ? c->chain_tiles : 32;  // upper limit (tests compare 1 against the default)
     if (vmax > 64) vmax = 64;
-    const long long tiles_p = (P + 3) / 4, total = ((R + 15) / 16) * tiles_p;
+    const long long tiles_p = (P + NM_TILE_SAMPLES - 1) / NM_TILE_SAMPLES, total = ((R + NM_TILE_RAYS - 1) / NM_TILE_RAYS) * tiles_p;
     long long ch = total / 16384;
     if (ch > vmax) ch = vmax;
     if (ch > tiles_p) ch = tiles_p;

@@ -300,6 +300,10 @@ __device__ __forceinline__ void nm_knn_wave(const NmGridView& g, float qx, float
 // 16 adjacent rays x 4 consecutive samples (the most compact 64-query footprint, see above);
 // importance samples, which are not regular in depth, go by depth buckets over 64 adjacent rays
 // (s.order); point-wise launches (mode 0) take 64 consecutive points.
+#ifndef NM_TILE_SAMPLES
+#define NM_TILE_SAMPLES 4   // consecutive samples of a ray per tile (power of two); the tile has 64 / NM_TILE_SAMPLES adjacent rays
+#endif
+#define NM_TILE_RAYS (64 / NM_TILE_SAMPLES)
 __host__ __device__ __forceinline__ int nm_chain_len(const NmPointSrc& s) { return (s.mode == 2 && !s.order && s.chain > 1) ? s.chain : 1; }
 __device__ __forceinline__ bool nm_lane_query(const NmPointSrc& s, long long Q, long long& q, long long& r, int& p, int it = 0) {
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -323,10 +327,10 @@ __device__ __forceinline__ bool nm_lane_query(const NmPointSrc& s, long long Q, 
         return id != 0xffffu && r < R;
     }
     const int chain = nm_chain_len(s);
-    const long long tiles_p = ((s.P + 3) >> 2), groups_p = (tiles_p + chain - 1) / chain;
+    const long long tiles_p = (s.P + NM_TILE_SAMPLES - 1) / NM_TILE_SAMPLES, groups_p = (tiles_p + chain - 1) / chain;
     const long long rb = wave / groups_p, sb = (wave - rb * groups_p) * chain + it;
-    r = rb * 16 + (lane >> 2);
-    p = (int)(sb * 4) + (lane & 3);
+    r = rb * NM_TILE_RAYS + lane / NM_TILE_SAMPLES;
+    p = (int)(sb * NM_TILE_SAMPLES) + (lane % NM_TILE_SAMPLES);
     q = r * s.P + p;
     return r < R && p < s.P;
 }
@@ -336,7 +340,7 @@ static inline unsigned nm_query_blocks(const NmPointSrc& s, long long Q) {
     else if (s.order) waves = ((Q / s.P + s.order_rays - 1) / s.order_rays) * (((long long)s.order_rays * s.P + 63) / 64);
     else {
         const int chain = (s.mode == 2 && s.chain > 1) ? s.chain : 1;
-        waves = ((Q / s.P + 15) / 16) * (((s.P + 3) / 4 + chain - 1) / chain);
+        waves = ((Q / s.P + NM_TILE_RAYS - 1) / NM_TILE_RAYS) * (((s.P + NM_TILE_SAMPLES - 1) / NM_TILE_SAMPLES + chain - 1) / chain);
     }
     return (unsigned)((waves + 3) / 4);  // 4 waves per 256-thread block
 }
@@ -479,13 +483,13 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_W
             init = nm_init_bound(src, r, p);
         }
         if (CHAIN) {
-            const float pr = __shfl(prev_rad, lane | 3), pd = __shfl(prev_dep, lane | 3);
+            const float pr = __shfl(prev_rad, lane | (NM_TILE_SAMPLES - 1)), pd = __shfl(prev_dep, lane | (NM_TILE_SAMPLES - 1));
             if (it > 0 && pr < NM_INF_F) {
                 const float b = (pr + fabsf(dep - pd)) * 1.0001f + 1e-5f;
                 init = fminf(init, b * b);
             }
             // ... and from the exact distances to that sample's 8 neighbours (usually far tighter)
-            const float nb = nm_bound_from_neighbours_lds(verts, prev_bi, threadIdx.x | 3, it > 0 && active, x, y, z);
+            const float nb = nm_bound_from_neighbours_lds(verts, prev_bi, threadIdx.x | (NM_TILE_SAMPLES - 1), it > 0 && active, x, y, z);
             init = fminf(init, nb);
         }
         float bd[8], wk[8], gr[3];
