@@ -301,7 +301,10 @@ __device__ __forceinline__ void nm_knn_wave(const NmGridView& g, float qx, float
 // importance samples, which are not regular in depth, go by depth buckets over 64 adjacent rays
 // (s.order); point-wise launches (mode 0) take 64 consecutive points.
 #ifndef NM_TILE_SAMPLES
-#define NM_TILE_SAMPLES 4   // consecutive samples of a ray per tile (power of two); the tile has 64 / NM_TILE_SAMPLES adjacent rays
+// consecutive samples of a ray per tile (power of two); the tile has 64 / NM_TILE_SAMPLES adjacent rays.  Measured on the 800x800 frame
+// (round 4, K-NN kernels per frame): 16 rays x 4 samples 83.6 ms, 32 x 2 84.5 ms, 64 x 1 (an 8x8 pixel patch at one depth, chained
+// along the ray) 85.7 ms -- the coarse passes are not footprint-bound, the shape stays.
+#define NM_TILE_SAMPLES 4
 #endif
 #define NM_TILE_RAYS (64 / NM_TILE_SAMPLES)
 __host__ __device__ __forceinline__ int nm_chain_len(const NmPointSrc& s) { return (s.mode == 2 && !s.order && s.chain > 1) ? s.chain : 1; }
