@@ -677,6 +677,91 @@ def gen_train_step_fixture(tag="train_step_v3000", V=3000, mlp_state=None, s_val
     np.savez_compressed(os.path.join(GOLDEN, "trainer_compute_loss.npz"), **cl)
 
 
+TRAIN_LOOP_LR = {"default": 5.0e-4, "color_features": 2.0e-3, "views_linears": 1.0e-4}
+TRAIN_LOOP_SCHED = {"type": "warmupcosine", "warmup_steps": 2}
+
+
+def gen_train_loop_fixture(tag="train_loop_v3000", V=3000, mlp_state=None, n_iters=6, num_iters=8, n_rays=96, HW=40):
+    """The reference's OWN optimisation loop body, several iterations in a row: train.train (train.py:165-195: Trainer.forward, mean of
+    every loss, zero_grad, backward, optimizer.step, scheduler.step(it)) with the optimizer of models/base.py:578-616 (dict learning rates:
+    a per-parameter group, a per-module group, the rest) and the scheduler of models/base.py:648-676 (warmupcosine as a LambdaLR, stepped
+    with the iteration number), ln_s frozen as train.py:290 does.  Records every iteration's losses and learning rates, the parameter
+    groups, and the parameters after the last iteration.  Only change: Trainer.forward's device argument (default "cuda") is "cpu"."""
+    import torch
+    print(f"[{tag}] reference train.train x {n_iters} (get_optimizer / get_scheduler of models/base.py), V={V}")
+    mesh = synthetic.fibonacci_blob(V)
+    lw = {"img": 1.0, "mask": 0.1, "eikonal": 0.1, "distill_density": 1.0, "distill_color": 1.0, "indicator_reg": 0.001}
+    model, kw_test, renderer, args = harness.build_reference(
+        mesh, seed=0, mlp_state=mlp_state,
+        overrides={"training:loss_weights": dict(lw), "data:N_rays": n_rays, "training:lr": dict(TRAIN_LOOP_LR),
+                   "training:scheduler": dict(TRAIN_LOOP_SCHED), "training:num_iters": num_iters})
+    import train as ref_train                                  # reference train.py
+    from models.base import get_optimizer, get_scheduler       # reference
+    from models.trainer import Trainer                         # reference
+    trainer = Trainer(model, loss_weights=dict(lw), teacher_model=None, device_ids=["cpu"])
+    trainer.teacher_model = StubTeacher()
+
+    class OnCpu:   # train.train calls trainer.forward without a device (default "cuda")
+        def forward(self, *a, **k):
+            return trainer.forward(*a, device="cpu", **k)
+
+    H = W = HW
+    K = synthetic.pinhole_intrinsics(H, W, 1.0)
+    rng = np.random.default_rng(41)
+    gt_rgb = rng.uniform(0, 1, (1, H * W, 3)).astype(np.float32)
+    obj_mask = rng.uniform(0, 1, (1, H * W)) > 0.4
+    poses = np.stack([synthetic.orbit_pose(3 + 2 * i) for i in range(n_iters)]).astype(np.float32)
+    kw = dict(kw_test)
+    kw.pop("rayschunk", None)
+    kw.update(perturb=False, calc_normal=True, H=H, W=W, N_samples=64, N_importance=64, rayschunk=4096)
+    ground_truth = {"rgb": torch.from_numpy(gt_rgb)}
+    model.train()
+    model.ln_s.requires_grad = args.training.setdefault("required_grad_lns", False)   # train.py:290
+    names = {id(p_): n for n, p_ in model.named_parameters()}
+    optimizer = get_optimizer(args, model)
+    groups = [[names[id(p_)] for p_ in g["params"]] for g in optimizer.param_groups]
+    scheduler = get_scheduler(args, optimizer, last_epoch=-1)
+    start = {n: p_.detach().numpy().copy() for n, p_ in model.named_parameters()}
+    out = {"group_lr0": np.array([g["initial_lr"] for g in optimizer.param_groups], np.float64)}
+    for gi, g in enumerate(groups):
+        out[f"group{gi}.names"] = np.array(g)
+    lr_used, lr_next, sel = [], [], []
+    loss_keys = None
+    loss_rows = []
+    for it in range(n_iters):
+        torch.manual_seed(500 + it)
+        mi = {"intrinsics": torch.from_numpy(K)[None], "c2w": torch.from_numpy(poses[it])[None], "object_mask": torch.from_numpy(obj_mask)}
+        lr_used.append([g["lr"] for g in optimizer.param_groups])
+        losses, extras = ref_train.train(args, it, None, mi, ground_truth, kw, OnCpu(), optimizer, scheduler)
+        lr_next.append([g["lr"] for g in optimizer.param_groups])
+        if loss_keys is None:
+            loss_keys = sorted(losses)
+        loss_rows.append([float(losses[k].item()) for k in loss_keys])
+        sel.append(extras["select_inds"].numpy())
+        print(f"    it {it}: lr {lr_used[-1]} total {float(losses['total']):.6f} img {float(losses['loss_img']):.6f}")
+    out.update(loss_keys=np.array(loss_keys), losses=np.array(loss_rows, np.float64), lr_used=np.array(lr_used, np.float64),
+               lr_next=np.array(lr_next, np.float64), select_inds=np.stack(sel))
+    for n, p_ in model.named_parameters():
+        end = p_.detach().numpy()
+        d = (end.astype(np.float64) - start[n].astype(np.float64))
+        out["dnorm." + n] = np.float64(np.linalg.norm(d))
+        out["dmax." + n] = np.float64(np.abs(d).max())
+        if end.ndim == 2 and end.size > 4096:
+            rows = np.sort(np.argsort(-np.linalg.norm(d, axis=1))[:48]).astype(np.int32)
+            out["rows." + n] = rows
+            out["end." + n] = end[rows].copy()
+            out["start." + n] = start[n][rows].copy()
+        else:
+            out["end." + n] = end.copy()
+            out["start." + n] = start[n].copy()
+    print("    largest parameter moves:", sorted(((float(v), k[5:]) for k, v in out.items() if k.startswith("dmax.")), reverse=True)[:4])
+    np.savez_compressed(os.path.join(GOLDEN, f"{tag}.npz"), V=np.int64(V), H=np.int64(H), W=np.int64(W), poses=poses, intrinsics=K,
+                        gt_rgb=gt_rgb, object_mask=obj_mask, N_rays=np.int64(n_rays), n_iters=np.int64(n_iters), num_iters=np.int64(num_iters),
+                        lr_keys=np.array(sorted(TRAIN_LOOP_LR)), lr_vals=np.array([TRAIN_LOOP_LR[k] for k in sorted(TRAIN_LOOP_LR)], np.float64),
+                        warmup_steps=np.int64(TRAIN_LOOP_SCHED["warmup_steps"]),
+                        loss_weight_keys=np.array(sorted(lw)), loss_weight_vals=np.array([lw[k] for k in sorted(lw)], np.float32), **out)
+
+
 def gen_surface_fixture(tag="surface_v3000", V=3000, mlp_state=None):
     """models/ray_casting.py of the reference (dead code there: imported nowhere) run on the reference's NeuMesh
     field: root_finding_surface_points (256 proposals + 8 secant steps) and sphere_tracing_surface_points, on the
@@ -954,7 +1039,7 @@ def gen_rays_fixture():
                         rays_o=ro[0].numpy(), rays_d=rd[0].numpy())
 
 
-KNOWN = ("scale", "train", "surface", "surf", "surf3", "trace", "paint", "edit", "deform", "surface140k", "train140k", "perturb", "edit140k")
+KNOWN = ("scale", "train", "surface", "surf", "surf3", "trace", "paint", "edit", "deform", "surface140k", "train140k", "perturb", "edit140k", "trainloop")
 
 
 def main():
@@ -989,6 +1074,8 @@ def main():
             gen_painting_step_fixture("painting_step_v3000", V=3000, mlp_state=sd)
         elif sys.argv[1] == "train":
             gen_train_step_fixture("train_step_v3000", V=3000, mlp_state=sd)
+        elif sys.argv[1] == "trainloop":
+            gen_train_loop_fixture("train_loop_v3000", V=3000, mlp_state=sd)
         else:
             gen_surface_fixture("surface_v3000", V=3000, mlp_state=sd)
         rp = os.path.join(GOLDEN, "REPORT.json")

@@ -342,3 +342,41 @@ def test_bench_line_guard_prints_the_line_when_the_main_thread_stalls():
              "assert emit() and not emit()\n") % ROOT
     r2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120)
     assert r2.returncode == 0 and r2.stdout.count("{") == 1, r2.stdout + r2.stderr[-300:]
+
+
+def test_training_loop_fixture_schedule_and_groups():
+    """CPU side of tests/test_gpu_train_loop.py: the loop helpers restated there (models/base.py:578-676, train.py:165-195) reproduce the
+    learning rates the reference's get_optimizer / get_scheduler produced (tests/golden/train_loop_v3000.npz), on a module tree with
+    the reference's names; the fixture's trajectory has the shape the GPU test relies on (two zero-rate iterations, then moves)."""
+    import warnings
+    import torch
+    import test_gpu_train_loop as tl
+    f = common.golden("train_loop_v3000")
+
+    class Tree(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ln_s = torch.nn.Parameter(torch.zeros(1))
+            self.color_features = torch.nn.Parameter(torch.zeros(4, 2))
+            self.views_linears = torch.nn.ModuleList([torch.nn.Linear(2, 2), torch.nn.Linear(2, 2)])
+            self.pts_linears = torch.nn.ModuleList([torch.nn.Linear(2, 2)])
+
+    m = Tree()
+    lr = {str(k): float(v) for k, v in zip(f["lr_keys"], f["lr_vals"])}
+    opt = tl.grouped_adam(torch, {"default": lr["default"], "color_features": lr["color_features"], "views_linears": lr["views_linears"]}, m)
+    names = {id(p): n for n, p in m.named_parameters()}
+    got = [[names[id(p)] for p in g["params"]] for g in opt.param_groups]
+    assert got == [["ln_s", "pts_linears.0.weight", "pts_linears.0.bias"], ["color_features"],
+                   ["views_linears.0.weight", "views_linears.0.bias", "views_linears.1.weight", "views_linears.1.bias"]]
+    assert np.allclose([g["lr"] for g in opt.param_groups], f["group_lr0"])
+    sched = tl.warmup_cosine(torch, opt, int(f["num_iters"]), int(f["warmup_steps"]))
+    for it in range(int(f["n_iters"])):
+        assert np.allclose([g["lr"] for g in opt.param_groups], f["lr_used"][it], rtol=1e-12, atol=0)
+        opt.step()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sched.step(it)
+        assert np.allclose([g["lr"] for g in opt.param_groups], f["lr_next"][it], rtol=1e-12, atol=0)
+    assert (f["lr_used"][:2] == 0).all() and (f["lr_used"][2:] > 0).all()
+    assert float(f["dmax.color_features"]) > 1e-3 and float(f["dmax.ln_s"]) == 0.0
+    assert [str(n) for n in f["group1.names"]] == ["color_features"] and all(str(n).startswith("views_linears.") for n in f["group2.names"])
