@@ -18,6 +18,8 @@ including, through the second derivative of the nabla graph, the eikonal term.
 """
 from __future__ import annotations
 
+import os
+import warnings
 from collections import OrderedDict
 
 import torch
@@ -54,6 +56,24 @@ def _cfg(args, group, key):
     return g[key] if isinstance(g, dict) else getattr(g, key)
 
 
+_POOL_WARNED = False
+
+
+def _warn_spinning_cpu_pool():
+    """A training step is ~430 launches from one host thread.  torch's CPU back end runs large tensor operations on an OpenMP pool whose
+    workers spin-wait after every parallel region; one such operation per iteration in the training process (the default collate's
+    torch.stack of an image, train.py:246-260 runs the loader with num_workers=0) slows the launching thread: 16.6 -> 33-50 ms per step
+    measured with 128 threads (tools/train_two_stream_stress.py).  Said once; nothing is changed on the caller's behalf."""
+    global _POOL_WARNED
+    if _POOL_WARNED or torch.get_num_threads() <= 16 or os.environ.get("OMP_WAIT_POLICY", "").lower() == "passive":
+        return
+    _POOL_WARNED = True
+    warnings.warn(f"neumesh_amd.Trainer: {torch.get_num_threads()} intra-op CPU threads with an active wait policy -- large CPU tensor operations "
+                  "in the training process (collate, image copies) make their workers spin beside the launch-bound training step (measured 2-3x "
+                  "slower steps). Set OMP_WAIT_POLICY=passive or OMP_NUM_THREADS=8, or call torch.set_num_threads(8); see INTEGRATION.md.",
+                  stacklevel=3)
+
+
 class Trainer(nn.Module):
     def __init__(self, model, loss_weights, teacher_model=None, device_ids=[0], batched=True):
         super().__init__()
@@ -67,6 +87,7 @@ class Trainer(nn.Module):
             teacher_model.to(self.device).eval()
         self.loss_weights = loss_weights
         self.density_loss = DensityLoss()
+        _warn_spinning_cpu_pool()
 
     # ------------------------------------------------------------------ one training step
     def forward(self, args, indices, model_input, ground_truth, render_kwargs_train: dict, it: int,
