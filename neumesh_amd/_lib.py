@@ -131,6 +131,8 @@ TESTING_SIGNATURES = {
     "nm_grid_create_host": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.POINTER(_P)]),
     "nm_grid_debug_export": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64]),
     "nm_selfcheck_field": (C.c_int, [_P, _P, C.POINTER(FieldTables), _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P]),
+    "nm_debug_gemm": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int,
+                                C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
 }
 
 _lib = None
@@ -183,7 +185,7 @@ def load_testing():
     """The -DNM_TESTING library (product exports + test hooks) as its own ctypes object: for the tests of the hooks and the
     measurement tools.  Handles are NOT interchangeable with those of the product library (two copies of the library state)."""
     import torch  # noqa: F401  (its libamdhip64 first, see load())
-    path = _build.build_testing()
+    path = os.environ.get("NEUMESH_HIP_TESTING_LIB") or _build.build_testing()   # override: experiments only
     lib = C.CDLL(path)
     for name, (res, args) in {**SIGNATURES, **TESTING_SIGNATURES}.items():
         fn = getattr(lib, name)

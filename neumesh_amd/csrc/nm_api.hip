@@ -727,7 +727,7 @@ static NmGemm nm_t_gemm(const float* A, long long lda, int a_kc, const float* B,
 
 #define NM_T_GEMM(g, split)                                                            \
     do {                                                                               \
-        if (nm_gemm_launch((g), (split), stream)) return nm_fail("nm_train: GEMM launch failed"); \
+        if (nm_gemm_launch((g), (split), stream, d->mlp_precision != 0)) return nm_fail("nm_train: GEMM launch failed"); \
     } while (0)
 
 int nm_train_forward(const nm_field_desc* d, nm_grid_t g, const nm_field_tables* t, const float* xyz, const float* view_dirs,
@@ -1699,6 +1699,34 @@ int nm_selfcheck_field(nm_field_t f, nm_grid_t g, const nm_field_tables* t, cons
                        view_dirs, 1, (long long)P, rgb, valu_tmp, NM_NO_SLOTS);
     NM_LAUNCH_CHECK();
     return 0;
+}
+
+// The training path's GEMM alone (nm_gemm.h): C[M,N] = A . B (+ bias / relu as in NmGemm), operand layouts as there.  mode 0 = fp32 pipe,
+// 1 = bf16 x 3.  iters > 0: launched that many times, *avg_ms = mean launch time (events on `stream`).
+int nm_debug_gemm(const float* A, int64_t lda, int a_kc, const float* B, int64_t ldb, int b_kc, float* C, int64_t ldc, int64_t M, int64_t N,
+                  int64_t K, const float* bias, int relu, int split_k, int accumulate, int mode, int iters, float* avg_ms, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    NmGemm g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.a_kc = a_kc; g.B = B; g.ldb = ldb; g.b_kc = b_kc; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.bias_rows = bias ? M : 0; g.relu = relu; g.atomic = accumulate;
+    hipEvent_t e0, e1;
+    NM_HIP(hipEventCreate(&e0));
+    NM_HIP(hipEventCreate(&e1));
+    int rc = 0;
+    for (int i = (iters > 1 ? -1 : 0); i < (iters > 0 ? iters : 1) && !rc; ++i) {
+        if (i == 0) hipEventRecord(e0, stream);
+        rc = nm_gemm_launch(g, split_k, stream, mode != 0);
+    }
+    hipEventRecord(e1, stream);
+    if (!rc && avg_ms) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = nm_fail("nm_debug_gemm: events failed");
+        *avg_ms = ms / (float)(iters > 0 ? iters : 1);
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return rc ? nm_fail("nm_debug_gemm: launch failed") : 0;
 }
 #endif  // NM_TESTING
 

@@ -155,9 +155,164 @@ __global__ __launch_bounds__(256) void nm_gemm_kernel(NmGemm g) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------ bf16 x 3 form
+// The same product on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16: 16 x the fp32 pipe's rate) with fp32-grade operands: every fp32
+// value is cut into three bf16 pieces BY TRUNCATION, a = b1 + b2 + b3 EXACTLY (8 + 8 + 8 significant bits; bf16 has fp32's exponent, so
+// cotangents of 1e-9 need no scaling -- an f16 split would), and a product is the six piece products of weight >= 2^-16,
+//   a.b = a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a3 b1 + a2 b2)      [dropped: a2 b3, a3 b2, a3 b3 <= 2^-24 |a||b|, fp32's own rounding]
+// accumulated in fp32 by the matrix pipe.  6 MFMAs per 16-k step and tile instead of 8 on a pipe that is 16 x faster.
+// Operand tiles are split ONCE, when they are stashed: three bf16 planes [row][k] per operand in LDS (row stride 24 halves = 48 bytes:
+// conflict-free ds_read_b128), K in steps of 16, two buffers: 73.7 KB, two workgroups per CU as before.
+#define NM_G3_BK 16
+#define NM_G3_LS 24
+#ifndef NM_G3_DEPTH
+#define NM_G3_DEPTH 4                  // steps whose operand rows are in flight
+#endif
+#ifndef NM_G3_THREADS
+#define NM_G3_THREADS 512              // 256: wave = 64 x 64 of the tile (2 x 2 MFMA tiles); 512: wave = 32 x 64 (1 x 2), four waves per SIMD
+#endif
+#define NM_G3_NV (512 / NM_G3_THREADS)   // float4 per thread and operand tile (128 rows x 16 k / 4 / threads)
+#define NM_G3_RT (512 / NM_G3_THREADS)   // row tiles (32 rows) per wave
+typedef __bf16 nm_bf8 __attribute__((ext_vector_type(8)));
+
+// (loads are UNCONDITIONAL, from a clamped address, and masked when they are consumed: a branch around a load, or a select right behind
+//  it, makes the compiler drain the whole ring of loads in flight)
+template <bool KC>
+__device__ __forceinline__ void nm_g3_fetch(const float* __restrict__ base, long long ld, long long r0, long long R, long long k0,
+                                            long long K1, float4 (&v)[NM_G3_NV], int t) {
+#pragma unroll
+    for (int i = 0; i < NM_G3_NV; ++i) {
+        long long r, k;
+        if (KC) { r = r0 + t / 4 + (NM_G3_THREADS / 4) * i; k = k0 + (t % 4) * 4; }
+        else { k = k0 + (t % NM_G3_BK); r = r0 + (t / NM_G3_BK) * 4 + (NM_G3_THREADS / 4) * i; }
+        const bool ok = r < R && k < K1;
+        const long long rc = ok ? r : 0, kc = ok ? k : 0;
+        v[i] = *reinterpret_cast<const float4*>(KC ? base + rc * ld + kc : base + kc * ld + rc);
+    }
+}
+
+// one value -> the upper halves of three floats whose sum is the value
+__device__ __forceinline__ void nm_g3_cut(float a, unsigned& b1, unsigned& b2, unsigned& b3) {
+    b1 = __float_as_uint(a) & 0xffff0000u;
+    const float r1 = a - __uint_as_float(b1);          // exact
+    b2 = __float_as_uint(r1) & 0xffff0000u;
+    b3 = __float_as_uint(r1 - __uint_as_float(b2));    // exact, <= 8 significant bits: its upper half holds all of it
+}
+
+template <bool KC>
+__device__ __forceinline__ void nm_g3_stash(unsigned short* __restrict__ tile, int plane_stride, const float4 (&v)[NM_G3_NV], int t,
+                                            long long r0, long long R, long long k0, long long K1) {
+#pragma unroll
+    for (int i = 0; i < NM_G3_NV; ++i) {
+        const int row = KC ? t / 4 + (NM_G3_THREADS / 4) * i : (t / NM_G3_BK) * 4 + (NM_G3_THREADS / 4) * i;
+        const int col = KC ? (t % 4) * 4 : t % NM_G3_BK;
+        const bool ok = r0 + row < R && k0 + col < K1;
+        unsigned b[3][4];
+        nm_g3_cut(ok ? v[i].x : 0.f, b[0][0], b[1][0], b[2][0]);
+        nm_g3_cut(ok ? v[i].y : 0.f, b[0][1], b[1][1], b[2][1]);
+        nm_g3_cut(ok ? v[i].z : 0.f, b[0][2], b[1][2], b[2][2]);
+        nm_g3_cut(ok ? v[i].w : 0.f, b[0][3], b[1][3], b[2][3]);
+        unsigned short* p = tile + row * NM_G3_LS + col;
+        if (KC) {   // 4 consecutive k of one row: one 8-byte store per plane
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                *reinterpret_cast<uint2*>(p + q * plane_stride) = make_uint2((b[q][0] >> 16) | (b[q][1] & 0xffff0000u), (b[q][2] >> 16) | (b[q][3] & 0xffff0000u));
+        } else {    // 4 consecutive rows at one k
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[q * plane_stride + e * NM_G3_LS] = (unsigned short)(b[q][e] >> 16);
+        }
+    }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(NM_G3_THREADS) void nm_gemm3_kernel(NmGemm g) {
+    constexpr int PLANE = (NM_G_BM + NM_G_BN) * NM_G3_LS;     // halves per plane: A rows, then B rows
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][3 * PLANE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, h = lane >> 5;
+    const int wm = wave % (128 / (32 * NM_G3_RT)), wn = wave / (128 / (32 * NM_G3_RT));   // the wave's rows 32 RT wm .., columns 64 wn ..
+    const long long m0 = (long long)blockIdx.x * NM_G_BM, n0 = (long long)blockIdx.y * NM_G_BN;
+    const long long kb = (long long)blockIdx.z * g.kchunk;
+    const long long ke = (kb + g.kchunk < g.K) ? kb + g.kchunk : g.K;
+    if (kb >= ke) return;
+    nm_gacc acc[NM_G3_RT][2];
+#pragma unroll
+    for (int i = 0; i < NM_G3_RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // The matrix-pipe time of a 16-k step (0.2 - 0.4 us per wave) is far below the latency of a global load, so the operand rows of the next
+    // NM_G3_DEPTH steps are kept in flight in a ring of registers (one step ahead, as in the fp32 kernel, left this kernel at the load
+    // latency per step).
+    float4 ra[NM_G3_DEPTH][NM_G3_NV], rb[NM_G3_DEPTH][NM_G3_NV];
+#pragma unroll
+    for (int u = 0; u < NM_G3_DEPTH; ++u) {
+        nm_g3_fetch<AKC>(g.A, g.lda, m0, g.M, kb + u * NM_G3_BK, ke, ra[u], t);
+        nm_g3_fetch<BKC>(g.B, g.ldb, n0, g.N, kb + u * NM_G3_BK, ke, rb[u], t);
+    }
+    int buf = 0;
+    for (long long k = kb; k < ke; k += NM_G3_DEPTH * NM_G3_BK) {
+#pragma unroll
+        for (int u = 0; u < NM_G3_DEPTH; ++u) {
+            const long long ks = k + u * NM_G3_BK;
+            if (ks >= ke) break;   // (uniform)
+            // a wave that is a step ahead writes the OTHER buffer; nobody is two steps ahead (one barrier per step)
+            nm_g3_stash<AKC>(lds[buf], PLANE, ra[u], t, m0, g.M, ks, ke);
+            nm_g3_stash<BKC>(lds[buf] + NM_G_BM * NM_G3_LS, PLANE, rb[u], t, n0, g.N, ks, ke);
+            nm_g3_fetch<AKC>(g.A, g.lda, m0, g.M, ks + NM_G3_DEPTH * NM_G3_BK, ke, ra[u], t);
+            nm_g3_fetch<BKC>(g.B, g.ldb, n0, g.N, ks + NM_G3_DEPTH * NM_G3_BK, ke, rb[u], t);
+            __syncthreads();
+            const unsigned short* as = lds[buf] + (32 * NM_G3_RT * wm + li) * NM_G3_LS + 8 * h;
+            const unsigned short* bs = lds[buf] + (NM_G_BM + 64 * wn + li) * NM_G3_LS + 8 * h;
+            nm_bf8 a[NM_G3_RT][3], b[2][3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int i = 0; i < NM_G3_RT; ++i) a[i][q] = *reinterpret_cast<const nm_bf8*>(as + q * PLANE + 32 * i * NM_G3_LS);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j][q] = *reinterpret_cast<const nm_bf8*>(bs + q * PLANE + 32 * j * NM_G3_LS);
+            }
+#pragma unroll
+            for (int i = 0; i < NM_G3_RT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {   // small terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], acc[i][j], 0, 0, 0);
+                }
+            buf ^= 1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NM_G3_RT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long n = n0 + 64 * wn + 32 * j + li;
+            if (n >= g.N) continue;
+            const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + 32 * NM_G3_RT * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= g.M) continue;
+                float c = acc[i][j][r];
+                if (m < g.bias_rows) c += bv;
+                if (g.relu) c = fmaxf(c, 0.f);
+                if (g.mask && !(g.mask[m * g.ldmask + n] > 0.f)) c = 0.f;
+                if (g.atomic) atomicAdd(g.C + m * g.ldc + n, c);
+                else g.C[m * g.ldc + n] = c;
+            }
+        }
+}
+
 // C = A . B with the operand layouts of `g`; split_k > 1: K is cut into that many chunks whose partial products are added
 // atomically (C must have been zeroed, or hold the value to accumulate onto).
-static inline int nm_gemm_launch(NmGemm g, int split_k, hipStream_t stream) {
+// bf16x3 = true: the bf16 x 3 kernel above; false: the fp32-pipe kernel.
+static inline int nm_gemm_launch(NmGemm g, int split_k, hipStream_t stream, bool bf16x3 = false) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return 0;
     long long chunks = split_k > 1 ? split_k : 1;
     long long kchunk = ((g.K + chunks - 1) / chunks + NM_G_BK - 1) / NM_G_BK * NM_G_BK;
@@ -165,6 +320,13 @@ static inline int nm_gemm_launch(NmGemm g, int split_k, hipStream_t stream) {
     g.kchunk = kchunk;
     if (chunks > 1) g.atomic = 1;
     const dim3 grid((unsigned)((g.M + NM_G_BM - 1) / NM_G_BM), (unsigned)((g.N + NM_G_BN - 1) / NM_G_BN), (unsigned)chunks);
+    if (bf16x3) {
+        if (g.a_kc && g.b_kc) hipLaunchKernelGGL((nm_gemm3_kernel<true, true>), grid, dim3(NM_G3_THREADS), 0, stream, g);
+        else if (g.a_kc && !g.b_kc) hipLaunchKernelGGL((nm_gemm3_kernel<true, false>), grid, dim3(NM_G3_THREADS), 0, stream, g);
+        else if (!g.a_kc && g.b_kc) hipLaunchKernelGGL((nm_gemm3_kernel<false, true>), grid, dim3(NM_G3_THREADS), 0, stream, g);
+        else hipLaunchKernelGGL((nm_gemm3_kernel<false, false>), grid, dim3(NM_G3_THREADS), 0, stream, g);
+        return hipGetLastError() == hipSuccess ? 0 : 1;
+    }
     if (g.a_kc && g.b_kc) hipLaunchKernelGGL((nm_gemm_kernel<true, true>), grid, dim3(256), 0, stream, g);
     else if (g.a_kc && !g.b_kc) hipLaunchKernelGGL((nm_gemm_kernel<true, false>), grid, dim3(256), 0, stream, g);
     else if (!g.a_kc && g.b_kc) hipLaunchKernelGGL((nm_gemm_kernel<false, true>), grid, dim3(256), 0, stream, g);

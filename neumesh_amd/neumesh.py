@@ -641,7 +641,10 @@ class NeuMesh(nn.Module):
         d.W, d.D_density, d.D_color = c["W"], ng, nc
         d.geometry_dim, d.color_dim = c["geometry_dim"], c["color_dim"]
         d.multires_d, d.multires_fg, d.multires_ft, d.multires_view = c["multires_d"], c["multires_fg"], c["multires_ft"], c["multires_view"]
-        d.enable_nablas_input, d.use_view_dirs, d.mlp_precision = int(self.enable_nablas_input), 1, 0
+        # mlp_precision of a training descriptor selects the GEMMs of nm_train_*: 0 = the fp32 matrix pipe, anything else = the bf16 x 3 form
+        # (fp32-grade operands cut into three bf16 pieces, csrc/nm_gemm.h); NEUMESH_TRAIN_GEMM=fp32 keeps the fp32 pipe for A/B
+        fp32_gemm = self.mlp_precision == "fp32" or os.environ.get("NEUMESH_TRAIN_GEMM", "bf16x3") == "fp32"
+        d.enable_nablas_input, d.use_view_dirs, d.mlp_precision = int(self.enable_nablas_input), 1, (0 if fp32_gemm else 6)
         for l in range(ng):
             d.geo_weight[l], d.geo_bias[l] = gw[l].data_ptr(), gb[l].data_ptr()
         d.density_weight, d.density_bias = gw[ng].data_ptr(), gb[ng].data_ptr()

@@ -256,7 +256,11 @@ def test_fused_sampler_of_the_training_renderer_equals_the_staged_sampler(cuda_d
         assert float((a[0] - b[0]).abs().max()) <= 1e-6 and float((a[1] - b[1]).abs().max()) <= 1e-6
         for k in a[3]:
             ref = a[3][k].abs().max().clamp_min(1e-12)
-            assert float((a[3][k] - b[3][k]).abs().max() / ref) <= 2e-3, k
+            # (scalar parameters of the density head sum the per-sample cotangents of ALL samples -- large terms of both signs, s = 200 --
+            #  with atomic adds whose order changes from run to run: density_linear.bias moves by 1-3e-3 of its value between two runs
+            #  of the SAME path; the 1 % of the reference-trainer test applies to them)
+            tol = 1e-2 if a[3][k].numel() == 1 else 2e-3
+            assert float((a[3][k] - b[3][k]).abs().max() / ref) <= tol, k
     else:   # other uniform numbers than the staged form draws (one [iters, R, n] block instead of per-iteration blocks): same estimator
         assert float((a[0] - b[0]).abs().mean()) < 0.05 and bool(torch.isfinite(b[0]).all())
         assert not torch.equal(a[2], b[2])
