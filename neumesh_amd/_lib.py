@@ -131,6 +131,7 @@ TESTING_SIGNATURES = {
     "nm_grid_create_host": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.POINTER(_P)]),
     "nm_grid_debug_export": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64]),
     "nm_selfcheck_field": (C.c_int, [_P, _P, C.POINTER(FieldTables), _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P]),
+    "nm_debug_last_deferred": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
     "nm_debug_gemm": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int,
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
 }

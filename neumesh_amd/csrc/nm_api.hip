@@ -106,6 +106,10 @@ struct nm_grid_s {
     int occupied = 0;
     float origin[3] = {0, 0, 0};
     float root_size = 0;
+    // scratch of the deferred queries of small launches (nm_launch_distance), one block per stream that used this handle: stream-ordered
+    // reuse is safe, two streams never share a block
+    std::mutex defer_mu;
+    std::vector<std::pair<hipStream_t, void*>> defer_scratch;
 };
 
 struct nm_field_s {
@@ -236,6 +240,8 @@ int nm_grid_destroy(nm_grid_t g) {
     if (!g) return 0;
     for (void* m : g->mem)
         if (m) hipFree(m);
+    for (auto& e : g->defer_scratch)
+        if (e.second) hipFree(e.second);
     delete g;
     return 0;
 }
@@ -297,11 +303,54 @@ struct NmGather {  // optional gather-interpolation outputs of the distance kern
 };
 static const NmGather NM_NO_GATHER = {nullptr, 0, nullptr, nullptr, 0, nullptr};
 
-static int nm_launch_distance(nm_grid_t g, const NmPointSrc& src, long long Q, const float* indicator, float w1,
+// Small launches: waves that exceed a work budget hand their queries on, each to a wave of its own (nm_kernels.h, "the deferred queries of a
+// small launch").  NM_DEFER_MAX_Q: above it a launch is throughput-bound and its tail does not matter.  Budget in work units (24 per node
+// test, 7 per staged vertex).  NEUMESH_KNN_BUDGET overrides it (0 = never defer; 1 = defer everything the list has room for: the tests'
+// way to run queries through the second path).
+#define NM_DEFER_MAX_Q (1ll << 18)
+#define NM_DEFER_CAP 8192
+#ifndef NM_DEFER_BUDGET
+#define NM_DEFER_BUDGET 30000
+#endif
+static size_t nm_defer_bytes() { return 256 + (size_t)NM_DEFER_CAP * (4 + 4 + 64 * 8 * sizeof(unsigned long long)); }
+static void* nm_defer_block(nm_grid_t g, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g->defer_mu);
+    for (auto& e : g->defer_scratch)
+        if (e.first == stream) return e.second;
+    void* p = nullptr;
+    if (hipMalloc(&p, nm_defer_bytes()) != hipSuccess) return nullptr;
+    g->defer_scratch.emplace_back(stream, p);
+    return p;
+}
+
+static int nm_launch_distance(nm_grid_t g, const NmPointSrc& src_in, long long Q, const float* indicator, float w1,
                               float* ds, int* idx32, long long* idx64, float* w, float* grad, hipStream_t stream,
                               float* radius = nullptr, NmGather ga = NM_NO_GATHER, bool counted = false) {
     if (Q <= 0) return 0;
     NmProfScope prof(NM_K_DISTANCE, counted ? 0 : Q, stream, counted ? NM_CNT_MID : NM_CNT_NONE);
+    NmPointSrc src = src_in;
+    src.budget = 0;
+    if (Q <= NM_DEFER_MAX_Q && nm_chain_len(src) <= 1 && !src.order) {
+        const char* e = getenv("NEUMESH_KNN_BUDGET");
+        const int budget = e ? atoi(e) : NM_DEFER_BUDGET;
+        char* blk = budget > 0 ? (char*)nm_defer_block(g, stream) : nullptr;
+        if (blk) {
+            src.budget = budget;
+            src.defer_cap = NM_DEFER_CAP;
+            src.defer_count = (int*)blk;
+            src.defer_list = (int*)(blk + 256);
+            src.defer_bound2 = (float*)(blk + 256 + (size_t)NM_DEFER_CAP * 4);
+            unsigned long long* keys = (unsigned long long*)(blk + 256 + (size_t)NM_DEFER_CAP * 8);
+            NM_HIP(hipMemsetAsync(src.defer_count, 0, 4, stream));
+            hipLaunchKernelGGL((nm_distance_kernel<false, true>), dim3(nm_query_blocks(src, Q)), dim3(256), 0, stream, g->view, src, Q, g->verts,
+                               indicator, w1, ds, idx32, idx64, w, grad, radius, ga.geo_table, ga.gdim, ga.fg, ga.col_table, ga.cdim, ga.ft);
+            hipLaunchKernelGGL(nm_knn_subtree_kernel, dim3(1536), dim3(256), 0, stream, g->view, src, src.defer_bound2, keys);
+            hipLaunchKernelGGL(nm_distance_deferred_kernel, dim3(NM_DEFER_CAP / 256), dim3(256), 0, stream, g->view, src, keys, g->verts, indicator, w1,
+                               ds, idx32, idx64, w, grad, radius, ga.geo_table, ga.gdim, ga.fg, ga.col_table, ga.cdim, ga.ft);
+            NM_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (nm_chain_len(src) > 1)
         hipLaunchKernelGGL(nm_distance_kernel<true>, dim3(nm_query_blocks(src, Q)), dim3(256), 0, stream, g->view, src, Q, g->verts,
                            indicator, w1, ds, idx32, idx64, w, grad, radius, ga.geo_table, ga.gdim, ga.fg, ga.col_table, ga.cdim, ga.ft);
@@ -1698,6 +1747,23 @@ int nm_selfcheck_field(nm_field_t f, nm_grid_t g, const nm_field_tables* t, cons
     hipLaunchKernelGGL((nm_col_mlp_kernel<true>), dim3(nm_blocks(P, 64)), dim3(256), 0, stream, f->col, s.ft, s.ds, nabla,
                        view_dirs, 1, (long long)P, rgb, valu_tmp, NM_NO_SLOTS);
     NM_LAUNCH_CHECK();
+    return 0;
+}
+
+// number of queries the last small launch on (g, stream) handed to the exhaustive kernels (synchronises the stream)
+int nm_debug_last_deferred(nm_grid_t g, int* count, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!g || !count) return nm_fail("nm_debug_last_deferred: NULL argument");
+    *count = -1;
+    void* blk = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g->defer_mu);
+        for (auto& e : g->defer_scratch)
+            if (e.first == stream) blk = e.second;
+    }
+    if (!blk) return 0;
+    NM_HIP(hipMemcpyAsync(count, blk, sizeof(int), hipMemcpyDeviceToHost, stream));
+    NM_HIP(hipStreamSynchronize(stream));
     return 0;
 }
 

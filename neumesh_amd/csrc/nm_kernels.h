@@ -46,6 +46,13 @@ struct NmPointSrc {
     const int* ray_index;
     // mode 2 (optional): the P samples are proposals p_off .. p_off + P - 1 of a p_total-point linspace (0 = the P points themselves)
     int p_off, p_total;
+    // small launches (nm_distance_kernel<false, true>): a wave whose traversal has spent `budget` work units (24 per node test, 7 per
+    // staged vertex) gives up and appends its queries to defer_list (defer_count entries so far, room for defer_cap); they are
+    // finished by a wave of their own each (nm_knn_split_kernel, nm_distance_deferred_kernel below).  budget = 0: never.
+    int budget, defer_cap;
+    int* defer_count;
+    int* defer_list;
+    float* defer_bound2;
 };
 
 #ifdef NM_TESTING
@@ -159,9 +166,12 @@ __device__ __forceinline__ float nm_wave_max(float v) {
     return v;
 }
 
-template <int K>
-__device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float qx, float qy, float qz, bool active,
-                                                     float rx, float ry, float rz, unsigned long long (&kk)[K], float init_d2) {
+// BUDGET: returns true (nothing in kk is final then) as soon as the traversal has spent `budget` work units -- see NmPointSrc.budget.
+// SUB: the traversal covers the subtree of the INTERNAL node `top` only (never climbs above it).
+template <int K, bool BUDGET = false, bool SUB = false>
+__device__ __forceinline__ bool nm_knn_search_packet(const NmGridView& g, float qx, float qy, float qz, bool active,
+                                                     float rx, float ry, float rz, unsigned long long (&kk)[K], float init_d2, int budget = 0,
+                                                     uint32_t top = 0u) {
     const unsigned long long act_mask = __builtin_amdgcn_ballot_w64(active);
     // ONE query in the wave (small point-wise launches, NmPointSrc.lanes = 1): the leaf scans turn from "this lane's query against
     // every staged vertex, one at a time" into "the query against THIS lane's vertex" -- 64 candidate distances per step, the few
@@ -181,11 +191,13 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
     for (int k = 0; k < K; ++k) kk[k] = nm_key(init_d2, 0x7fffffff);
     const uint32_t kx = (uint32_t)NM_UNIFORM_I(nm_float_key(rx)), ky = (uint32_t)NM_UNIFORM_I(nm_float_key(ry)),
                    kz = (uint32_t)NM_UNIFORM_I(nm_float_key(rz));  // wave-uniform, kept in SGPRs
-    NmNode rec = nm_ld_node(g.nodes, 0);
+    NmNode rec = nm_ld_node(g.nodes, SUB ? top : 0u);
     int first = nm_octant(rec, kx, ky, kz);
     unsigned om = nm_visit_mask(rec, first);
     bool at_root = true;
+    int work = 0;   // (BUDGET only; wave-uniform)
     for (;;) {
+        if (BUDGET && work > budget) return true;
         // The list passes through one opaque definition per trip.  Without it the compiler carries the eight keys in TWO
         // register sets (one for this loop, one for the leaf scan below) and copies one into the other at every node --
         // 16 v_mov_b64 per trip, a quarter of the traversal's vector instructions; with it 8 (K-NN per frame 109 -> 103 ms).
@@ -196,7 +208,7 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
             const int c_prev = (int)((rec.info >> 8) & 7u);
             const uint32_t parent = rec.parent;
             rec = nm_ld_node(g.nodes, parent);
-            at_root = parent == 0u;
+            at_root = parent == (SUB ? top : 0u);
             first = nm_octant(rec, kx, ky, kz);
             om = nm_visit_mask(rec, first) & ~((2u << nm_perm(c_prev ^ first)) - 1u);
             continue;
@@ -206,6 +218,7 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
         const int c = first ^ nm_perm(i);
         const uint32_t mask = rec.info & 255u;
         const NmNode crec = nm_ld_node(g.nodes, rec.first + (uint32_t)__popc(mask & ((1u << c) - 1u)));
+        if (BUDGET) work += 24;
         // every lane tests (an inactive lane's result is masked out of the vote): no divergent region around the bound,
         // and the vote is a scalar compare of the mask (__any() goes through a vector select + compare)
         const bool nearer = nm_box_lb2(crec, qx, qy, qz) <= nm_key_d2(kk[K - 1]);
@@ -220,6 +233,7 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
             float4* stage = nm_leaf_lds[threadIdx.x >> 6];
             const nm_f32x2 qyz = {qy, qz};          // with __launch_bounds__(NM_KNN_BLOCK) and launched with that block size
             const uint32_t ln = threadIdx.x & 63u;
+            if (BUDGET) work += single ? 8 * (int)((crec.end - crec.first + 63u) >> 6) : 7 * (int)(crec.end - crec.first);
             if (single) {
                 for (uint32_t p0 = crec.first; p0 < crec.end; p0 += 64) {
                     const uint32_t cnt = crec.end - p0 < 64u ? crec.end - p0 : 64u;
@@ -269,18 +283,19 @@ __device__ __forceinline__ void nm_knn_search_packet(const NmGridView& g, float 
             om = nm_visit_mask(rec, first);
         }
     }
+    return false;
 }
 
 // K-NN for the calling lane's query; the whole wave must call it (inactive lanes pass
 // active=false).  Picks the cooperative traversal when the wave's queries are compact
 // (bounding-box extent below a fraction of the root cube), lane-private traversals otherwise
 // (e.g. randomly scattered points through the point-wise API).
-template <int K>
-__device__ __forceinline__ void nm_knn_wave(const NmGridView& g, float qx, float qy, float qz, bool active,
-                                            unsigned long long (&kk)[K], float init_d2 = NM_INF_F) {
+template <int K, bool BUDGET = false>
+__device__ __forceinline__ bool nm_knn_wave(const NmGridView& g, float qx, float qy, float qz, bool active,
+                                            unsigned long long (&kk)[K], float init_d2 = NM_INF_F, int budget = 0) {
     // inactive lanes borrow an active lane's position so that they do not stretch the box
     const unsigned long long act = __ballot(active);
-    if (act == 0ull) return;
+    if (act == 0ull) return false;
     const int src = __builtin_ctzll(act);
     const float sx = __shfl(qx, src), sy = __shfl(qy, src), sz = __shfl(qz, src);
     const float px = active ? qx : sx, py = active ? qy : sy, pz = active ? qz : sz;
@@ -289,11 +304,12 @@ __device__ __forceinline__ void nm_knn_wave(const NmGridView& g, float qx, float
     const float loz = nm_wave_min(pz), hiz = nm_wave_max(pz);
     const float ext = nm_uniform_f(fmaxf(fmaxf(hix - lox, hiy - loy), hiz - loz));
     if (ext <= g.coop_extent) {
-        nm_knn_search_packet<K>(g, qx, qy, qz, active, nm_uniform_f(0.5f * (lox + hix)), nm_uniform_f(0.5f * (loy + hiy)),
-                                nm_uniform_f(0.5f * (loz + hiz)), kk, init_d2);
+        return nm_knn_search_packet<K, BUDGET>(g, qx, qy, qz, active, nm_uniform_f(0.5f * (lox + hix)), nm_uniform_f(0.5f * (loy + hiy)),
+                                               nm_uniform_f(0.5f * (loz + hiz)), kk, init_d2, budget);
     } else if (active) {
         nm_knn_search<K>(g, qx, qy, qz, kk, nullptr, init_d2);
     }
+    return false;
 }
 
 // Lane -> query mapping.  Ray-structured launches (modes 1, 2) give each wave a tile of
@@ -454,7 +470,53 @@ __global__ __launch_bounds__(NM_KNN_BLOCK) void nm_knn_kernel(NmGridView g, NmPo
 // (models/mesh_grid.py:88-144 fused; nothing of shape [Q,8,3] is ever materialised)
 // Any output pointer may be null.  ds_out is indexed by q (compact).
 // Occupancy: NM_KNN_WAVES / NM_KNN_WAVES_CHAIN above.
-template <bool CHAIN>
+// The outputs of one query from its neighbour keys (everything behind the search): shared by the traversal kernels and by the kernel
+// that answers the deferred queries.  The whole wave calls it (the code gather is wave-cooperative).
+__device__ __forceinline__ void nm_distance_finish(const NmPointSrc& src, bool active, long long q, long long r, int p, float x, float y, float z,
+                                                   const float (&bd)[8], int (&bi)[8],   // squared distances, indices (bi is scratch afterwards)
+                                                   const float* __restrict__ verts, const float* __restrict__ indicator, float w1,
+                                                   float* __restrict__ ds_out, int* __restrict__ idx32_out, long long* __restrict__ idx64_out,
+                                                   float* __restrict__ w_out, float* __restrict__ grad_out, float* __restrict__ radius_out,
+                                                   const float* __restrict__ geo_table, int gdim, float* __restrict__ fg_out,
+                                                   const float* __restrict__ col_table, int cdim, float* __restrict__ ft_out) {
+    float wk[8], gr[3];
+    float ds = 0.f;
+    long long o = 0;
+    if (active) {
+        ds = nm_projected_distance8(x, y, z, bd, bi, verts, indicator, w1, wk, grad_out ? gr : nullptr);
+        o = (src.order && src.out_by_slot) ? (long long)blockIdx.x * blockDim.x + threadIdx.x : nm_out_index(src, q, r, p);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            bi[k] = 0;
+            wk[k] = 0.f;
+        }
+    }
+    if (fg_out) nm_gather_interp(geo_table, gdim, bi, wk, active, o, fg_out);
+    if (ft_out) nm_gather_interp(col_table, cdim, bi, wk, active, o, ft_out);
+    if (!active) return;
+    if (ds_out) ds_out[o] = ds;
+    if (radius_out) radius_out[o] = nm_sqrt(bd[7]);
+    if (idx32_out) {
+        *reinterpret_cast<int4*>(idx32_out + o * 8) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+        *reinterpret_cast<int4*>(idx32_out + o * 8 + 4) = make_int4(bi[4], bi[5], bi[6], bi[7]);
+    }
+    if (idx64_out) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) idx64_out[o * 8 + k] = (long long)bi[k];
+    }
+    if (w_out) {
+        *reinterpret_cast<float4*>(w_out + o * 8) = make_float4(wk[0], wk[1], wk[2], wk[3]);
+        *reinterpret_cast<float4*>(w_out + o * 8 + 4) = make_float4(wk[4], wk[5], wk[6], wk[7]);
+    }
+    if (grad_out) {
+        grad_out[o * 3] = gr[0];
+        grad_out[o * 3 + 1] = gr[1];
+        grad_out[o * 3 + 2] = gr[2];
+    }
+}
+
+template <bool CHAIN, bool BUDGET = false>
 __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_WAVES) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
                                                           const float* __restrict__ verts,
                                                           const float* __restrict__ indicator, float w1,
@@ -495,16 +557,36 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_W
             const float nb = nm_bound_from_neighbours_lds(verts, prev_bi, threadIdx.x | (NM_TILE_SAMPLES - 1), it > 0 && active, x, y, z);
             init = fminf(init, nb);
         }
-        float bd[8], wk[8], gr[3];
+        float bd[8];
         int bi[8];
-        {
-            unsigned long long kk[8];
-            nm_knn_wave<8>(g, x, y, z, active, kk, init);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                bd[k] = nm_key_d2(kk[k]);
-                bi[k] = nm_key_idx(kk[k]);
+        unsigned long long kk[8];
+        if (BUDGET) {
+            if (nm_knn_wave<8, true>(g, x, y, z, active, kk, init, src.budget)) {   // (wave-uniform) over budget: hand the queries on
+                const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
+                const int n = __popcll(am);
+                int old = 0;
+                if (lane == 0) old = atomicAdd(src.defer_count, n);
+                old = __builtin_amdgcn_readfirstlane(old);
+                if (old + n <= src.defer_cap) {
+                    if (active) {
+                        const int at = old + __popcll(am & ((1ull << lane) - 1ull));
+                        src.defer_list[at] = (int)q;
+                        src.defer_bound2[at] = nm_key_d2(kk[7]);   // K-th best so far (or the warm-start bound / +INF): proven
+                    }
+                    continue;
+                }
+                // the list is full: finish here after all.  What this wave reserved inside the list stays empty (-1) -- the counter has
+                // moved past it, and the slots would otherwise hold entries of an earlier launch
+                if (active && old + __popcll(am & ((1ull << lane) - 1ull)) < src.defer_cap) src.defer_list[old + __popcll(am & ((1ull << lane) - 1ull))] = -1;
+                nm_knn_wave<8>(g, x, y, z, active, kk, init);
             }
+        } else {
+            nm_knn_wave<8>(g, x, y, z, active, kk, init);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            bd[k] = nm_key_d2(kk[k]);
+            bi[k] = nm_key_idx(kk[k]);
         }
         prev_rad = (active && bi[7] != 0x7fffffff) ? nm_sqrt(bd[7]) : NM_INF_F;
         prev_dep = dep;
@@ -512,44 +594,197 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_W
 #pragma unroll
             for (int k = 0; k < 8; ++k) prev_bi[k][threadIdx.x] = active ? bi[k] : 0x7fffffff;
         }
-        float ds = 0.f;
-        long long o = 0;
-        if (active) {
-            ds = nm_projected_distance8(x, y, z, bd, bi, verts, indicator, w1, wk, grad_out ? gr : nullptr);
-            o = (src.order && src.out_by_slot) ? (long long)blockIdx.x * blockDim.x + threadIdx.x : nm_out_index(src, q, r, p);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                bi[k] = 0;
-                wk[k] = 0.f;
-            }
-        }
-        if (fg_out) nm_gather_interp(geo_table, gdim, bi, wk, active, o, fg_out);
-        if (ft_out) nm_gather_interp(col_table, cdim, bi, wk, active, o, ft_out);
-        if (!active) continue;
-        if (ds_out) ds_out[o] = ds;
-        if (radius_out) radius_out[o] = nm_sqrt(bd[7]);
-        if (idx32_out) {
-            *reinterpret_cast<int4*>(idx32_out + o * 8) = make_int4(bi[0], bi[1], bi[2], bi[3]);
-            *reinterpret_cast<int4*>(idx32_out + o * 8 + 4) = make_int4(bi[4], bi[5], bi[6], bi[7]);
-        }
-        if (idx64_out) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) idx64_out[o * 8 + k] = (long long)bi[k];
-        }
-        if (w_out) {
-            *reinterpret_cast<float4*>(w_out + o * 8) = make_float4(wk[0], wk[1], wk[2], wk[3]);
-            *reinterpret_cast<float4*>(w_out + o * 8 + 4) = make_float4(wk[4], wk[5], wk[6], wk[7]);
-        }
-        if (grad_out) {
-            grad_out[o * 3] = gr[0];
-            grad_out[o * 3 + 1] = gr[1];
-            grad_out[o * 3 + 2] = gr[2];
-        }
+        nm_distance_finish(src, active, q, r, p, x, y, z, bd, bi, verts, indicator, w1, ds_out, idx32_out, idx64_out, w_out, grad_out, radius_out,
+                           geo_table, gdim, fg_out, col_table, cdim, ft_out);
     }
 #ifdef NM_TESTING
     nm_wave_log_write(nm_t0, ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 #endif
+}
+
+// ------------------------------------------------------------------------ the deferred queries of a small launch
+// A small launch (a training batch: 10^4 ... 10^5 points) lives as long as its slowest wave, and the slowest waves hold queries near the
+// medial axis of the object -- every surface patch about equally far, box bounds prune little, the traversal degenerates into a walk over
+// most of the index by ONE wave (tools/knn_wave_times.py: wave life p50 0.11 ms, p99 0.5 ms, max 1.2 ms = the launch).  Such waves give
+// up after NmPointSrc.budget work units (nm_distance_kernel<false, true>), leaving each query with the K-th best distance found so far --
+// a PROVEN upper bound -- and the query is finished by a whole wave of its own: lane (c1, c2) searches the level-2 subtree with child
+// digits (c1, c2) with a lane-private traversal started from that bound (64 subtrees in parallel instead of one after the other), the
+// 64 sorted lists are merged by eight wave-wide minima, and nm_distance_deferred_kernel computes the outputs (weights, projected
+// distance, gathers) from the merged keys.  Same candidate arithmetic and (d2, index) order, subtrees skipped only on the proven
+// bound: exact.  (First built as an exhaustive scan of all vertices by the whole chip: 26 k wave instructions per query, twice what the
+// hardest traversal itself costs -- 0.4-0.7 ms for the deferred queries of one launch; dropped.)
+
+// nm_knn_search restricted to the subtree of node `top` (never climbs above it); kk already holds the starting list
+template <int K>
+__device__ __forceinline__ void nm_knn_search_subtree(const NmGridView& g, uint32_t top, float qx, float qy, float qz, unsigned long long (&kk)[K]) {
+    const uint32_t kx = nm_float_key(qx), ky = nm_float_key(qy), kz = nm_float_key(qz);
+    NmNode rec = g.nodes[top];
+    if (nm_box_lb2(rec, qx, qy, qz) > nm_key_d2(kk[K - 1])) return;
+    if ((rec.info & 255u) == 0u) {   // the subtree is one leaf
+        for (uint32_t p = rec.first; p < rec.end; ++p) {
+            const float4 v = g.sverts[p];
+            const unsigned long long key = nm_key(nm_dist2(qx, qy, qz, v.x, v.y, v.z), nm_as_int(v.w));
+            if (key < kk[K - 1]) nm_topk_insert<K>(kk, key);
+        }
+        return;
+    }
+    int first = nm_octant(rec, kx, ky, kz);
+    unsigned om = nm_visit_mask(rec, first);
+    bool at_top = true;
+    for (;;) {
+        if (om == 0u) {
+            if (at_top) break;
+            const int c_prev = (int)((rec.info >> 8) & 7u);
+            const uint32_t parent = rec.parent;
+            rec = g.nodes[parent];
+            at_top = parent == top;
+            first = nm_octant(rec, kx, ky, kz);
+            om = nm_visit_mask(rec, first) & ~((2u << nm_perm(c_prev ^ first)) - 1u);
+            continue;
+        }
+        const int i = nm_ctz(om);
+        om &= om - 1u;
+        const int c = first ^ nm_perm(i);
+        const uint32_t mask = rec.info & 255u;
+        const NmNode crec = g.nodes[rec.first + (uint32_t)nm_popc(mask & ((1u << c) - 1u))];
+        if (nm_box_lb2(crec, qx, qy, qz) > nm_key_d2(kk[K - 1])) continue;
+        if ((crec.info & 255u) == 0u) {
+            for (uint32_t p = crec.first; p < crec.end; ++p) {
+                const float4 v = g.sverts[p];
+                const unsigned long long key = nm_key(nm_dist2(qx, qy, qz, v.x, v.y, v.z), nm_as_int(v.w));
+                if (key < kk[K - 1]) nm_topk_insert<K>(kk, key);
+            }
+        } else {
+            rec = crec;
+            at_top = false;
+            first = nm_octant(rec, kx, ky, kz);
+            om = nm_visit_mask(rec, first);
+        }
+    }
+}
+
+__device__ __forceinline__ void nm_query_rp(const NmPointSrc& s, long long q, long long& r, int& p) {
+    if (s.mode == 0) { r = q; p = 0; return; }
+    r = q / s.P;
+    p = (int)(q - r * s.P);
+}
+
+__device__ __forceinline__ unsigned long long nm_wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(v & 0xffffffffull), o), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o);
+        const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+        v = w < v ? w : v;
+    }
+    return v;
+}
+
+// unit of work = (64 consecutive deferred queries) x (level-2 subtree c1, c2): keys[(slot * 64 + 8 c1 + c2) * 8 + k] = the K = 8 best keys of
+// query `slot` inside that subtree that beat its bound (placeholders where there are none)
+__global__ __launch_bounds__(NM_KNN_BLOCK) void nm_knn_subtree_kernel(NmGridView g, NmPointSrc src, const float* __restrict__ bound2,
+                                                                      unsigned long long* __restrict__ keys) {
+    int n = *src.defer_count;
+    if (n > src.defer_cap) n = src.defer_cap;
+    if (n <= 0) return;
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const long long units = (long long)((n + 63) >> 6) * 64;
+    const NmNode root = nm_ld_node(g.nodes, 0);
+    const uint32_t rmask = root.info & 255u;
+    for (long long u = wave0; u < units; u += nwaves) {
+        const int tile = (int)(u >> 6), sub = (int)(u & 63), c1 = sub >> 3, c2 = sub & 7;
+        const int slot = tile * 64 + lane;
+        const int qd = slot < n ? src.defer_list[slot] : -1;
+        const bool active = qd >= 0;
+        float x = 0.f, y = 0.f, z = 0.f, dep = 0.f, b2 = NM_INF_F;
+        if (active) {
+            long long r;
+            int p;
+            nm_query_rp(src, (long long)qd, r, p);
+            nm_fetch_point(src, r, p, x, y, z, dep);
+            b2 = bound2[slot];
+        }
+        unsigned long long kk[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) kk[k] = nm_key(b2, 0x7fffffff);
+        // the unit's subtree (wave-uniform): level-2 node (c1, c2); a level-1 LEAF belongs to c2 = 0, a root that is a leaf to unit 0
+        uint32_t top = 0xffffffffu;
+        bool leaf = false;
+        if (rmask == 0u) {
+            if (sub == 0) { top = 0u; leaf = true; }
+        } else if ((rmask >> c1) & 1u) {
+            const uint32_t i1 = root.first + (uint32_t)__popc(rmask & ((1u << c1) - 1u));
+            const NmNode n1 = nm_ld_node(g.nodes, i1);
+            const uint32_t m1 = n1.info & 255u;
+            if (m1 == 0u) {
+                if (c2 == 0) { top = i1; leaf = true; }
+            } else if ((m1 >> c2) & 1u) {
+                top = n1.first + (uint32_t)__popc(m1 & ((1u << c2) - 1u));
+                leaf = (nm_ld_node(g.nodes, top).info & 255u) == 0u;
+            }
+        }
+        if (top != 0xffffffffu) {
+            if (leaf) {
+                const NmNode t = nm_ld_node(g.nodes, top);
+                for (uint32_t p = t.first; p < t.end; ++p) {
+                    const float4 v = nm_ld_vert(g.sverts, p);
+                    const unsigned long long key = nm_key(nm_dist2(x, y, z, v.x, v.y, v.z), nm_as_int(v.w));
+                    if (active && key < kk[7]) nm_topk_insert<8>(kk, key);
+                }
+            } else {
+                // packet centre: the mean position of the tile's queries is not needed -- any point orders the children validly; lane 0's
+                const float rx = nm_uniform_f(x), ry = nm_uniform_f(y), rz = nm_uniform_f(z);
+                nm_knn_search_packet<8, false, true>(g, x, y, z, active, rx, ry, rz, kk, b2, 0, top);
+            }
+        }
+        if (active) {
+            unsigned long long* o = keys + ((long long)slot * 64 + sub) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = kk[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(NM_KNN_BLOCK) void nm_distance_deferred_kernel(NmGridView g, NmPointSrc src, const unsigned long long* __restrict__ keys,
+                                                                            const float* __restrict__ verts, const float* __restrict__ indicator, float w1,
+                                                                            float* __restrict__ ds_out, int* __restrict__ idx32_out,
+                                                                            long long* __restrict__ idx64_out, float* __restrict__ w_out,
+                                                                            float* __restrict__ grad_out, float* __restrict__ radius_out,
+                                                                            const float* __restrict__ geo_table, int gdim, float* __restrict__ fg_out,
+                                                                            const float* __restrict__ col_table, int cdim, float* __restrict__ ft_out) {
+    int n = *src.defer_count;
+    if (n > src.defer_cap) n = src.defer_cap;
+    const long long slot = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (((slot >> 6) << 6) >= n) return;   // (whole wave)
+    const int qd = slot < n ? src.defer_list[slot] : -1;
+    const bool active = qd >= 0;
+    long long q = 0, r = 0;
+    int p = 0;
+    float x = 0.f, y = 0.f, z = 0.f, dep = 0.f;
+    unsigned long long kk[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) kk[k] = nm_key(NM_INF_F, 0x7fffffff);
+    if (active) {
+        q = (long long)qd;
+        nm_query_rp(src, q, r, p);
+        nm_fetch_point(src, r, p, x, y, z, dep);
+        const unsigned long long* in = keys + slot * 64 * 8;
+        for (int c = 0; c < 64; ++c)
+            for (int k = 0; k < 8; ++k) {          // each subtree's list is ascending
+                const unsigned long long key = in[c * 8 + k];
+                if (!(key < kk[7])) break;
+                nm_topk_insert<8>(kk, key);
+            }
+    }
+    float bd[8];
+    int bi[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        bd[k] = nm_key_d2(kk[k]);
+        bi[k] = nm_key_idx(kk[k]);
+    }
+    nm_distance_finish(src, active, q, r, p, x, y, z, bd, bi, verts, indicator, w1, ds_out, idx32_out, idx64_out, w_out, grad_out, radius_out,
+                       geo_table, gdim, fg_out, col_table, cdim, ft_out);
 }
 
 // ---------------------------------------------------- bounded near/far straight from the probes

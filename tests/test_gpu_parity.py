@@ -149,6 +149,48 @@ def test_knn_cooperative_and_private_paths_agree(dtu_scale, cuda_device, torch_m
         assert np.array_equal(idx.cpu().numpy(), ridx) and np.array_equal(d2.cpu().numpy(), rd2)
 
 
+def test_small_launch_deferral_is_exact(dtu_scale, cuda_device, torch_mod, monkeypatch):
+    """Small launches (<= 2^18 points) give up a wave's traversal after a work budget and finish its queries subtree by subtree on the
+    whole chip (csrc/nm_kernels.h "the deferred queries of a small launch"; budget: NEUMESH_KNN_BUDGET, 0 = off, 1 = defer whatever
+    the list has room for).  Every output of the fused K-NN + distance kernel is identical bit for bit whichever way a query went:
+    points near the centre of the object (the expensive ones: every surface patch about equally far), ray-ordered probes, scattered
+    points; 20 000 points, so that budget 1 also overflows the 8192-entry list (the waves that find it full finish on their own), and
+    a second call right after with fewer points (entries of the earlier launch must not be picked up)."""
+    torch = torch_mod
+    from neumesh_amd import synthetic
+    mesh, _, model = dtu_scale
+    rng = np.random.default_rng(21)
+    o, d = synthetic.camera_rays(synthetic.orbit_pose(4), synthetic.pinhole_intrinsics(800, 800), 800, 800, start=400 * 800 + 380, count=40)
+    d = orender.normalize(d)
+    t = np.linspace(1.0, 3.4, 256, dtype=np.float32)
+    probes = (o[:, None, :] + t[None, :, None] * d[:, None, :]).reshape(-1, 3)
+    centre = 0.05 * rng.standard_normal((4000, 3))
+    scattered = rng.uniform(-1.2, 1.2, (5760, 3))
+    q = _t(np.concatenate([probes, centre, scattered]).astype(np.float32), cuda_device)
+    assert q.shape[0] == 20000
+    ind = model.indicator_vector.detach()
+
+    def run(points):
+        with torch.no_grad():
+            ds, idx, w = model.compute_distance(points)
+            feat = model.mesh_grid.compute_distance_interpolate(points, model.geometry_features.detach(), ind, 0.1)
+        return [ds, idx, w] + list(feat)
+
+    monkeypatch.setenv("NEUMESH_KNN_BUDGET", "0")
+    ref, ref_small = run(q), run(q[:3000])
+    ridx, _ = oknn.knn_bruteforce(q[:2000].cpu().numpy(), mesh.vertices, 8)
+    assert np.array_equal(ref[1][:2000].cpu().numpy(), ridx)
+    for budget in ("1", "3000", "30000"):
+        monkeypatch.setenv("NEUMESH_KNN_BUDGET", budget)
+        for got, want in ((run(q), ref), (run(q[:3000]), ref_small)):
+            assert len(got) == len(want)
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), budget
+    monkeypatch.delenv("NEUMESH_KNN_BUDGET")
+    for a, b in zip(run(q), ref):
+        assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------- field
 def test_compute_distance_matches_reference(small, cuda_device, torch_mod):
     _, _, model = small
