@@ -271,8 +271,13 @@ static NmPointSrc nm_src_xyz(const float* xyz, long long Q = 0) {
     // ~11 cycles per instruction of a wave that has its SIMD to itself: fewer queries per wave = more, shorter waves that overlap.  Aim at
     // >= 8192 waves, down to ONE query per wave (measured on a training step's eight K-NN launches, tools/train_trace.sh: target 4096 waves
     // with >= 8 queries each 6.9 ms, 8192 / >= 4: 6.5, 8192 / >= 1: 5.6 -- the 8 k-point launches 0.40-0.69 -> 0.26-0.33 ms --, 16384 / >= 1: 5.8).
+    long long target = 8192;
+#ifdef NM_TESTING
+    static const int target_env = getenv("NEUMESH_KNN_WAVE_TARGET") ? atoi(getenv("NEUMESH_KNN_WAVE_TARGET")) : 0;   // A/B of the wave count aimed at
+    if (target_env > 0) target = target_env;
+#endif
     if (Q > 0)
-        while (s.lanes > 1 && Q / s.lanes < 8192) s.lanes >>= 1;
+        while (s.lanes > 1 && Q / s.lanes < target) s.lanes >>= 1;
 #ifdef NM_TESTING
     static const int lanes_env = getenv("NEUMESH_KNN_LANES") ? atoi(getenv("NEUMESH_KNN_LANES")) : 0;   // tools/knn_small.py: queries per wave A/B
     if (lanes_env > 0) s.lanes = lanes_env;
