@@ -229,7 +229,7 @@ def consumer_rows(mesh, model, dev, H, W):
             p_.grad = None
         out["train_step (512 rays x 128 samples of one view, img + eikonal + mask + indicator losses, forward + backward + Adam)"] = {
             "ms_per_step": dt * 1e3, "value": 512 / dt, "unit": "rays/s", "steps": 8,
-            "field_backend": f"{backend}: nm_train_forward / nm_train_backward (closed-form reverse pass, fp32 MFMA GEMMs)" if backend == "hip" else backend,
+            "field_backend": f"{backend}: nm_train_forward / nm_train_backward (closed-form reverse pass, GEMMs on the bf16 pipe with fp32 operands cut into three pieces)" if backend == "hip" else backend,
             "ms_per_step_torch_autograd_field": dt_torch * 1e3}
     except Exception as ex:
         out["train_step"] = {"error": str(ex)[-300:]}

@@ -317,7 +317,7 @@ static const NmGather NM_NO_GATHER = {nullptr, 0, nullptr, nullptr, 0, nullptr};
 #ifndef NM_DEFER_BUDGET
 #define NM_DEFER_BUDGET 30000
 #endif
-static size_t nm_defer_bytes() { return 256 + (size_t)NM_DEFER_CAP * (4 + 4 + 64 * 8 * sizeof(unsigned long long)); }
+static size_t nm_defer_bytes() { return 256 + (size_t)NM_DEFER_CAP * (8 + 4 + 4 + 64 * 8 * sizeof(unsigned long long)); }   // count | masks | list | bounds | keys
 static void* nm_defer_block(nm_grid_t g, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g->defer_mu);
     for (auto& e : g->defer_scratch)
@@ -343,14 +343,15 @@ static int nm_launch_distance(nm_grid_t g, const NmPointSrc& src_in, long long Q
             src.budget = budget;
             src.defer_cap = NM_DEFER_CAP;
             src.defer_count = (int*)blk;
-            src.defer_list = (int*)(blk + 256);
-            src.defer_bound2 = (float*)(blk + 256 + (size_t)NM_DEFER_CAP * 4);
-            unsigned long long* keys = (unsigned long long*)(blk + 256 + (size_t)NM_DEFER_CAP * 8);
-            NM_HIP(hipMemsetAsync(src.defer_count, 0, 4, stream));
+            unsigned long long* masks = (unsigned long long*)(blk + 256);
+            src.defer_list = (int*)(blk + 256 + (size_t)NM_DEFER_CAP * 8);
+            src.defer_bound2 = (float*)(blk + 256 + (size_t)NM_DEFER_CAP * 12);
+            unsigned long long* keys = (unsigned long long*)(blk + 256 + (size_t)NM_DEFER_CAP * 16);
+            NM_HIP(hipMemsetAsync(blk, 0, 256 + (size_t)NM_DEFER_CAP * 8, stream));   // the counter and the masks
             hipLaunchKernelGGL((nm_distance_kernel<false, true>), dim3(nm_query_blocks(src, Q)), dim3(256), 0, stream, g->view, src, Q, g->verts,
                                indicator, w1, ds, idx32, idx64, w, grad, radius, ga.geo_table, ga.gdim, ga.fg, ga.col_table, ga.cdim, ga.ft);
-            hipLaunchKernelGGL(nm_knn_subtree_kernel, dim3(1536), dim3(256), 0, stream, g->view, src, src.defer_bound2, keys);
-            hipLaunchKernelGGL(nm_distance_deferred_kernel, dim3(NM_DEFER_CAP / 256), dim3(256), 0, stream, g->view, src, keys, g->verts, indicator, w1,
+            hipLaunchKernelGGL(nm_knn_subtree_kernel, dim3(1536), dim3(256), 0, stream, g->view, src, src.defer_bound2, keys, masks);
+            hipLaunchKernelGGL(nm_distance_deferred_kernel, dim3(NM_DEFER_CAP / 256), dim3(256), 0, stream, g->view, src, keys, masks, g->verts, indicator, w1,
                                ds, idx32, idx64, w, grad, radius, ga.geo_table, ga.gdim, ga.fg, ga.col_table, ga.cdim, ga.ft);
             NM_LAUNCH_CHECK();
             return 0;

@@ -681,8 +681,9 @@ __device__ __forceinline__ unsigned long long nm_wave_min_u64(unsigned long long
 
 // unit of work = (64 consecutive deferred queries) x (level-2 subtree c1, c2): keys[(slot * 64 + 8 c1 + c2) * 8 + k] = the K = 8 best keys of
 // query `slot` inside that subtree that beat its bound (placeholders where there are none)
+// (only subtrees that hold a candidate write their list; bit `sub` of mask[slot] says so -- zeroed by the host before the launch)
 __global__ __launch_bounds__(NM_KNN_BLOCK) void nm_knn_subtree_kernel(NmGridView g, NmPointSrc src, const float* __restrict__ bound2,
-                                                                      unsigned long long* __restrict__ keys) {
+                                                                      unsigned long long* __restrict__ keys, unsigned long long* __restrict__ mask) {
     int n = *src.defer_count;
     if (n > src.defer_cap) n = src.defer_cap;
     if (n <= 0) return;
@@ -737,15 +738,17 @@ __global__ __launch_bounds__(NM_KNN_BLOCK) void nm_knn_subtree_kernel(NmGridView
                 nm_knn_search_packet<8, false, true>(g, x, y, z, active, rx, ry, rz, kk, b2, 0, top);
             }
         }
-        if (active) {
+        if (active && nm_key_idx(kk[0]) != 0x7fffffff) {
             unsigned long long* o = keys + ((long long)slot * 64 + sub) * 8;
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] = kk[k];
+            atomicOr(mask + slot, 1ull << sub);
         }
     }
 }
 
 __global__ __launch_bounds__(NM_KNN_BLOCK) void nm_distance_deferred_kernel(NmGridView g, NmPointSrc src, const unsigned long long* __restrict__ keys,
+                                                                            const unsigned long long* __restrict__ mask,
                                                                             const float* __restrict__ verts, const float* __restrict__ indicator, float w1,
                                                                             float* __restrict__ ds_out, int* __restrict__ idx32_out,
                                                                             long long* __restrict__ idx64_out, float* __restrict__ w_out,
@@ -769,12 +772,14 @@ __global__ __launch_bounds__(NM_KNN_BLOCK) void nm_distance_deferred_kernel(NmGr
         nm_query_rp(src, q, r, p);
         nm_fetch_point(src, r, p, x, y, z, dep);
         const unsigned long long* in = keys + slot * 64 * 8;
-        for (int c = 0; c < 64; ++c)
+        for (unsigned long long m = mask[slot]; m; m &= m - 1ull) {
+            const int c = __builtin_ctzll(m);
             for (int k = 0; k < 8; ++k) {          // each subtree's list is ascending
                 const unsigned long long key = in[c * 8 + k];
                 if (!(key < kk[7])) break;
                 nm_topk_insert<8>(kk, key);
             }
+        }
     }
     float bd[8];
     int bi[8];
