@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void nm_gemm_kernel(NmGemm g) {
 // The same product on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16: 16 x the fp32 pipe's rate) with fp32-grade operands: every fp32
 // value is cut into three bf16 pieces BY TRUNCATION, a = b1 + b2 + b3 EXACTLY (8 + 8 + 8 significant bits; bf16 has fp32's exponent, so
 // cotangents of 1e-9 need no scaling -- an f16 split would), and a product is the six piece products of weight >= 2^-16,
-//   a.b = a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a3 b1 + a2 b2)      [dropped: a2 b3, a3 b2, a3 b3 <= 2^-24 |a||b|, fp32's own rounding]
+//   a.b = a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a3 b1 + a2 b2)      [dropped: a2 b3 + a3 b2 + a3 b3 < 2^-21 |a||b| in the worst case of
+//                                                                  truncated pieces (|a2| < 2^-7 |a|, |a3| < 2^-15 |a|), ~2^-23 typically]
 // accumulated in fp32 by the matrix pipe.  6 MFMAs per 16-k step and tile instead of 8 on a pipe that is 16 x faster.
 // Operand tiles are split ONCE, when they are stashed: three bf16 planes [row][k] per operand in LDS (row stride 24 halves = 48 bytes:
 // conflict-free ds_read_b128), K in steps of 16, two buffers: 73.7 KB, two workgroups per CU as before.
@@ -173,6 +174,10 @@ __global__ __launch_bounds__(256) void nm_gemm_kernel(NmGemm g) {
 #endif
 #define NM_G3_NV (512 / NM_G3_THREADS)   // float4 per thread and operand tile (128 rows x 16 k / 4 / threads)
 #define NM_G3_RT (512 / NM_G3_THREADS)   // row tiles (32 rows) per wave
+#ifndef NM_G3_PRODUCTS
+#define NM_G3_PRODUCTS 6                 // piece products per fp32 product: 6, or 8 (+ a2 b3, a3 b2): measured 73 vs 82 us per product with the SAME error
+                                         // against float64 (7.5e-7 of max |C| at K = 256: the fp32 accumulation of the sum dominates, not the dropped terms)
+#endif
 typedef __bf16 nm_bf8 __attribute__((ext_vector_type(8)));
 
 // (loads are UNCONDITIONAL, from a clamped address, and masked when they are consumed: a branch around a load, or a select right behind
@@ -278,6 +283,10 @@ __global__ __launch_bounds__(NM_G3_THREADS) void nm_gemm3_kernel(NmGemm g) {
             for (int i = 0; i < NM_G3_RT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {   // small terms first
+#if NM_G3_PRODUCTS == 8
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][1], acc[i][j], 0, 0, 0);
+#endif
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], acc[i][j], 0, 0, 0);

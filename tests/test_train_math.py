@@ -117,3 +117,48 @@ def test_composite_reverse_scan_equals_autograd(white):
     assert float(acc.min()) < 1e-6 and float(acc.max()) > 0.5
     for name, a, b in zip(("sdf", "radiance", "nablas", "s"), got, want):
         assert float((a - b).abs().max()) <= 1e-9 * max(1.0, float(b.abs().max())), (name, float((a - b).abs().max()))
+
+
+def test_bf16_three_piece_product_is_fp32_grade():
+    """The arithmetic of the training GEMMs (csrc/nm_gemm.h, nm_gemm3_kernel), emulated in numpy: an fp32 value cut into three bf16
+    pieces by truncation is reproduced EXACTLY by their sum (also values of cotangent size, 1e-9, and subnormal-adjacent ones -- bf16
+    shares fp32's exponent range, which is why no scale factors are needed), every piece IS a bf16 number (low 16 bits zero), and the six
+    piece products the kernel adds differ from the full product by the three it drops: < 2^-21 |a||b| in the worst case of truncated
+    pieces (|a2| < 2^-7 |a|, |a3| < 2^-15 |a|), 2^-23 on average.  A K = 256 dot product of such six-term products, accumulated in
+    float64, is within 2^-22 of the exact one relative to sum |a||b| -- the fp32 accumulation of 256 terms on either pipe costs as
+    much (tools/gemm_bench.py: 7.5e-7 of max |C| with six products, with eight, and on the fp32 pipe)."""
+    rng = np.random.default_rng(0)
+
+    def cut(a):
+        a = a.astype(np.float32)
+        b1 = (a.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+        r1 = (a - b1).astype(np.float32)
+        b2 = (r1.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+        r2 = (r1 - b2).astype(np.float32)
+        b3 = (r2.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32)
+        return b1, b2, b3, r2
+
+    for scale in (1.0, 0.06, 1e-6, 1e-9, 3e-30, 1e4):
+        a = (rng.standard_normal(20000) * scale).astype(np.float32)
+        b = (rng.standard_normal(20000) * 0.06).astype(np.float32)
+        a1, a2, a3, ar = cut(a)
+        b1, b2, b3, br = cut(b)
+        assert np.array_equal(ar, a3) and np.array_equal(br, b3)                      # the third piece holds all that is left
+        assert np.array_equal((a1.astype(np.float64) + a2 + a3), a.astype(np.float64))  # a = a1 + a2 + a3 exactly
+        for piece in (a1, a2, a3):
+            assert not (piece.view(np.uint32) & np.uint32(0xFFFF)).any()
+        A, B = [x.astype(np.float64) for x in (a1, a2, a3)], [x.astype(np.float64) for x in (b1, b2, b3)]
+        six = A[0] * B[0] + (A[0] * B[1] + A[1] * B[0]) + (A[0] * B[2] + A[2] * B[0] + A[1] * B[1])
+        full = a.astype(np.float64) * b.astype(np.float64)
+        err = np.abs(six - full)
+        assert (err <= 2.0 ** -21 * np.abs(full) + 1e-300).all(), scale
+        assert err.mean() <= 2.0 ** -23 * np.abs(full).mean(), scale
+    # a dot product of the layer width
+    a = rng.standard_normal((512, 256)).astype(np.float32)
+    b = (rng.standard_normal((256, 64)) * 0.06).astype(np.float32)
+    A, B = cut(a)[:3], cut(b)[:3]
+    A, B = [x.astype(np.float64) for x in A], [x.astype(np.float64) for x in B]
+    six = A[0] @ B[0] + (A[0] @ B[1] + A[1] @ B[0]) + (A[0] @ B[2] + A[2] @ B[0] + A[1] @ B[1])
+    full = a.astype(np.float64) @ b.astype(np.float64)
+    mag = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+    assert (np.abs(six - full) <= 2.0 ** -22 * mag).all()
