@@ -330,7 +330,9 @@ int nm_surface_hits(nm_field_t field, nm_grid_t grid, const nm_field_tables* tab
  * the kernel's forward-mode tangent, so a cotangent on it -- the eikonal loss -- needs no second-order machinery).
  *
  * `desc` carries the fp32 weights in PyTorch layout ([out, in], weight-norm already folded: the caller's autograd maps the
- * returned gradient of a folded weight to its g / v parameters); mlp_precision is ignored (fp32 operands, fp32 matrix pipe).
+ * returned gradient of a folded weight to its g / v parameters).  Operands and results are fp32 either way; mlp_precision selects the
+ * matrix pipe of the layer products: 0 = v_mfma_f32_32x32x2_f32, anything else = the bf16 pipe with every fp32 operand cut into three
+ * exact bf16 pieces and six piece products per product (same error against float64, 1.5 x faster; csrc/nm_gemm.h).
  * view_dirs == NULL: geometry only (rgb is not computed).  with_nabla == 0: sdf only (forward_density_only under autograd).
  * nm_train_backward must follow an nm_train_forward on the same workspace, P and flags; g_sdf [P], g_nabla [P,3], g_rgb [P,3]
  * are the cotangents (NULL = zero).  Gradients are ADDED into the non-NULL members of `out` (device pointers, shapes of the
