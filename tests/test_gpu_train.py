@@ -264,3 +264,42 @@ def test_fused_sampler_of_the_training_renderer_equals_the_staged_sampler(cuda_d
     else:   # other uniform numbers than the staged form draws (one [iters, R, n] block instead of per-iteration blocks): same estimator
         assert float((a[0] - b[0]).abs().mean()) < 0.05 and bool(torch.isfinite(b[0]).all())
         assert not torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_training_gemm_alone_ragged_shapes(cuda_device, torch_mod, mode):
+    """csrc/nm_gemm.h through the testing library's nm_debug_gemm: the three operand layouts of a linear layer's products (forward
+    X W^T, input gradient dY W, weight gradient dY^T X with split-K and atomic accumulation onto a non-zero C), bias + ReLU epilogue,
+    sizes that are not multiples of the 128 x 128 tile, of the 16 / 32-wide k step or of the split chunk -- fp32 pipe (mode 0) and
+    bf16 x 3 (mode 1) against float64, cotangent-sized operands included (no scaling: bf16 has fp32's exponent)."""
+    import ctypes as C
+    torch = torch_mod
+    from neumesh_amd import _lib
+    lib = _lib.load_testing()
+    st = _lib.current_stream(cuda_device)
+    g = torch.Generator(device="cpu").manual_seed(3)
+
+    def run(A, lda, akc, B, ldb, bkc, M, N, K, split=1, bias=None, relu=0, c0=None):
+        Cc = (torch.zeros(M, N) if c0 is None else c0.clone()).to(cuda_device)
+        _lib.check(lib.nm_debug_gemm(_lib.ptr(A), lda, akc, _lib.ptr(B), ldb, bkc, _lib.ptr(Cc), N, M, N, K, _lib.ptr(bias), relu, split,
+                                     1 if (split > 1 or c0 is not None) else 0, mode, 0, None, st), "nm_debug_gemm", lib)
+        torch.cuda.synchronize()
+        return Cc.double().cpu()
+
+    def close(got, want, what):
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 4e-6 * scale + 1e-30, (what, float((got - want).abs().max()), scale)
+
+    for M, N, K in ((1, 64, 16), (130, 256, 48), (776, 176, 256), (5000, 128, 1000), (257, 4, 36)):
+        X = torch.randn(M, K, generator=g)
+        W = torch.randn(N, K, generator=g) * 0.06
+        b = torch.randn(N, generator=g)
+        Xd, Wd, bd = X.to(cuda_device), W.to(cuda_device), b.to(cuda_device)
+        close(run(Xd, K, 1, Wd, K, 1, M, N, K), X.double() @ W.double().T, ("forward", M, N, K))
+        close(run(Xd, K, 1, Wd, K, 1, M, N, K, bias=bd, relu=1), torch.relu(X.double() @ W.double().T + b.double()), ("bias+relu", M, N, K))
+        dY = torch.randn(M, N, generator=g) * 1e-6
+        dYd = dY.to(cuda_device)
+        close(run(dYd, N, 1, Wd, K, 0, M, K, N), dY.double() @ W.double(), ("input grad", M, N, K))        # [M,N] x [N,K]
+        c0 = torch.randn(N, K, generator=g) * 1e-6
+        for split in (1, 3, 7):
+            close(run(dYd, N, 0, Xd, K, 0, N, K, M, split=split, c0=c0), c0.double() + dY.double().T @ X.double(), ("weight grad", M, N, K, split))
