@@ -788,6 +788,9 @@ def main():
             short("two_half_frame_chunks_on_two_streams (rayschunk = half a frame: the low-occupancy per-ray kernels of one chunk run beside the other chunk's "
                   "kernels; identical pixels; the per-kernel event times of this run overlap, so the roofline figures are taken from the one-stream headline run)",
                   chunk=(n_rays + 1) // 2, keep_frame0=True)
+            r = short("library_default_chunks (rayschunk = 65536, the value volume_render uses when the caller names none -- ~4 GB of workspace per lane instead "
+                      "of 40 --, chunks alternating between two streams; identical pixels)", chunk=65536, keep_frame0=True)
+            cfgd["default_rayschunk_ms_per_frame"] = r.get("ms_per_frame")
             short("weight_eps_1e-10 (mid-points of visibility weight < 1e-10 not evaluated: the one variant that is not bit-identical; "
                   "rgb / normals move by < 127e-10, depth / acc not at all)", weight_eps=1e-10, keep_frame0=True)
             short("config3_shape (64 samples/ray, white background)", samples=64, white=True)
