@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void nm_gemm_kernel(NmGemm g) {
 #define NM_G3_BK 16
 #define NM_G3_LS 24
 #ifndef NM_G3_DEPTH
-#define NM_G3_DEPTH 4                  // steps whose operand rows are in flight
+#define NM_G3_DEPTH 2                  // steps whose operand rows are in flight (512 threads: 2 -> 70 us, 4 -> 73, 6 -> 77 per [65536,256]x[256,256];
+                                       // 256 threads needed 4: there the ring hides the latency, here four waves per SIMD do)
 #endif
 #ifndef NM_G3_THREADS
 #define NM_G3_THREADS 512              // 256: wave = 64 x 64 of the tile (2 x 2 MFMA tiles); 512: wave = 32 x 64 (1 x 2), four waves per SIMD
