@@ -322,8 +322,12 @@ static void* nm_defer_block(nm_grid_t g, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g->defer_mu);
     for (auto& e : g->defer_scratch)
         if (e.first == stream) return e.second;
+    if (g->defer_scratch.size() >= 8) return nullptr;   // an application that keeps making streams: later ones simply do not defer
     void* p = nullptr;
-    if (hipMalloc(&p, nm_defer_bytes()) != hipSuccess) return nullptr;
+    if (hipMalloc(&p, nm_defer_bytes()) != hipSuccess) {
+        (void)hipGetLastError();                          // (not an error of the call: the launch runs without the second phase)
+        return nullptr;
+    }
     g->defer_scratch.emplace_back(stream, p);
     return p;
 }
