@@ -7,9 +7,12 @@ K=8, r=100.0, return_sorted=True -> squared distances ascending, int64 indices).
 Arithmetic: ``dx = q - v`` in IEEE fp32, ``d2 = (dx*dx + dy*dy) + dz*dz``
 without FMA contraction, the K smallest by ``(d2, vertex index)`` ascending.
 
-Parity unpinned: the reference has no golden vectors for this boundary (FRNN is external,
-un-vendored and un-pinned), so the arithmetic above is a declaration, checked for
-self-consistency (C brute force == numpy brute force == kd-tree + re-rank) in tests/.
+Pinning: the rest of the oracle (field, renderer, editing, training math) is pinned by fixtures generated
+from the imported reference (oracle/gen_golden.py).  For THIS boundary only the order of exact ties is a
+declaration -- FRNN is external, un-vendored and un-pinned and the reference holds no golden vectors for
+it -- so the arithmetic above is checked for self-consistency (C brute force == numpy brute force ==
+kd-tree + re-rank) in tests/, and every downstream fixture (which the reference produced through its
+kd-tree stand-in with the same re-rank) agrees with it.
 """
 from __future__ import annotations
 
