@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 9
+#define NM_ABI_VERSION 10
 #define NM_MAX_K 32
 
 typedef struct nm_grid_s* nm_grid_t;    /* spatial index over the mesh vertices */
@@ -61,6 +61,15 @@ int nm_device_count(void);
 int nm_grid_create(const float* verts_device, int64_t V, int leaf_level, nm_stream_t stream,
                    nm_grid_t* out);
 int nm_grid_destroy(nm_grid_t g);
+/* Per-index options.
+ *   NM_GRID_DEFER_BUDGET  point-wise launches of <= 2^18 queries: work units (24 per node test, 7 per scanned vertex) after which a
+ *                         wave hands its unfinished queries to the whole chip (exact either way).  0 = never, -1 = the build's
+ *                         default (30000).  The hand-over needs 33.7 MB of scratch per (index, stream) that used it, allocated with
+ *                         hipMalloc on the first such launch of a stream (at most 8 streams per index; later ones do not defer).
+ *   NM_GRID_TRIM          frees that scratch (value ignored).  The caller vouches that no launch on this index is in flight. */
+#define NM_GRID_DEFER_BUDGET 1
+#define NM_GRID_TRIM 2
+int nm_grid_set_option(nm_grid_t g, int option, int64_t value);
 
 typedef struct nm_grid_info {
     int64_t num_vertices;
@@ -203,6 +212,17 @@ typedef struct nm_render_cfg {
     const float* u_rand;         /* NULL: deterministic importance samples (sample_pdf(det=True), perturb=False).  Else device
                                     [N_upsample_iters][R][N_importance / N_upsample_iters] uniform numbers in [0,1): the stratum
                                     positions of sample_pdf(det=False) (rend_util.py:300-302), rows in the CALLER's ray order */
+    /* ABI v10: several ray chunks in flight on several streams (the caller's loop over renderer.py:353-363's chunks).  None of the
+       three changes a result bit. */
+    int32_t overlap;             /* 0 = every kernel is a plain grid launch (one chunk at a time: the right form).  1 = the call is one of
+                                    several chunks rendered concurrently on different streams: its K-NN kernels run in the pull form
+                                    (one-wave workgroups drawing packets from a counter) and make room for the MLP kernels of the OTHER
+                                    chunks whenever one is queued -- at most knn_keep K-NN waves stay on a SIMD then -- so that the
+                                    vector-issue-bound searches run under the matrix-pipe-bound MLPs instead of beside them */
+    int32_t knn_keep;            /* K-NN waves a SIMD keeps while an MLP launch wants room; 0 = default (1: what two MLP workgroups per CU
+                                    leave in registers and LDS) */
+    int32_t mlp_prio;            /* s_setprio level of the MLP kernels' waves (0..3; 0 = default): the pull waves live long and would otherwise
+                                    win the oldest-first issue arbitration against every MLP wave */
 } nm_render_cfg;
 #define NM_MAX_EDIT 4
 

@@ -11,7 +11,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_K = 32
 
 
@@ -46,9 +46,11 @@ class RenderCfg(C.Structure):
                 ("mid_group_rays", C.c_int32), ("weight_eps", C.c_float),
                 ("n_edit", C.c_int32), ("code_dims", C.c_int32), ("edit_field", C.c_void_p * 4),
                 ("edit_mask", C.c_void_p * 4), ("edit_color_features", C.c_void_p),
-                ("edit_use_rot", C.c_int32 * 4), ("edit_rot", (C.c_float * 9) * 4), ("u_rand", C.c_void_p)]
+                ("edit_use_rot", C.c_int32 * 4), ("edit_rot", (C.c_float * 9) * 4), ("u_rand", C.c_void_p),
+                ("overlap", C.c_int32), ("knn_keep", C.c_int32), ("mlp_prio", C.c_int32)]
 
 
+GRID_DEFER_BUDGET, GRID_TRIM = 1, 2   # nm_grid_set_option
 # nm_render_cfg.flags (include/neumesh_hip.h)
 RENDER_FULL_PROBES, RENDER_NO_ZERO_SKIP, RENDER_NO_RAY_SORT, RENDER_NO_MID_ORDER, RENDER_EAGER_NABLAS, RENDER_SAMPLE_ONLY = 1, 2, 4, 8, 16, 32
 
@@ -87,6 +89,7 @@ SIGNATURES = {
     "nm_grid_create": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.POINTER(_P)]),
     "nm_grid_destroy": (C.c_int, [_P]),
     "nm_grid_get_info": (C.c_int, [_P, C.POINTER(GridInfo)]),
+    "nm_grid_set_option": (C.c_int, [_P, C.c_int, C.c_int64]),
     "nm_knn": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, _P, _P]),
     "nm_compute_distance": (C.c_int, [_P, _P, C.c_int64, _P, C.c_float, C.c_int, _P, _P, _P, _P, _P]),
     "nm_distance_interpolate": (C.c_int, [_P, _P, C.c_int64, _P, C.c_float, _P, C.c_int, _P, _P, _P, _P, _P]),
@@ -132,6 +135,7 @@ TESTING_SIGNATURES = {
     "nm_grid_debug_export": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64]),
     "nm_selfcheck_field": (C.c_int, [_P, _P, C.POINTER(FieldTables), _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "nm_debug_last_deferred": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
+    "nm_debug_simd_keys": (C.c_int, [_P, C.c_int, _P]),
     "nm_debug_gemm": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int,
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
 }

@@ -110,6 +110,7 @@ struct nm_grid_s {
     // reuse is safe, two streams never share a block
     std::mutex defer_mu;
     std::vector<std::pair<hipStream_t, void*>> defer_scratch;
+    std::atomic<int> defer_budget{-1};   // work units after which a wave of a small launch hands its queries on; -1 = the build's default (nm_grid_set_option)
 };
 
 struct nm_field_s {
@@ -246,6 +247,22 @@ int nm_grid_destroy(nm_grid_t g) {
     return 0;
 }
 
+int nm_grid_set_option(nm_grid_t g, int option, int64_t value) {
+    if (!g) return nm_fail("nm_grid_set_option: NULL handle");
+    if (option == NM_GRID_DEFER_BUDGET) {
+        if (value < -1 || value > (1ll << 30)) return nm_fail("nm_grid_set_option: budget %lld out of range", (long long)value);
+        g->defer_budget.store((int)value, std::memory_order_relaxed);
+        return 0;
+    }
+    if (option == NM_GRID_TRIM) {   // give the deferral scratch back (33.7 MB per stream that used the index); the caller vouches that no launch on this index is in flight
+        std::lock_guard<std::mutex> lk(g->defer_mu);
+        for (auto& e : g->defer_scratch) (void)hipFree(e.second);
+        g->defer_scratch.clear();
+        return 0;
+    }
+    return nm_fail("nm_grid_set_option: unknown option %d", option);
+}
+
 int nm_grid_get_info(nm_grid_t g, nm_grid_info* out) {
     if (!g || !out) return nm_fail("nm_grid_get_info: NULL argument");
     out->num_vertices = g->view.V;
@@ -332,16 +349,87 @@ static void* nm_defer_block(nm_grid_t g, hipStream_t stream) {
     return p;
 }
 
+// ---- several chunks in flight (nm_render_cfg.overlap): the device-wide yield state of the pull kernels (nm_kernels.h) and what a call
+// needs to launch them.  One NmYield per device, allocated on first use and never freed (33 KB); every stream of the process shares it.
+struct NmOverlap {
+    NmYield* y = nullptr;                 // nullptr: overlap mode off for this call
+    unsigned long long* counters = nullptr;   // packet counters of this call's K-NN launches (in the caller's workspace, zeroed at the start of the call)
+    int used = 0;                         // counters handed out so far
+    int cap = 1, simds = 1024, prio = 0;
+};
+#define NM_PULL_COUNTERS 16
+static int nm_yield_state(NmYield** out, int* simds) {
+    static std::mutex mu;
+    static NmYield* per_dev[64] = {nullptr};
+    static int simd_count[64] = {0};
+    int dev = 0;
+    NM_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return nm_fail("overlap mode: device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(mu);
+    if (!per_dev[dev]) {
+        NmYield* y = nullptr;
+        NM_HIP(hipMalloc((void**)&y, sizeof(NmYield)));
+        NM_HIP(hipMemset(y, 0, sizeof(NmYield)));
+        hipDeviceProp_t prop;
+        NM_HIP(hipGetDeviceProperties(&prop, dev));
+        simd_count[dev] = 4 * (prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+        per_dev[dev] = y;
+    }
+    *out = per_dev[dev];
+    *simds = simd_count[dev];
+    return 0;
+}
+static NmPull nm_pull_for(NmOverlap* ov, long long npackets) {
+    NmPull pl;
+    pl.next = ov->counters + (ov->used++ % NM_PULL_COUNTERS);
+    pl.npackets = npackets;
+    pl.y = ov->y;
+    pl.cap = ov->cap;
+    return pl;
+}
+static inline unsigned nm_pull_grid(const NmOverlap* ov, long long npackets, int waves_per_simd) {
+    const long long full = (long long)ov->simds * waves_per_simd;
+    return (unsigned)(npackets < full ? npackets : full);
+}
+// an MLP launch of a call in overlap mode: announce it (the pull waves of the other chunks make room), launch, withdraw
+struct NmWantRoom {
+    NmYield* y;
+    hipStream_t s;
+    NmWantRoom(const NmOverlap* ov, hipStream_t stream) : y(ov ? ov->y : nullptr), s(stream) {
+        if (y) hipLaunchKernelGGL(nm_yield_add_kernel, dim3(1), dim3(1), 0, s, y, 1);
+    }
+    ~NmWantRoom() {
+        if (y) hipLaunchKernelGGL(nm_yield_add_kernel, dim3(1), dim3(1), 0, s, y, -1);
+    }
+};
+
+// work budget of small launches: the build's constant unless the index was given its own (nm_grid_set_option)
+static int nm_defer_budget(nm_grid_t g) {
+    const int b = g->defer_budget.load(std::memory_order_relaxed);
+    return b >= 0 ? b : NM_DEFER_BUDGET;
+}
+
 static int nm_launch_distance(nm_grid_t g, const NmPointSrc& src_in, long long Q, const float* indicator, float w1,
                               float* ds, int* idx32, long long* idx64, float* w, float* grad, hipStream_t stream,
-                              float* radius = nullptr, NmGather ga = NM_NO_GATHER, bool counted = false) {
+                              float* radius = nullptr, NmGather ga = NM_NO_GATHER, bool counted = false, NmOverlap* ov = nullptr) {
     if (Q <= 0) return 0;
     NmProfScope prof(NM_K_DISTANCE, counted ? 0 : Q, stream, counted ? NM_CNT_MID : NM_CNT_NONE);
     NmPointSrc src = src_in;
     src.budget = 0;
+    if (ov && ov->y && src.mode != 0) {   // pull form: one-wave workgroups draw the launch's packets from a counter
+        const long long packets = (long long)nm_query_blocks(src, Q) * 4;
+        const NmPull pl = nm_pull_for(ov, packets);
+        if (nm_chain_len(src) > 1)
+            hipLaunchKernelGGL(nm_distance_pull_kernel<true>, dim3(nm_pull_grid(ov, packets, NM_KNN_WAVES_CHAIN)), dim3(64), 0, stream, g->view, src, Q, pl, g->verts,
+                               indicator, w1, ds, idx32, idx64, w, grad, radius, ga.geo_table, ga.gdim, ga.fg, ga.col_table, ga.cdim, ga.ft);
+        else
+            hipLaunchKernelGGL(nm_distance_pull_kernel<false>, dim3(nm_pull_grid(ov, packets, NM_KNN_WAVES)), dim3(64), 0, stream, g->view, src, Q, pl, g->verts,
+                               indicator, w1, ds, idx32, idx64, w, grad, radius, ga.geo_table, ga.gdim, ga.fg, ga.col_table, ga.cdim, ga.ft);
+        NM_LAUNCH_CHECK();
+        return 0;
+    }
     if (Q <= NM_DEFER_MAX_Q && nm_chain_len(src) <= 1 && !src.order) {
-        const char* e = getenv("NEUMESH_KNN_BUDGET");
-        const int budget = e ? atoi(e) : NM_DEFER_BUDGET;
+        const int budget = nm_defer_budget(g);
         char* blk = budget > 0 ? (char*)nm_defer_block(g, stream) : nullptr;
         if (blk) {
             src.budget = budget;
@@ -639,12 +727,14 @@ static const NmSlotMap NM_NO_SLOTS = {nullptr, 0, 0, 0};
 
 static int nm_launch_geo(nm_field_t f, const float* fg, const float* ds, const float* grad, long long P, bool nabla,
                          float* sdf, int Pper, int stride, int off, float* nabla_out, hipStream_t stream,
-                         NmRecMap rmap = NM_COMPACT, int nabla_slotted = 0, NmSlotMap smap = NM_NO_SLOTS, bool counted = false) {
+                         NmRecMap rmap = NM_COMPACT, int nabla_slotted = 0, NmSlotMap smap = NM_NO_SLOTS, bool counted = false, const NmOverlap* ov = nullptr) {
     if (P <= 0) return 0;
     NmProfScope prof(nabla ? NM_K_GEO_NABLA : NM_K_GEO, counted ? 0 : P, stream, counted ? NM_CNT_MID : NM_CNT_NONE);
+    NmWantRoom room(ov, stream);
+    const int prio = ov ? ov->prio : 0;
     if (f->precision == 2) {
         const dim3 gr(nm_blocks(P, nabla ? 32 : 64)), bl(NM_H_THREADS);
-#define NM_GEO_H2(NB, FX, NP) hipLaunchKernelGGL((nm_geo_mlp_h2_kernel<NB, FX, NP>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow)
+#define NM_GEO_H2(NB, FX, NP) hipLaunchKernelGGL((nm_geo_mlp_h2_kernel<NB, FX, NP>), gr, bl, 0, stream, f->geo_h2, fg, ds, grad, rmap, P, sdf, Pper, stride, off, nabla_out, nabla_slotted, smap, f->overflow, prio)
         if (f->geo_np == 3) {
             if (nabla && f->geo_fixed) NM_GEO_H2(true, true, 3);
             else if (nabla) NM_GEO_H2(true, false, 3);
@@ -677,11 +767,13 @@ static int nm_launch_geo(nm_field_t f, const float* fg, const float* ds, const f
 }
 
 static int nm_launch_col(nm_field_t f, const float* ft, const float* ds, const float* nabla, const float* dirs, int dir_div,
-                         long long P, float* rgb, hipStream_t stream, NmSlotMap smap = NM_NO_SLOTS, bool counted = false) {
+                         long long P, float* rgb, hipStream_t stream, NmSlotMap smap = NM_NO_SLOTS, bool counted = false, const NmOverlap* ov = nullptr) {
     if (P <= 0) return 0;
     NmProfScope prof(NM_K_COLOR, counted ? 0 : P, stream, counted ? NM_CNT_MID : NM_CNT_NONE);
+    NmWantRoom room(ov, stream);
+    const int prio = ov ? ov->prio : 0;
     if (f->precision == 2) {
-#define NM_COL_H2(FX, NP) hipLaunchKernelGGL((nm_col_mlp_h2_kernel<FX, NP>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h2, ft, ds, nabla, dirs, dir_div, P, rgb, smap, f->overflow)
+#define NM_COL_H2(FX, NP) hipLaunchKernelGGL((nm_col_mlp_h2_kernel<FX, NP>), dim3(nm_blocks(P, 64)), dim3(NM_H_THREADS), 0, stream, f->col_h2, ft, ds, nabla, dirs, dir_div, P, rgb, smap, f->overflow, prio)
         if (f->col_np == 3) {
             if (f->col_fixed) NM_COL_H2(true, 3);
             else NM_COL_H2(false, 3);
@@ -1022,6 +1114,7 @@ struct NmWorkspace {
     NmScratch pts;    // compact records of the mid-point pass
     float *nab_rot, *dirn_rot;             // texture editing with a rotated reference frame: nablas [pos][3], directions [R][3]
     float *rgb_ref, *edit_w, *edit_share;  // texture editing: reference colours [R][N][3], renormalised painted weights [pos][8], (rest, paint) shares [pos][2]
+    unsigned long long* pull_counters;     // packet counters of the call's pull-form K-NN launches (nm_render_cfg.overlap), NM_PULL_COUNTERS of them
     size_t bytes;
 };
 static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) {
@@ -1030,6 +1123,7 @@ static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) 
     char* p = (char*)base;
     size_t o = 0;
     auto take = [&](size_t bytes) { char* r = p + o; o += nm_align(bytes); return r; };
+    w.pull_counters = (unsigned long long*)take(NM_PULL_COUNTERS * sizeof(unsigned long long));
     w.rays_o_s = (float*)take((size_t)R * 12);
     w.rays_d_s = (float*)take((size_t)R * 12);
     w.key_in = (unsigned*)take((size_t)R * 4);
@@ -1094,6 +1188,8 @@ static int nm_check_cfg(const nm_render_cfg* c) {
     if (c->N_importance > 0 && (c->N_upsample_iters < 1 || c->N_importance % c->N_upsample_iters)) return nm_fail("nm_render: N_importance %% N_upsample_iters != 0");
     if (c->bounded_near_far && (c->probe_grid < 2 || c->probe_grid > 4096)) return nm_fail("nm_render: probe_grid=%d", c->probe_grid);
     if (c->n_edit < 0 || c->n_edit > NM_MAX_EDIT) return nm_fail("nm_render: n_edit=%d (0..%d)", c->n_edit, NM_MAX_EDIT);
+    if (c->overlap < 0 || c->overlap > 1 || c->knn_keep < 0 || c->knn_keep > 8 || c->mlp_prio < 0 || c->mlp_prio > 3)
+        return nm_fail("nm_render: overlap=%d knn_keep=%d mlp_prio=%d (0..1, 0..8, 0..3)", c->overlap, c->knn_keep, c->mlp_prio);
     for (int i = 0; i < c->n_edit; ++i)
         if (!c->edit_field[i] || !c->edit_mask[i] || !c->edit_color_features) return nm_fail("nm_render: texture editing: NULL reference field / mask / colour table");
     return 0;
@@ -1127,6 +1223,16 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     const NmWorkspace ws = nm_carve_ws(workspace, c, R);
     const int N = c->N_samples + c->N_importance, cap = N;
     const dim3 rgrid(nm_blocks(R, 64)), rblock(64);
+    // several chunks in flight (cfg.overlap): pull-form K-NN launches that yield to the other chunks' MLP launches (nm_kernels.h)
+    NmOverlap ov_state, *ov = nullptr;
+    if (c->overlap) {
+        if (nm_yield_state(&ov_state.y, &ov_state.simds)) return 1;
+        ov_state.counters = ws.pull_counters;
+        ov_state.cap = c->knn_keep > 0 ? c->knn_keep : 1;
+        ov_state.prio = c->mlp_prio;
+        NM_HIP(hipMemsetAsync(ws.pull_counters, 0, NM_PULL_COUNTERS * sizeof(unsigned long long), stream));
+        ov = &ov_state;
+    }
     const dim3 rblock_io(NM_RAY_IO_THREADS);   // upsample / finalize: 64 rays per workgroup, every thread moves rows between HBM and LDS
 
     // processing order: rays sorted by the Morton code of their closest approach to the scene centre (see
@@ -1157,6 +1263,12 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
         if (!(c->flags & NM_RENDER_FULL_PROBES)) {  // first / last hit only (nm_probe_bounds_kernel)
             NmProfScope prof(NM_K_DISTANCE, 0, stream, NM_CNT_PROBE);  // units = probes actually searched (device counter)
             static_assert(NM_PROBE_STEP == 8, "launch geometry below is for 8 probes per ray and step");
+            if (ov) {
+                const long long packets = (R + 7) / 8;
+                hipLaunchKernelGGL(nm_probe_bounds_pull_kernel<8>, dim3(nm_pull_grid(ov, packets, NM_KNN_WAVES_PROBE)), dim3(64), 0, stream, g->view, nm_pull_for(ov, packets),
+                                   rays_o, ws.dirn, ws.nf0, (long long)R, c->probe_grid, c->probe_thresh, g->verts, t->indicator_vector, t->indicator_weight, ws.nf,
+                                   nm_prof_counter(NM_CNT_PROBE));
+            } else
             hipLaunchKernelGGL(nm_probe_bounds_kernel<8>, dim3(nm_blocks((R + 7) / 8, 4)), dim3(256), 0, stream, g->view, rays_o, ws.dirn, ws.nf0,
                                    (long long)R, c->probe_grid, c->probe_thresh, g->verts, t->indicator_vector, t->indicator_weight, ws.nf,
                                    nm_prof_counter(NM_CNT_PROBE));
@@ -1170,7 +1282,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
             src.bound = nullptr;
             src.out_stride = 0;
             src.out_off = 0;
-            if (nm_launch_distance(g, src, (long long)R * c->probe_grid, t->indicator_vector, t->indicator_weight, ws.probe, nullptr, nullptr, nullptr, nullptr, stream)) return 1;
+            if (nm_launch_distance(g, src, (long long)R * c->probe_grid, t->indicator_vector, t->indicator_weight, ws.probe, nullptr, nullptr, nullptr, nullptr, stream, nullptr, NM_NO_GATHER, false, ov)) return 1;
             hipLaunchKernelGGL(nm_rays_bounds_kernel, rgrid, rblock, 0, stream, ws.probe, (long long)R, c->probe_grid, c->probe_thresh, ws.nf0, ws.nf);
             NM_LAUNCH_CHECK();
         }
@@ -1206,7 +1318,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     src.bound = nullptr;
     src.out_stride = cap;
     src.out_off = 0;
-    if (nm_launch_distance(g, src, (long long)R * c->N_samples, t->indicator_vector, t->indicator_weight, ws.slots.ds, nullptr, nullptr, nullptr, want_grad ? ws.slots.grad : nullptr, stream, ws.radius, ga_slots)) return 1;
+    if (nm_launch_distance(g, src, (long long)R * c->N_samples, t->indicator_vector, t->indicator_weight, ws.slots.ds, nullptr, nullptr, nullptr, want_grad ? ws.slots.grad : nullptr, stream, ws.radius, ga_slots, false, ov)) return 1;
     // With normals requested the sampling passes already run the tangent form of the geometry MLP:
     // forward_with_nablas(pts) (renderer.py:271-276) is evaluated at exactly these points, and the
     // value rows of the tangent kernel are bit-identical to the forward-only kernel, so the nablas
@@ -1216,7 +1328,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     float* nab_slot = eager_nabla ? ws.nab_mid : nullptr;
     {
         const NmRecMap rm = {c->N_samples, cap, 0, nullptr, 0};
-        if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, want_grad ? ws.slots.grad : nullptr, (long long)R * c->N_samples, eager_nabla, ws.sdf, c->N_samples, cap, 0, nab_slot, stream, rm, 1)) return 1;
+        if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, want_grad ? ws.slots.grad : nullptr, (long long)R * c->N_samples, eager_nabla, ws.sdf, c->N_samples, cap, 0, nab_slot, stream, rm, 1, NM_NO_SLOTS, false, ov)) return 1;
     }
     if (dbg && dbg->sdf_coarse) {
         hipLaunchKernelGGL(nm_rows_out_kernel, dim3(nm_blocks(R * c->N_samples, 256)), dim3(256), 0, stream, ws.sdf, (long long)R, c->N_samples, cap, perm, dbg->sdf_coarse);
@@ -1251,9 +1363,9 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
                 src.order = ws.order;
                 src.order_rays = fine_g;
             }
-            if (nm_launch_distance(g, src, (long long)R * n_new, t->indicator_vector, t->indicator_weight, ws.slots.ds, nullptr, nullptr, nullptr, want_grad ? ws.slots.grad : nullptr, stream, ws.radius, ga_slots)) return 1;
+            if (nm_launch_distance(g, src, (long long)R * n_new, t->indicator_vector, t->indicator_weight, ws.slots.ds, nullptr, nullptr, nullptr, want_grad ? ws.slots.grad : nullptr, stream, ws.radius, ga_slots, false, ov)) return 1;
             const NmRecMap rm = {n_new, cap, n, nullptr, 0};
-            if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, want_grad ? ws.slots.grad : nullptr, (long long)R * n_new, eager_nabla, ws.sdf, n_new, cap, n, nab_slot, stream, rm, 1)) return 1;
+            if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, want_grad ? ws.slots.grad : nullptr, (long long)R * n_new, eager_nabla, ws.sdf, n_new, cap, n, nab_slot, stream, rm, 1, NM_NO_SLOTS, false, ov)) return 1;
             n += n_new;
             pending = n_new;
         }
@@ -1309,7 +1421,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     if (want_grad && !eager_nabla) {
         if (!(use_order && skip_zero)) return nm_fail("nm_render_rays: internal: lazy nablas need the zero-weight list");
         const NmRecMap rm = {N - 1, cap, 0, ws.slot, 1};
-        if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, ws.slots.grad, mid_pts, true, nullptr, 1, N, 0, ws.nab_pts, stream, rm, 1, smap, true)) return 1;
+        if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, ws.slots.grad, mid_pts, true, nullptr, 1, N, 0, ws.nab_pts, stream, rm, 1, smap, true, ov)) return 1;
     }
     src.mode = 1;
     src.P = N - 1;
@@ -1322,10 +1434,10 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     {
         const NmGather ga_mid = {t->geometry_features, f->geo.gdim, ws.pts.fg, t->color_features, f->col.cdim, ws.pts.ft};
         if (nm_launch_distance(g, src, (long long)R * (N - 1), t->indicator_vector, t->indicator_weight, ws.pts.ds, c->n_edit > 0 ? ws.pts.idx : nullptr, nullptr,
-                               c->n_edit > 0 ? ws.pts.w : nullptr, ws.pts.grad, stream, nullptr, ga_mid, skip_zero)) return 1;
+                               c->n_edit > 0 ? ws.pts.w : nullptr, ws.pts.grad, stream, nullptr, ga_mid, skip_zero, ov)) return 1;
     }
-    if (nm_launch_geo(f, ws.pts.fg, ws.pts.ds, ws.pts.grad, mid_pts, true, nullptr, 1, 1, 0, ws.nab_mid, stream, NM_COMPACT, 0, smap, skip_zero)) return 1;
-    if (nm_launch_col(f, ws.pts.ft, ws.pts.ds, ws.nab_mid, ws.dirn, N - 1, mid_pts, ws.rgb_mid, stream, smap, skip_zero)) return 1;
+    if (nm_launch_geo(f, ws.pts.fg, ws.pts.ds, ws.pts.grad, mid_pts, true, nullptr, 1, 1, 0, ws.nab_mid, stream, NM_COMPACT, 0, smap, skip_zero, ov)) return 1;
+    if (nm_launch_col(f, ws.pts.ft, ws.pts.ds, ws.nab_mid, ws.dirn, N - 1, mid_pts, ws.rgb_mid, stream, smap, skip_zero, ov)) return 1;
     // Texture editing (texture_neumesh.py:79-121): per reference model, the painted share of every mid-point's interpolation
     // weight, the reference colour from the edited colour table under the painted neighbours' renormalised weights, the blend.
     for (int e = 0; e < c->n_edit; ++e) {
@@ -1341,7 +1453,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
             hipLaunchKernelGGL(nm_rotate_rows3_kernel, dim3(nm_blocks(R, 256)), dim3(256), 0, stream, (long long)R, rm, ws.dirn, ws.dirn_rot);
             NM_LAUNCH_CHECK();
         }
-        if (nm_launch_col(rf, ws.pts.fg, ws.pts.ds, rot ? ws.nab_rot : ws.nab_mid, rot ? ws.dirn_rot : ws.dirn, N - 1, mid_pts, ws.rgb_ref, stream, smap, skip_zero)) return 1;
+        if (nm_launch_col(rf, ws.pts.fg, ws.pts.ds, rot ? ws.nab_rot : ws.nab_mid, rot ? ws.dirn_rot : ws.dirn, N - 1, mid_pts, ws.rgb_ref, stream, smap, skip_zero, ov)) return 1;
         hipLaunchKernelGGL(nm_edit_blend_kernel, dim3(nm_blocks(mid_pts, 256)), dim3(256), 0, stream, mid_pts, smap, N - 1, ws.edit_share, ws.rgb_ref, ws.rgb_mid);
         NM_LAUNCH_CHECK();
     }
@@ -1774,6 +1886,20 @@ int nm_debug_last_deferred(nm_grid_t g, int* count, nm_stream_t stream_) {
     if (!blk) return 0;
     NM_HIP(hipMemcpyAsync(count, blk, sizeof(int), hipMemcpyDeviceToHost, stream));
     NM_HIP(hipStreamSynchronize(stream));
+    return 0;
+}
+
+// nm_simd_key() of `n` one-wave workgroups (each holds its SIMD for a few microseconds so that the launch spreads over the chip): the
+// pull kernels count their resident waves per SIMD by this key, so a full launch must show 4 x CUs distinct values
+__global__ __launch_bounds__(64) void nm_debug_simd_key_kernel(int* __restrict__ out) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < 2000) __builtin_amdgcn_s_sleep(8);   // 100 MHz counter: 20 us
+    if (threadIdx.x == 0) out[blockIdx.x] = nm_simd_key();
+}
+int nm_debug_simd_keys(int* out_device, int n, nm_stream_t stream_) {
+    if (!out_device || n < 1) return nm_fail("nm_debug_simd_keys: bad arguments");
+    hipLaunchKernelGGL(nm_debug_simd_key_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream_, out_device);
+    NM_LAUNCH_CHECK();
     return 0;
 }
 

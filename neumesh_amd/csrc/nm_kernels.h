@@ -168,7 +168,7 @@ __device__ __forceinline__ float nm_wave_max(float v) {
 
 // BUDGET: returns true (nothing in kk is final then) as soon as the traversal has spent `budget` work units -- see NmPointSrc.budget.
 // SUB: the traversal covers the subtree of the INTERNAL node `top` only (never climbs above it).
-template <int K, bool BUDGET = false, bool SUB = false>
+template <int K, bool BUDGET = false, bool SUB = false, int BLK = NM_KNN_BLOCK>
 __device__ __forceinline__ bool nm_knn_search_packet(const NmGridView& g, float qx, float qy, float qz, bool active,
                                                      float rx, float ry, float rz, unsigned long long (&kk)[K], float init_d2, int budget = 0,
                                                      uint32_t top = 0u) {
@@ -229,9 +229,9 @@ __device__ __forceinline__ bool nm_knn_search_packet(const NmGridView& g, float 
             // scores them from LDS (same-address reads: broadcast).  A/B on the 800x800 frame, same call: scalar-path scan
             // (s_load_dwordx16 = 4 vertices per dependent load) 103.2 ms of K-NN per frame, this 100.9, vector load +
             // v_readlane broadcast 115.5; the leaf level keeps its optimum (~32 vertices per leaf: 101 vs 127-130 ms at ~120).
-            __shared__ float4 nm_leaf_lds[NM_KNN_BLOCK / 64][64];  // one stage per wave: every kernel that traverses is compiled
+            __shared__ float4 nm_leaf_lds[BLK / 64][64];  // one stage per wave: every kernel that traverses is compiled
             float4* stage = nm_leaf_lds[threadIdx.x >> 6];
-            const nm_f32x2 qyz = {qy, qz};          // with __launch_bounds__(NM_KNN_BLOCK) and launched with that block size
+            const nm_f32x2 qyz = {qy, qz};          // with __launch_bounds__(BLK) and launched with that block size (NM_KNN_BLOCK; 64 for the pull kernels)
             const uint32_t ln = threadIdx.x & 63u;
             if (BUDGET) work += single ? 8 * (int)((crec.end - crec.first + 63u) >> 6) : 7 * (int)(crec.end - crec.first);
             if (single) {
@@ -290,7 +290,7 @@ __device__ __forceinline__ bool nm_knn_search_packet(const NmGridView& g, float 
 // active=false).  Picks the cooperative traversal when the wave's queries are compact
 // (bounding-box extent below a fraction of the root cube), lane-private traversals otherwise
 // (e.g. randomly scattered points through the point-wise API).
-template <int K, bool BUDGET = false>
+template <int K, bool BUDGET = false, int BLK = NM_KNN_BLOCK>
 __device__ __forceinline__ bool nm_knn_wave(const NmGridView& g, float qx, float qy, float qz, bool active,
                                             unsigned long long (&kk)[K], float init_d2 = NM_INF_F, int budget = 0) {
     // inactive lanes borrow an active lane's position so that they do not stretch the box
@@ -304,7 +304,7 @@ __device__ __forceinline__ bool nm_knn_wave(const NmGridView& g, float qx, float
     const float loz = nm_wave_min(pz), hiz = nm_wave_max(pz);
     const float ext = nm_uniform_f(fmaxf(fmaxf(hix - lox, hiy - loy), hiz - loz));
     if (ext <= g.coop_extent) {
-        return nm_knn_search_packet<K, BUDGET>(g, qx, qy, qz, active, nm_uniform_f(0.5f * (lox + hix)), nm_uniform_f(0.5f * (loy + hiy)),
+        return nm_knn_search_packet<K, BUDGET, false, BLK>(g, qx, qy, qz, active, nm_uniform_f(0.5f * (lox + hix)), nm_uniform_f(0.5f * (loy + hiy)),
                                                nm_uniform_f(0.5f * (loz + hiz)), kk, init_d2, budget);
     } else if (active) {
         nm_knn_search<K>(g, qx, qy, qz, kk, nullptr, init_d2);
@@ -324,8 +324,9 @@ __device__ __forceinline__ bool nm_knn_wave(const NmGridView& g, float qx, float
 #endif
 #define NM_TILE_RAYS (64 / NM_TILE_SAMPLES)
 __host__ __device__ __forceinline__ int nm_chain_len(const NmPointSrc& s) { return (s.mode == 2 && !s.order && s.chain > 1) ? s.chain : 1; }
-__device__ __forceinline__ bool nm_lane_query(const NmPointSrc& s, long long Q, long long& q, long long& r, int& p, int it = 0) {
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+// `wave`: index of the 64-query packet within the launch (nm_launch_wave(): the wave's position in the grid; the pull kernels draw it from a counter)
+__device__ __forceinline__ long long nm_launch_wave() { return ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; }
+__device__ __forceinline__ bool nm_lane_query(const NmPointSrc& s, long long Q, long long& q, long long& r, int& p, int it, long long wave) {
     const int lane = threadIdx.x & 63;
     if (s.mode == 0) {
         const int L = s.lanes > 0 ? s.lanes : 64;
@@ -427,7 +428,8 @@ __global__ __launch_bounds__(256) void nm_interp_kernel(const float* __restrict_
 // The neighbour lists live in LDS ([k][thread of the workgroup]) rather than in eight loop-carried registers per lane read through eight
 // cross-lane shuffles: the chained kernels write a lane's list after every search and read the list of the lane they warm-start
 // from (same wave: DS operations of a wave execute in order, no barrier needed).
-__device__ __forceinline__ float nm_bound_from_neighbours_lds(const float* __restrict__ verts, const int (*nbr)[NM_KNN_BLOCK], int src_thread,
+template <int BLK>
+__device__ __forceinline__ float nm_bound_from_neighbours_lds(const float* __restrict__ verts, const int (*nbr)[BLK], int src_thread,
                                                               bool usable, float x, float y, float z) {
     float worst = 0.f;
     bool ok = usable;
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(NM_KNN_BLOCK) void nm_knn_kernel(NmGridView g, NmPo
                                                      long long* __restrict__ idx_out, float* __restrict__ d2_out) {
     long long q, r;
     int p;
-    const bool active = nm_lane_query(src, Q, q, r, p);
+    const bool active = nm_lane_query(src, Q, q, r, p, 0, nm_launch_wave());
     float x = 0.f, y = 0.f, z = 0.f, dep = 0.f;
     if (active) nm_fetch_point(src, r, p, x, y, z, dep);
     unsigned long long kk[K];
@@ -472,7 +474,8 @@ __global__ __launch_bounds__(NM_KNN_BLOCK) void nm_knn_kernel(NmGridView g, NmPo
 // Occupancy: NM_KNN_WAVES / NM_KNN_WAVES_CHAIN above.
 // The outputs of one query from its neighbour keys (everything behind the search): shared by the traversal kernels and by the kernel
 // that answers the deferred queries.  The whole wave calls it (the code gather is wave-cooperative).
-__device__ __forceinline__ void nm_distance_finish(const NmPointSrc& src, bool active, long long q, long long r, int p, float x, float y, float z,
+// `list_pos`: position of this lane's query in the launch's lane list (packet index * 64 + lane): the record index of launches that store by list position
+__device__ __forceinline__ void nm_distance_finish(const NmPointSrc& src, bool active, long long q, long long r, int p, long long list_pos, float x, float y, float z,
                                                    const float (&bd)[8], int (&bi)[8],   // squared distances, indices (bi is scratch afterwards)
                                                    const float* __restrict__ verts, const float* __restrict__ indicator, float w1,
                                                    float* __restrict__ ds_out, int* __restrict__ idx32_out, long long* __restrict__ idx64_out,
@@ -484,7 +487,7 @@ __device__ __forceinline__ void nm_distance_finish(const NmPointSrc& src, bool a
     long long o = 0;
     if (active) {
         ds = nm_projected_distance8(x, y, z, bd, bi, verts, indicator, w1, wk, grad_out ? gr : nullptr);
-        o = (src.order && src.out_by_slot) ? (long long)blockIdx.x * blockDim.x + threadIdx.x : nm_out_index(src, q, r, p);
+        o = (src.order && src.out_by_slot) ? list_pos : nm_out_index(src, q, r, p);
     } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -516,16 +519,17 @@ __device__ __forceinline__ void nm_distance_finish(const NmPointSrc& src, bool a
     }
 }
 
-template <bool CHAIN, bool BUDGET = false>
-__global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_WAVES) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
-                                                          const float* __restrict__ verts,
-                                                          const float* __restrict__ indicator, float w1,
-                                                          float* __restrict__ ds_out, int* __restrict__ idx32_out,
-                                                          long long* __restrict__ idx64_out,
-                                                          float* __restrict__ w_out, float* __restrict__ grad_out,
-                                                          float* __restrict__ radius_out,
-                                                          const float* __restrict__ geo_table, int gdim, float* __restrict__ fg_out,
-                                                          const float* __restrict__ col_table, int cdim, float* __restrict__ ft_out) {
+// nm_distance_body: the work of ONE wave on packet `wave` of the launch.  BLK = threads of the calling kernel's workgroup (sizes the LDS arrays).
+template <bool CHAIN, bool BUDGET, int BLK>
+__device__ __forceinline__ void nm_distance_body(const NmGridView& g, const NmPointSrc& src, long long Q, long long wave,
+                                                 const float* __restrict__ verts,
+                                                 const float* __restrict__ indicator, float w1,
+                                                 float* __restrict__ ds_out, int* __restrict__ idx32_out,
+                                                 long long* __restrict__ idx64_out,
+                                                 float* __restrict__ w_out, float* __restrict__ grad_out,
+                                                 float* __restrict__ radius_out,
+                                                 const float* __restrict__ geo_table, int gdim, float* __restrict__ fg_out,
+                                                 const float* __restrict__ col_table, int cdim, float* __restrict__ ft_out) {
     // Chained tiles (regular depth grids: probes, coarse samples): the wave walks `chain` consecutive
     // 4-sample tiles of its 16 rays; from the second tile on every lane starts its search from a
     // proven bound -- the K-th-neighbour radius of the LAST sample of the previous tile on the same
@@ -537,11 +541,11 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_W
     const int chain = CHAIN ? nm_chain_len(src) : 1;
     const int lane = threadIdx.x & 63;
     float prev_rad = NM_INF_F, prev_dep = 0.f;
-    __shared__ int prev_bi[CHAIN ? 8 : 1][NM_KNN_BLOCK];   // neighbours of each lane's previous sample (chained tiles only)
+    __shared__ int prev_bi[CHAIN ? 8 : 1][CHAIN ? BLK : 64];   // neighbours of each lane's previous sample (chained tiles only)
     for (int it = 0; it < chain; ++it) {
         long long q, r;
         int p;
-        const bool active = nm_lane_query(src, Q, q, r, p, it);
+        const bool active = nm_lane_query(src, Q, q, r, p, it, wave);
         float x = 0.f, y = 0.f, z = 0.f, dep = 0.f, init = NM_INF_F;
         if (active) {
             nm_fetch_point(src, r, p, x, y, z, dep);
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_W
         int bi[8];
         unsigned long long kk[8];
         if (BUDGET) {
-            if (nm_knn_wave<8, true>(g, x, y, z, active, kk, init, src.budget)) {   // (wave-uniform) over budget: hand the queries on
+            if (nm_knn_wave<8, true, BLK>(g, x, y, z, active, kk, init, src.budget)) {   // (wave-uniform) over budget: hand the queries on
                 const unsigned long long am = __builtin_amdgcn_ballot_w64(active);
                 const int n = __popcll(am);
                 int old = 0;
@@ -578,10 +582,10 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_W
                 // the list is full: finish here after all.  What this wave reserved inside the list stays empty (-1) -- the counter has
                 // moved past it, and the slots would otherwise hold entries of an earlier launch
                 if (active && old + __popcll(am & ((1ull << lane) - 1ull)) < src.defer_cap) src.defer_list[old + __popcll(am & ((1ull << lane) - 1ull))] = -1;
-                nm_knn_wave<8>(g, x, y, z, active, kk, init);
+                nm_knn_wave<8, false, BLK>(g, x, y, z, active, kk, init);
             }
         } else {
-            nm_knn_wave<8>(g, x, y, z, active, kk, init);
+            nm_knn_wave<8, false, BLK>(g, x, y, z, active, kk, init);
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -594,13 +598,102 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_W
 #pragma unroll
             for (int k = 0; k < 8; ++k) prev_bi[k][threadIdx.x] = active ? bi[k] : 0x7fffffff;
         }
-        nm_distance_finish(src, active, q, r, p, x, y, z, bd, bi, verts, indicator, w1, ds_out, idx32_out, idx64_out, w_out, grad_out, radius_out,
+        nm_distance_finish(src, active, q, r, p, wave * 64 + lane, x, y, z, bd, bi, verts, indicator, w1, ds_out, idx32_out, idx64_out, w_out, grad_out, radius_out,
                            geo_table, gdim, fg_out, col_table, cdim, ft_out);
     }
 #ifdef NM_TESTING
-    nm_wave_log_write(nm_t0, ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    nm_wave_log_write(nm_t0, wave);
 #endif
 }
+
+template <bool CHAIN, bool BUDGET = false>
+__global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_WAVES) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
+                                                          const float* __restrict__ verts,
+                                                          const float* __restrict__ indicator, float w1,
+                                                          float* __restrict__ ds_out, int* __restrict__ idx32_out,
+                                                          long long* __restrict__ idx64_out,
+                                                          float* __restrict__ w_out, float* __restrict__ grad_out,
+                                                          float* __restrict__ radius_out,
+                                                          const float* __restrict__ geo_table, int gdim, float* __restrict__ fg_out,
+                                                          const float* __restrict__ col_table, int cdim, float* __restrict__ ft_out) {
+    nm_distance_body<CHAIN, BUDGET, NM_KNN_BLOCK>(g, src, Q, nm_launch_wave(), verts, indicator, w1, ds_out, idx32_out, idx64_out, w_out, grad_out, radius_out,
+                                                  geo_table, gdim, fg_out, col_table, cdim, ft_out);
+}
+
+// ------------------------------------------------------------------------------ pull kernels (K-NN beside the MLP kernels of another ray chunk)
+// The K-NN kernels are bound by vector-instruction issue, the MLP kernels by the matrix pipe, and the two pipes of a SIMD run side by side
+// (MI355X_MICROARCH.md, wave scheduling).  When a call is rendered as several ray chunks on several streams, one chunk's K-NN kernels can therefore
+// run UNDER another chunk's MLP kernels -- if both are resident on the same SIMDs: two MLP workgroups per CU leave 512 - 2 x 192 = 128 registers per
+// SIMD lane and 16 KB (geometry) / 8 KB (colour) of LDS, room for exactly one K-NN wave per SIMD.  A grid-mapped K-NN launch never leaves that
+// room: its own pending workgroups refill every slot its waves free, and an MLP workgroup (192 registers on all four SIMDs of ONE CU + 72 KB of LDS at
+// once) starves until the K-NN grid is exhausted.  The pull form:
+//   * workgroup = ONE wave (64 threads: its registers and its 1.25 / 3 KB of LDS are freed the moment it exits); the launch has at most
+//     (SIMDs of the chip) x (waves per SIMD the kernel is compiled for) of them, and every wave draws packet indices from a counter until none are left;
+//   * NmYield (one per device, shared by all streams): `wanted` = MLP launches queued or running (raised / lowered by one-thread kernels around
+//     them), occ[simd] = pull waves resident on that SIMD (from HW_REG_HW_ID / HW_REG_XCC_ID);
+//   * while wanted > 0 a SIMD keeps at most `cap` pull waves: the others exit before their next packet, a wave that arrives on a full SIMD exits at
+//     once -- so the MLP workgroups find room within one packet's time (~0.1 ms), wherever the launch order put them;
+//   * with wanted == 0 the launch fills the chip like the grid-mapped form.
+// Which wave evaluates which packet changes no result bit (every packet's outputs depend on its own queries only).
+struct NmYield {
+    int wanted;          // MLP launches that want room (queued or running)
+    int pad[15];
+    int occ[2048 * 4];   // pull waves per SIMD, index = nm_simd_key()
+};
+struct NmPull {
+    unsigned long long* next;   // packet counter of THIS launch (zeroed by the host, stream-ordered)
+    long long npackets;
+    NmYield* y;                 // nullptr: never yield
+    int cap;                    // pull waves a SIMD keeps while MLP launches want room
+};
+// (xcc, se, sh, cu, simd) of the calling wave -> [0, 8192)
+__device__ __forceinline__ int nm_simd_key() {
+    const unsigned hw = __builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_REG_HW_ID: simd_id [5:4], cu_id [11:8], sh_id [12], se_id [15:13]
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));   // HW_REG_XCC_ID [3:0]
+    return (int)((((xcc & 7u) << 8 | ((hw >> 13) & 7u) << 5 | ((hw >> 12) & 1u) << 4 | ((hw >> 8) & 15u)) << 2) | ((hw >> 4) & 3u));
+}
+// true: this wave leaves (its occ entry is already given back)
+__device__ __forceinline__ bool nm_pull_should_leave(const NmPull& pl, int key) {
+    if (!pl.y) return false;
+    int leave = 0;
+    if ((threadIdx.x & 63) == 0 && __hip_atomic_load(&pl.y->wanted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
+        __hip_atomic_load(&pl.y->occ[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pl.cap) {
+        if (atomicSub(&pl.y->occ[key], 1) > pl.cap) leave = 1;
+        else atomicAdd(&pl.y->occ[key], 1);
+    }
+    return __builtin_amdgcn_readfirstlane(leave) != 0;
+}
+__device__ __forceinline__ long long nm_pull_next(const NmPull& pl) {
+    unsigned long long w = 0;
+    if ((threadIdx.x & 63) == 0) w = atomicAdd(pl.next, 1ull);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(w & 0xffffffffull)), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(w >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+#define NM_PULL_LOOP(BODY)                                                                           \
+    const int nm_key_ = pl.y ? nm_simd_key() : 0;                                                     \
+    if (pl.y && (threadIdx.x & 63) == 0) atomicAdd(&pl.y->occ[nm_key_], 1);                           \
+    for (;;) {                                                                                        \
+        if (nm_pull_should_leave(pl, nm_key_)) return;                                                \
+        const long long wave = nm_pull_next(pl);                                                      \
+        if (wave >= pl.npackets) break;                                                               \
+        BODY;                                                                                         \
+    }                                                                                                 \
+    if (pl.y && (threadIdx.x & 63) == 0) atomicSub(&pl.y->occ[nm_key_], 1);
+
+template <bool CHAIN>
+__global__ __launch_bounds__(64, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_WAVES) void nm_distance_pull_kernel(NmGridView g, NmPointSrc src, long long Q, NmPull pl,
+                                                          const float* __restrict__ verts,
+                                                          const float* __restrict__ indicator, float w1,
+                                                          float* __restrict__ ds_out, int* __restrict__ idx32_out,
+                                                          long long* __restrict__ idx64_out,
+                                                          float* __restrict__ w_out, float* __restrict__ grad_out,
+                                                          float* __restrict__ radius_out,
+                                                          const float* __restrict__ geo_table, int gdim, float* __restrict__ fg_out,
+                                                          const float* __restrict__ col_table, int cdim, float* __restrict__ ft_out) {
+    NM_PULL_LOOP((nm_distance_body<CHAIN, false, 64>(g, src, Q, wave, verts, indicator, w1, ds_out, idx32_out, idx64_out, w_out, grad_out, radius_out,
+                                                     geo_table, gdim, fg_out, col_table, cdim, ft_out)))
+}
+__global__ void nm_yield_add_kernel(NmYield* y, int delta) { atomicAdd(&y->wanted, delta); }
 
 // ------------------------------------------------------------------------ the deferred queries of a small launch
 // A small launch (a training batch: 10^4 ... 10^5 points) lives as long as its slowest wave, and the slowest waves hold queries near the
@@ -788,7 +881,7 @@ __global__ __launch_bounds__(NM_KNN_BLOCK) void nm_distance_deferred_kernel(NmGr
         bd[k] = nm_key_d2(kk[k]);
         bi[k] = nm_key_idx(kk[k]);
     }
-    nm_distance_finish(src, active, q, r, p, x, y, z, bd, bi, verts, indicator, w1, ds_out, idx32_out, idx64_out, w_out, grad_out, radius_out,
+    nm_distance_finish(src, active, q, r, p, slot, x, y, z, bd, bi, verts, indicator, w1, ds_out, idx32_out, idx64_out, w_out, grad_out, radius_out,
                        geo_table, gdim, fg_out, col_table, cdim, ft_out);
 }
 
@@ -804,14 +897,13 @@ __global__ __launch_bounds__(NM_KNN_BLOCK) void nm_distance_deferred_kernel(NmGr
 // [R,P] probe array.
 // S = probes per ray and step (4: 16 rays per wave, 8: 8 rays per wave -- half as many serial steps per wave, up to 4 more probes
 // per ray and walk; nm_render_rays picks)
-template <int S>
-__global__ __launch_bounds__(NM_KNN_BLOCK, NM_KNN_WAVES_PROBE) void nm_probe_bounds_kernel(NmGridView g, const float* __restrict__ rays_o,
-                                                                 const float* __restrict__ dirn, const float* __restrict__ nearfar0,
-                                                                 long long R, int P, float thresh, const float* __restrict__ verts,
-                                                                 const float* __restrict__ indicator, float w1,
-                                                                 float* __restrict__ nearfar,
-                                                                 unsigned long long* __restrict__ searched) {
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+template <int S, int BLK>
+__device__ __forceinline__ void nm_probe_bounds_body(const NmGridView& g, long long wave, const float* __restrict__ rays_o,
+                                                     const float* __restrict__ dirn, const float* __restrict__ nearfar0,
+                                                     long long R, int P, float thresh, const float* __restrict__ verts,
+                                                     const float* __restrict__ indicator, float w1,
+                                                     float* __restrict__ nearfar,
+                                                     unsigned long long* __restrict__ searched) {
     constexpr int LOG_S = S == 8 ? 3 : 2;
     constexpr unsigned SMASK = (1u << S) - 1u;
     const int lane = threadIdx.x & 63, sub = lane & (S - 1), quad = lane & ~(S - 1);
@@ -827,7 +919,7 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, NM_KNN_WAVES_PROBE) void nm_probe_bou
     int first_idx = -1, last_idx = -1;
     unsigned n_searched = 0;  // probes this wave searched (profiling: one atomic per wave at the end)
     // one step: probe p of this lane's ray; returns ds (and the K-th-neighbour radius for the next warm start)
-    __shared__ int nbr[8][NM_KNN_BLOCK];  // neighbours of each lane's last probe
+    __shared__ int nbr[8][BLK];  // neighbours of each lane's last probe
 #pragma unroll
     for (int k = 0; k < 8; ++k) nbr[k][threadIdx.x] = 0x7fffffff;
     const int wave_base = threadIdx.x & ~63;
@@ -838,7 +930,7 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, NM_KNN_WAVES_PROBE) void nm_probe_bou
         if (src_lane >= 0) init = fminf(init, nm_bound_from_neighbours_lds(verts, nbr, wave_base | src_lane, act, x, y, z));
         if (searched) n_searched += (unsigned)__popcll(__ballot(act));
         unsigned long long kk[8];
-        nm_knn_wave<8>(g, x, y, z, act, kk, init);
+        nm_knn_wave<8, false, BLK>(g, x, y, z, act, kk, init);
         float bd[8], wk[8];
         int bi[8];
 #pragma unroll
@@ -904,6 +996,25 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, NM_KNN_WAVES_PROBE) void nm_probe_bou
         nm_ray_bounds_finish(mn, mx, n0, f0, nearfar + 2 * r, nearfar + 2 * r + 1);
     }
     if (searched && lane == 0 && n_searched) atomicAdd(searched, (unsigned long long)n_searched);
+}
+template <int S>
+__global__ __launch_bounds__(NM_KNN_BLOCK, NM_KNN_WAVES_PROBE) void nm_probe_bounds_kernel(NmGridView g, const float* __restrict__ rays_o,
+                                                                 const float* __restrict__ dirn, const float* __restrict__ nearfar0,
+                                                                 long long R, int P, float thresh, const float* __restrict__ verts,
+                                                                 const float* __restrict__ indicator, float w1,
+                                                                 float* __restrict__ nearfar,
+                                                                 unsigned long long* __restrict__ searched) {
+    nm_probe_bounds_body<S, NM_KNN_BLOCK>(g, nm_launch_wave(), rays_o, dirn, nearfar0, R, P, thresh, verts, indicator, w1, nearfar, searched);
+}
+// pull form (see nm_distance_pull_kernel)
+template <int S>
+__global__ __launch_bounds__(64, NM_KNN_WAVES_PROBE) void nm_probe_bounds_pull_kernel(NmGridView g, NmPull pl, const float* __restrict__ rays_o,
+                                                                 const float* __restrict__ dirn, const float* __restrict__ nearfar0,
+                                                                 long long R, int P, float thresh, const float* __restrict__ verts,
+                                                                 const float* __restrict__ indicator, float w1,
+                                                                 float* __restrict__ nearfar,
+                                                                 unsigned long long* __restrict__ searched) {
+    NM_PULL_LOOP((nm_probe_bounds_body<S, 64>(g, wave, rays_o, dirn, nearfar0, R, P, thresh, verts, indicator, w1, nearfar, searched)))
 }
 
 // ------------------------------------------------------------------------- per-ray kernels

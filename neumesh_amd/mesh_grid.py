@@ -45,10 +45,20 @@ class GridHandle:
         self._h = h
         self.device = v.device
         self.num_vertices = int(v.shape[0])
+        self._budget = None   # NEUMESH_KNN_BUDGET as last handed to the library (the library itself reads no environment)
 
     @property
     def handle(self):
+        import os
+        b = os.environ.get("NEUMESH_KNN_BUDGET")   # tuning / test knob of the small-launch hand-over (nm_grid_set_option)
+        if b != self._budget:
+            _lib.check(_lib.load().nm_grid_set_option(self._h, _lib.GRID_DEFER_BUDGET, int(b) if b not in (None, "") else -1), "nm_grid_set_option")
+            self._budget = b
         return self._h
+
+    def trim(self):
+        """Free the index's deferral scratch (33.7 MB per stream that ran small point-wise launches on it).  Call with the device idle."""
+        _lib.check(_lib.load().nm_grid_set_option(self._h, _lib.GRID_TRIM, 0), "nm_grid_set_option")
 
     def info(self) -> dict:
         gi = _lib.GridInfo()

@@ -69,6 +69,9 @@ def _to_device_async(t: torch.Tensor, device) -> torch.Tensor:
     host AND ordered in the stream, i.e. it waits for everything queued before it; a copy from pinned memory is just queued."""
     if t.device.type == "cuda":
         return t
+    if not torch.cuda.is_available():
+        from ._lib import NeuMeshHipError
+        raise NeuMeshHipError(f"ray generation for device {device!r}: no HIP device visible (the render / training path has no CPU fallback)")
     return t.pin_memory().to(device, non_blocking=True)
 
 

@@ -121,9 +121,10 @@ class _Workspace:
 # stream are ordered by it (fork/join below), calls on different streams or devices never share scratch.
 DEFAULT_RAYSCHUNK = 1 << 16   # rays per nm_render_rays call unless NEUMESH_RAYSCHUNK says otherwise (_fused_chunk)
 WS_KEEP_BYTES = int(float(os.environ.get("NEUMESH_WS_KEEP_GB", "10")) * (1 << 30))   # pooled workspaces above this are returned after the call
-_POOLS = OrderedDict()      # (device, caller stream) -> two workspaces; least recently used first
+MAX_LANES = 8               # chunk lanes (streams with a workspace each) a call may use
+_POOLS = OrderedDict()      # (device, caller stream) -> its lanes' workspaces; least recently used first
 _POOLS_LOCK = threading.Lock()
-_POOLS_MAX = 4              # pools kept (each holds up to two full-chunk workspaces): callers on many short-lived streams
+_POOLS_MAX = 4              # pools kept (each holds up to one full-chunk workspace per lane in use): callers on many short-lived streams
                             # (nn.DataParallel worker threads, per-request streams) must not accumulate them
 
 
@@ -132,7 +133,7 @@ def _lanes_for(device, stream_handle: int):
     with _POOLS_LOCK:
         pool = _POOLS.pop(key, None)
         if pool is None:
-            pool = [_Workspace(), _Workspace()]
+            pool = [_Workspace() for _ in range(MAX_LANES)]
         _POOLS[key] = pool                      # most recently used last
         while len(_POOLS) > _POOLS_MAX:
             _POOLS.popitem(last=False)          # (its tensors are freed once the evicted call's own references go)
@@ -145,11 +146,31 @@ def release_workspaces():
         _POOLS.clear()
 
 
-def _n_lanes() -> int:
+DEFAULT_LANES = 2
+
+
+def _env_int(name: str, default: int) -> int:
     try:
-        return max(1, min(2, int(os.environ.get("NEUMESH_RENDER_STREAMS", "2"))))
+        return int(os.environ.get(name, "") or default)
     except ValueError:
-        return 2
+        return default
+
+
+def _n_lanes() -> int:
+    """Ray chunks of one call in flight at a time (NEUMESH_RENDER_STREAMS): each on its own stream with its own workspace."""
+    return max(1, min(MAX_LANES, _env_int("NEUMESH_RENDER_STREAMS", DEFAULT_LANES)))
+
+
+def _overlap_settings(n_lanes: int):
+    """(overlap, knn_keep, mlp_prio) of nm_render_cfg for a call cut into chunks on n_lanes streams.  With more than one chunk in flight the
+    K-NN kernels of a chunk take the pull form and make room for the other chunks' MLP kernels (NEUMESH_OVERLAP=0 keeps the plain launches)."""
+    if n_lanes < 2 or not _env_int("NEUMESH_OVERLAP", DEFAULT_OVERLAP):
+        return 0, 0, 0
+    return 1, max(0, min(8, _env_int("NEUMESH_KNN_KEEP", 0))), max(0, min(3, _env_int("NEUMESH_MLP_PRIO", DEFAULT_MLP_PRIO)))
+
+
+DEFAULT_OVERLAP = 0
+DEFAULT_MLP_PRIO = 0
 
 
 def fusable_edit_model(model) -> bool:
@@ -226,7 +247,7 @@ def _fused_chunk(lib, cfg, R: int, rayschunk: int, dev, extra_per_ray: int = 0) 
         return want
     free -= int(extra_per_ray) * R            # tensors of the whole call (allocated before the first chunk runs)
     while chunk > want:
-        need = int(lib.nm_render_workspace_bytes(C.byref(cfg), chunk)) * (1 if chunk >= R else 2)
+        need = int(lib.nm_render_workspace_bytes(C.byref(cfg), chunk)) * (1 if chunk >= R else min(_n_lanes(), -(-R // chunk)))
         if 0 <= need <= free // 2:
             break
         chunk = max(want, chunk // 2)
@@ -270,6 +291,7 @@ def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed,
         main = torch.cuda.current_stream(dev)
         lanes = _lanes_for(dev, main.cuda_stream)[:min(_n_lanes(), len(starts))]
         wss = [lane.get(ws_bytes, dev) for lane in lanes]
+        cfg.overlap, cfg.knn_keep, cfg.mlp_prio = _overlap_settings(len(lanes))
         if len(lanes) > 1:  # fork: the side streams start after everything already queued on the caller's stream
             side = [lane.side_stream(dev) for lane in lanes]
             for st in side:

@@ -410,6 +410,79 @@ def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=8
     )
 
 
+def gen_surf_sensitivity(tag="render_v140k_surf", mlp_state=None, s_value=400.0, n_seeds=8, n_time=3):
+    """The reference's OWN spread on the headline fixture, and its own speed.
+
+    (a) `n_seeds` independent last-bit perturbations of the fixture's ray directions -- seed 0: every component one ulp up (the run
+        the fixture itself carries as self_err_1ulp), seeds 1..: every component moved by -1 / 0 / +1 ulp at random -- each rendered by
+        the imported reference exactly as the fixture was; per seed the number of rays whose rgb moves by more than 1e-4 and the
+        largest move.  The product's end-to-end gate is `count <= max over seeds`, `max error <= 2 x max over seeds`
+        (tests/test_gpu_parity.py).  Written to tests/golden/<tag>_sens.npz; the pinned <tag>.npz is only READ (and checked: the
+        unperturbed render must reproduce its rgb bit for bit).
+    (b) the un-spied production call renderer(rays, detailed_output=False, **render_kwargs_test) on the first 512 fixture rays,
+        `n_time` repeats, median: REPORT.json["reference_timing"] -- what bench.py quotes as the reference's CPU rays/s."""
+    import time
+    import torch
+    from scipy.spatial import cKDTree
+    from oracle import knn as oknn
+    f = np.load(os.path.join(GOLDEN, f"{tag}.npz"))
+    V, n_rays = int(f["V"]), f["rays_o"].shape[0]
+    print(f"[{tag}_sens] V={V} rays={n_rays}, {n_seeds} perturbation seeds")
+    mesh = synthetic.fibonacci_blob(V)
+    model, kw, renderer, _ = harness.build_reference(mesh, seed=0, mlp_state=mlp_state, s_value=s_value)
+    import frnn as frnn_stub
+    tree = cKDTree(mesh.vertices.astype(np.float64))
+    old_knn = frnn_stub.KNN_FN[0]
+    frnn_stub.KNN_FN[0] = lambda q, v, K: oknn.knn_kdtree(q, v, K, tree=tree)
+    kw = dict(kw)
+    n_s = int(f["N_samples"]) if "N_samples" in f.files else 64          # (fixtures written before these keys existed: the headline shape)
+    n_i = int(f["N_importance"]) if "N_importance" in f.files else 64
+    kw.update(rayschunk=n_rays, calc_normal=True, N_samples=n_s, N_importance=n_i, perturb=False,
+              white_bkgd=bool(f["white_bkgd"]) if "white_bkgd" in f.files else False)
+    rays_o, rays_d = f["rays_o"], f["rays_d"]
+
+    def render(rd, n=None):
+        with torch.no_grad():
+            rgb, _, _ = renderer(torch.from_numpy(rays_o[:n])[None], torch.from_numpy(rd[:n])[None], detailed_output=False, **dict(kw, rayschunk=n or n_rays))
+        return rgb[0].numpy()
+
+    try:
+        base = render(rays_d)
+        assert np.array_equal(base, f["rgb"]), "the unperturbed reference render does not reproduce the pinned fixture"
+        up, down = np.nextafter(rays_d, np.float32(10), dtype=np.float32), np.nextafter(rays_d, np.float32(-10), dtype=np.float32)
+        errs, counts, maxes = [], [], []
+        for seed in range(n_seeds):
+            if seed == 0:
+                rd = up
+            else:
+                pick = np.random.default_rng(1000 + seed).integers(-1, 2, rays_d.shape)
+                rd = np.where(pick > 0, up, np.where(pick < 0, down, rays_d)).astype(np.float32)
+            e = np.abs(render(rd) - base).max(-1).astype(np.float32)
+            errs.append(e)
+            counts.append(int((e > 1e-4).sum()))
+            maxes.append(float(e.max()))
+            print(f"    seed {seed}: {counts[-1]}/{n_rays} rays > 1e-4, max {maxes[-1]:.2e}, median {np.median(e):.1e}")
+        assert np.array_equal(errs[0], f["self_err_1ulp"]), "seed 0 is the fixture's own 1-ulp run"
+        n_t = min(512, n_rays)
+        render(rays_d, 8)
+        times = []
+        for _ in range(n_time):
+            t0 = time.perf_counter()
+            render(rays_d, n_t)
+            times.append(time.perf_counter() - t0)
+    finally:
+        frnn_stub.KNN_FN[0] = old_knn
+    med = float(np.median(times))
+    REPORT["reference_timing"] = {"rays_per_s": n_t / med, "rays": n_t, "repeats": n_time, "seconds": [float(t) for t in times], "cores": os.cpu_count(),
+                                  "torch_threads": int(torch.get_num_threads()), "V": V, "samples_per_ray": n_s + n_i,
+                                  "scene": tag, "call": "models/renderer.py SingleRenderer.forward(rays, detailed_output=False, **render_kwargs_test), unmodified; "
+                                  "FRNN stand-in: scipy cKDTree candidates + declared fp32 re-rank (oracle/knn.py)"}
+    REPORT[f"{tag}.reference_self_sensitivity_seeds"] = {"rays_gt_1e-4": counts, "max": maxes, "n_rays": n_rays}
+    print(f"    reference timing: {n_t} rays, median of {n_time}: {med:.2f} s = {n_t / med:.1f} rays/s ({os.cpu_count()} cores, {torch.get_num_threads()} torch threads)")
+    np.savez_compressed(os.path.join(GOLDEN, f"{tag}_sens.npz"), self_err=np.stack(errs), rays_gt_1e_4=np.asarray(counts, np.int64),
+                        max_err=np.asarray(maxes, np.float32), state_sha256=np.array(state_digest(mlp_state) if mlp_state is not None else ""))
+
+
 def gen_painting_step_fixture(tag="painting_step_v3000", V=3000, mlp_state=None, n_paint=40, n_bg=56):
     """The texture-painting fine-tune step through the REFERENCE's Trainer.forward_painting (models/trainer.py:119-172): painted rays
     rendered with random colour directions (renderer.py:279-289), background rays with per-sample outputs for the distillation terms
@@ -1039,7 +1112,7 @@ def gen_rays_fixture():
                         rays_o=ro[0].numpy(), rays_d=rd[0].numpy())
 
 
-KNOWN = ("scale", "train", "surface", "surf", "surf3", "trace", "paint", "edit", "deform", "surface140k", "train140k", "perturb", "edit140k", "trainloop")
+KNOWN = ("scale", "train", "surface", "surf", "surfsens", "surf3", "trace", "paint", "edit", "deform", "surface140k", "train140k", "perturb", "edit140k", "trainloop")
 
 
 def main():
@@ -1052,6 +1125,8 @@ def main():
             gen_scale_fixture("render_v140k_dtu", mlp_state=sd)
         elif sys.argv[1] == "surf":   # the scene with a surface (neumesh_amd.synthetic.surface_mlp_state), s = 400
             gen_scale_fixture("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0)
+        elif sys.argv[1] == "surfsens":   # the reference's own spread over 8 last-bit perturbations of the surf fixture's rays + its speed (reads render_v140k_surf.npz)
+            gen_surf_sensitivity("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0)
         elif sys.argv[1] == "surf3":  # BASELINE configs[3] shape (32 + 32 samples, white background) on the same scene, at headline scale
             gen_scale_fixture("render_v140k_surf_c3", n_rays=1024, mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0,
                               n_samples=32, n_importance=32, white_bkgd=True)
@@ -1108,6 +1183,7 @@ def main():
     gen_texture_edit_scale_fixture("texture_edit_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd))
     gen_surface_scale_fixture("surface_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd))
     gen_train_step_fixture("train_step_v140k_surf", V=140_000, mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0, n_rays=256, HW=64, kdtree=True)
+    gen_surf_sensitivity("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0)
     with open(os.path.join(GOLDEN, "REPORT.json"), "w") as f:
         json.dump(REPORT, f, indent=1, sort_keys=True)
     print("all oracle-vs-reference checks passed; fixtures written to", GOLDEN)

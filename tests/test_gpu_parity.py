@@ -1548,3 +1548,55 @@ def test_stochastic_sampler_matches_reference_fixture(small, cuda_device, torch_
     dd = np.abs(g["d_final"] - d_mid_ref)                                          # the reference's sample placement (a uniform number within an
     assert (dd <= 2e-6).mean() >= 0.995 and dd.max() < 5e-3, (float(dd.max()), float((dd > 2e-6).mean()))   # ulp of a CDF edge may change bins)
     assert np.abs(f["d_all"] - rf["d_all"]).max() > 1e-3                           # ... which is not the deterministic one
+
+
+# --------------------------------------------------------------------- several chunks in flight (nm_render_cfg.overlap, ABI v10)
+@pytest.mark.gpu
+def test_simd_keys_of_the_pull_kernels_cover_the_chip(cuda_device, torch_mod):
+    """The pull kernels count their resident waves per SIMD under a key built from HW_REG_HW_ID / HW_REG_XCC_ID (nm_simd_key): a launch
+    that fills the chip must show exactly 4 keys per CU, all inside the table (nm_kernels.h: NmYield.occ)."""
+    torch = torch_mod
+    from neumesh_amd import _lib
+    lib = _lib.load_testing()
+    n = 1 << 16
+    out = torch.full((n,), -1, dtype=torch.int32, device=cuda_device)
+    _lib.check(lib.nm_debug_simd_keys(_lib.ptr(out), n, _lib.current_stream(cuda_device)), "nm_debug_simd_keys", lib)
+    torch.cuda.synchronize()
+    keys = out.cpu().numpy()
+    assert keys.min() >= 0 and keys.max() < 8192
+    cus = torch.cuda.get_device_properties(cuda_device).multi_processor_count
+    uniq = np.unique(keys)
+    assert len(uniq) == 4 * cus, (len(uniq), cus)
+    assert len(np.unique(uniq >> 2)) == cus   # 4 SIMDs under every CU key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes,keep,prio", [(2, 0, 0), (3, 1, 2), (4, 2, 0)])
+def test_chunks_in_flight_with_pull_form_knn_render_identical_pixels(surf_scale, cuda_device, torch_mod, monkeypatch, lanes, keep, prio):
+    """A call cut into ray chunks on several streams with nm_render_cfg.overlap = 1 -- K-NN kernels in the pull form (one-wave workgroups
+    drawing packets from a counter, leaving their SIMD when an MLP launch of another chunk wants room) -- returns every output bit for
+    bit as the same call rendered in one piece with plain launches; also with a ragged last chunk, normals off and the lego shape."""
+    torch = torch_mod
+    from neumesh_amd import renderer as rmod
+    from neumesh_amd import synthetic
+    mesh, state, model = surf_scale
+    H = W = 192
+    o, d = synthetic.camera_rays(synthetic.orbit_pose(2), synthetic.pinhole_intrinsics(H, W), H, W)
+    o, d = _t(o, cuda_device), _t(d, cuda_device)
+    for kw in (dict(calc_normal=True), dict(calc_normal=False, N_samples=32, N_importance=32, white_bkgd=True)):
+        kw.update(perturb=False, detailed_output=False)
+        monkeypatch.setenv("NEUMESH_RAYSCHUNK", "0")
+        monkeypatch.setenv("NEUMESH_RENDER_STREAMS", "1")
+        monkeypatch.setenv("NEUMESH_OVERLAP", "0")
+        with torch.no_grad():
+            rgb_a, dep_a, ex_a = rmod.volume_render(o, d, model, rayschunk=H * W, **kw)
+        monkeypatch.setenv("NEUMESH_RENDER_STREAMS", str(lanes))
+        monkeypatch.setenv("NEUMESH_OVERLAP", "1")
+        monkeypatch.setenv("NEUMESH_KNN_KEEP", str(keep))
+        monkeypatch.setenv("NEUMESH_MLP_PRIO", str(prio))
+        with torch.no_grad():
+            rgb_b, dep_b, ex_b = rmod.volume_render(o, d, model, rayschunk=5000, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(rgb_a, rgb_b) and torch.equal(dep_a, dep_b) and torch.equal(ex_a["mask_volume"], ex_b["mask_volume"])
+        if kw["calc_normal"]:
+            assert torch.equal(ex_a["normals_volume"], ex_b["normals_volume"])
