@@ -56,8 +56,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 DEFAULT_PRECISION = "f16x2s"    # the library's default MLP arithmetic (neumesh_amd/neumesh.py); rows of other modes are labelled
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF dense
 PEAK_HBM_GBS = 8000.0
+NOMINAL_CLOCK_MHZ = 2400.0      # the clock the dense MFMA peaks above are quoted at
 KNN_BYTES_PER_QUERY = 76    # 12 in + 8*4 idx + 8*4 w  
-PROFILE_TAG = "r04"         # profiles/<tag>_pmc_*.json: rocprofv3 --pmc passes of this command (tools/pmc_*.py)
+PROFILE_TAG, PROFILE_TAG_PREVIOUS = "r05", "r04"          # profiles/<tag>_pmc_*.json: rocprofv3 --pmc passes of this command (tools/pmc_*.py)
 
 MODEL_CFG = dict(D_density=3, D_color=4, W=256, geometry_dim=32, color_dim=32, multires_view=4, multires_d=8,
                  multires_fg=2, multires_ft=2, enable_nablas_input=True, speed_factor=10.0, learn_indicator_weight=False)
@@ -159,14 +160,22 @@ def cpu_baseline(mesh, model, H, W, n_rays, rays0, samples=128, white_bkgd=False
     t = time.perf_counter()
     out = orender.render_rays(orc, o[sel], d[sel], cfg)
     dt = time.perf_counter() - t
+    # the imported REFERENCE itself, timed where its tree exists (the build container): the committed record oracle/gen_golden.py surfsens wrote
+    # (tests/golden/REPORT.json "reference_timing": the un-spied production call, median of 3) -- a record, not a literal
+    rt = {}
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "REPORT.json")) as f:
+            rt = json.load(f).get("reference_timing", {})
+    except (OSError, ValueError):
+        pass
     res = {"value": n_rays / dt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
-           # the imported REFERENCE itself, timed where its tree exists (the build container; oracle/gen_golden.py surf, tests/golden/REPORT.json)
-           "reference_rays_per_s_build_container": 103.0, "reference_cores_build_container": 8,
+           "reference_rays_per_s_build_container": rt.get("rays_per_s"), "reference_cores_build_container": rt.get("cores"),
+           "reference_timing_record": rt or None,
            "sample": f"{n_rays} rays strided over frame 0 of the same {H}x{W}x{samples} workload, {dt:.1f} s; numpy fp32 oracle + "
                      f"scipy cKDTree candidates re-ranked with the declared fp32 arithmetic (BLAS/OpenMP threads = all cores; the same oracle as one "
                      f"single-threaded process per core reached 298 rays/s on 256 x 256 rays and 47 rays/s on 256 x 22 rays on this box type: it does not scale, so the one-process figure stands); "
-                     f"the imported REFERENCE itself (kind 'reference', used automatically where /root/reference exists) did 103 rays/s on this scene "
-                     f"on the 8 cores of the build container (oracle/gen_golden.py surf; tests/golden/REPORT.json)"}
+                     f"the imported REFERENCE itself (kind 'reference', used automatically where /root/reference exists): reference_timing_record, "
+                     f"from tests/golden/REPORT.json (oracle/gen_golden.py surfsens, build container)"}
     return res, out["rgb"], sel
 
 
@@ -311,11 +320,13 @@ def parity_blocks(gpu_rgb_frame0, H, W, V, oracle_rgb, sel, scene="surf", model=
 
 
 def _load_profile(name):
-    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{name}.json")
-    try:
-        return json.load(open(path)), os.path.relpath(path, ROOT)
-    except Exception:
-        return None, None
+    for tag in (PROFILE_TAG, PROFILE_TAG_PREVIOUS):   # (the round's own passes once they are committed; until then the previous round's)
+        path = os.path.join(ROOT, "profiles", f"{tag}_{name}.json")
+        try:
+            return json.load(open(path)), os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 def read_prof(lib):
@@ -326,6 +337,35 @@ def read_prof(lib):
         _lib.check(lib.nm_profile_read(k, C.byref(ms), C.byref(n), C.byref(u)), "nm_profile_read")
         prof[name] = {"ms": ms.value, "launches": n.value, "points": u.value, "flop_per_point": flop}
     return prof
+
+
+def clock_under_load(lib, dev, work, micros=300, pause_s=0.02):
+    """Shader clock (MHz) while `work()` -- which enqueues GPU work and returns -- is executing: a sampler thread calls nm_profile_clock on a
+    stream of its own (one wave counting its clock against the 100 MHz counter for `micros` us) until the work has drained.
+    Returns dict(mean, min, max, samples) or None."""
+    import torch
+    samples, stop = [], threading.Event()
+    side = torch.cuda.Stream(device=dev)
+
+    def sampler():
+        torch.cuda.set_device(dev)
+        mhz = C.c_float()
+        while not stop.is_set():
+            if lib.nm_profile_clock(micros, C.byref(mhz), C.c_void_p(side.cuda_stream)) == 0 and mhz.value > 0:
+                samples.append(float(mhz.value))
+            time.sleep(pause_s)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    work()                       # enqueue first: the sampler's kernels then run beside it
+    th.start()
+    torch.cuda.current_stream(dev).synchronize()
+    stop.set()
+    th.join(timeout=5)
+    if len(samples) > 2:
+        samples = samples[:-1]   # (the last one may have run after the work ended)
+    if not samples:
+        return None
+    return {"mean": sum(samples) / len(samples), "min": min(samples), "max": max(samples), "samples": len(samples)}
 
 
 def stress5_run(args, dev, world, rank, steps, warmup):
@@ -726,6 +766,21 @@ def main():
         }
         cfgd = out["config"]
         extra = {}
+        if world == 1:   # the clock the chip holds under this very load (the pipe peaks above assume the nominal 2.4 GHz)
+            try:
+                m_ = model
+                cfg_c = make_render_cfg(calc_normal=not args.no_normals, N_samples=args.samples // 2, N_importance=args.samples // 2, white_bkgd=args.white_bkgd, flags=head_flags)
+                ro_c, rd_c = make_rays(synthetic.orbit_pose(0), intr, args.H, args.W, dev)
+                tb_c = m_.field_tables()
+                clk = clock_under_load(lib, dev, lambda: [render_rays_fused(m_, ro_c, rd_c, cfg_c, args.rayschunk or n_rays, tables=tb_c) for _ in range(2)])
+                if clk:
+                    out["roofline"]["shader_clock_mhz_under_load"] = clk
+                    out["roofline"]["frac_at_measured_clock"] = alg / (peak * clk["mean"] / NOMINAL_CLOCK_MHZ)
+                    out["roofline"]["clock_note"] = (f"peak = dense MFMA rate at the nominal {NOMINAL_CLOCK_MHZ:.0f} MHz; under this workload the shader clock is "
+                                                     f"{clk['mean']:.0f} MHz (nm_profile_clock sampled beside two frames), i.e. the pipe's own ceiling here is "
+                                                     f"{peak * clk['mean'] / NOMINAL_CLOCK_MHZ:.0f} TFLOP/s")
+            except Exception as ex:
+                out["roofline"]["shader_clock_mhz_under_load"] = {"error": str(ex)}
         # Everything from here on is context beside the headline (variant rows, consumers of the path, the CPU baseline).  A watchdog makes sure
         # the ONE line of the contract is printed even if one of those rows should stall: after --extras-budget seconds it prints the line with the
         # rows finished so far and ends the process.  (Blocking HIP calls release the interpreter lock, so the thread runs.)
@@ -762,8 +817,10 @@ def main():
             r = short("data_independent_frame (every probe + every mid-point evaluated: the reference's work)",
                       flags=_lib.RENDER_FULL_PROBES | _lib.RENDER_NO_ZERO_SKIP)
             cfgd["data_independent_rays_per_s"], cfgd["data_independent_ms_per_frame"] = r.get("value"), r.get("ms_per_frame")
-            r = short("mlp_precision_fp32 (fp32-input MFMA)", precision="fp32")
+            r = short("mlp_precision_fp32 (fp32-input MFMA)", precision="fp32", keep_frame0=True)
             cfgd["fp32_rays_per_s"], cfgd["fp32_ms_per_frame"] = r.get("value"), r.get("ms_per_frame")
+            fxr = r.get("vs_reference_fixture", {})
+            cfgd["fp32_max_abs_rgb_vs_reference"], cfgd["fp32_frac_rays_within_1e-4"] = fxr.get("max_abs_rgb"), fxr.get("frac_rays_within_1e-4")
             cfgd["fp32_mlp_tflops"], cfgd["fp32_frac_of_fp32_mfma_peak"] = r.get("achieved_tflops_algorithmic"), r.get("frac_of_pipe_peak")
             other_acc = "f16x2" if args.mlp_precision == "f16x2s" else "f16x2s"
             r = short(f"mlp_precision_{other_acc} (split-half operands with {'two accumulators, residual halves scaled by 2^11: the default of rounds 1-3' if other_acc == 'f16x2' else 'one accumulator'})",
@@ -791,6 +848,8 @@ def main():
             r = short("library_default_chunks (rayschunk = 65536, the value volume_render uses when the caller names none -- ~4 GB of workspace per lane instead "
                       "of 40 --, chunks alternating between two streams; identical pixels)", chunk=65536, keep_frame0=True)
             cfgd["default_rayschunk_ms_per_frame"] = r.get("ms_per_frame")
+            # what a caller of volume_render gets without naming a chunk (render.py:211-218 passes 4096: a lower bound here), beside the one-call headline
+            out["value_library_default_chunks"], out["ms_per_frame_library_default_chunks"] = r.get("value"), r.get("ms_per_frame")
             short("weight_eps_1e-10 (mid-points of visibility weight < 1e-10 not evaluated: the one variant that is not bit-identical; "
                   "rgb / normals move by < 127e-10, depth / acc not at all)", weight_eps=1e-10, keep_frame0=True)
             short("config3_shape (64 samples/ray, white background)", samples=64, white=True)

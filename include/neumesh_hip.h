@@ -244,6 +244,10 @@ typedef struct nm_render_cfg {
  *                 dbg->d_all (required), dbg->near_far and dbg->sdf_all are written; rgb / depth / acc / normals may be NULL.
  *                 The training renderer places its samples with this call and queries the field with autograd afterwards. */
 #define NM_RENDER_SAMPLE_ONLY 32u
+/*   NO_FORK       (calc_normal) keep the mid-points' K-NN launch behind the sample points' nabla launch on the caller's stream instead of
+ *                 running it beside that launch on a side stream of the call (two independent kernels, one bound by vector issue, one by
+ *                 the matrix pipe) */
+#define NM_RENDER_NO_FORK 64u
 
 int64_t nm_render_workspace_bytes(const nm_render_cfg* cfg, int64_t R);
 
@@ -417,6 +421,9 @@ int nm_assemble_frame(const float* rgb, const float* depth, const float* normals
  * Process-wide log, mutex-protected; intended for one measuring thread (bench.py). */
 int nm_profile_enable(int on);
 int nm_profile_read(int kind, double* total_ms, int64_t* launches, int64_t* units);
+/* Shader clock in MHz as one wave measures it over `micros` microseconds (its cycle counter against the constant 100 MHz counter).  Called on
+ * a stream of its own while a workload runs on another, it returns the clock the chip holds under that load.  Synchronises `stream`. */
+int nm_profile_clock(int micros, float* mhz, nm_stream_t stream);
 
 /* Launches `iters` back-to-back passes of one internal kernel on `stream`, bracketed by HIP
  * events recorded on that same stream; returns the average duration in milliseconds.

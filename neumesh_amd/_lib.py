@@ -52,7 +52,7 @@ class RenderCfg(C.Structure):
 
 GRID_DEFER_BUDGET, GRID_TRIM = 1, 2   # nm_grid_set_option
 # nm_render_cfg.flags (include/neumesh_hip.h)
-RENDER_FULL_PROBES, RENDER_NO_ZERO_SKIP, RENDER_NO_RAY_SORT, RENDER_NO_MID_ORDER, RENDER_EAGER_NABLAS, RENDER_SAMPLE_ONLY = 1, 2, 4, 8, 16, 32
+RENDER_FULL_PROBES, RENDER_NO_ZERO_SKIP, RENDER_NO_RAY_SORT, RENDER_NO_MID_ORDER, RENDER_EAGER_NABLAS, RENDER_SAMPLE_ONLY, RENDER_NO_FORK = 1, 2, 4, 8, 16, 32, 64
 
 
 class Camera(C.Structure):
@@ -124,6 +124,7 @@ SIGNATURES = {
     "nm_assemble_frame": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P]),
     "nm_profile_enable": (C.c_int, [C.c_int]),
     "nm_profile_read": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "nm_profile_clock": (C.c_int, [C.c_int, C.POINTER(C.c_float), _P]),
     "nm_time_kernel": (C.c_int, [_P, _P, C.POINTER(FieldTables), C.c_int, _P, _P, C.c_int64, _P, C.c_int,
                                  C.POINTER(C.c_float), _P]),
 }

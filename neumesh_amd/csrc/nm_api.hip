@@ -381,12 +381,14 @@ static int nm_yield_state(NmYield** out, int* simds) {
 }
 static NmPull nm_pull_for(NmOverlap* ov, long long npackets) {
     NmPull pl;
-    pl.next = ov->counters + (ov->used++ % NM_PULL_COUNTERS);
+    pl.next = ov->counters + 2 * ov->used++;   // (packet counter, waves at work); callers check nm_pull_ok() first
     pl.npackets = npackets;
     pl.y = ov->y;
     pl.cap = ov->cap;
+    pl.min_alive = ov->simds / 4;   // one wave per CU
     return pl;
 }
+static inline bool nm_pull_ok(const NmOverlap* ov) { return ov && ov->y && ov->used < NM_PULL_COUNTERS; }   // (a call with more K-NN launches than counters: plain launches for the rest)
 static inline unsigned nm_pull_grid(const NmOverlap* ov, long long npackets, int waves_per_simd) {
     const long long full = (long long)ov->simds * waves_per_simd;
     return (unsigned)(npackets < full ? npackets : full);
@@ -403,6 +405,32 @@ struct NmWantRoom {
     }
 };
 
+// ---- a second stream inside one call (nm_render_rays: the mid-point search beside the sample points' nabla launch).  One side stream + two
+// events per (device, caller stream) that asked for one, created on first use, kept for the life of the process (at most 64; later callers
+// simply run in order).  The fork / join is stream-ordered: no host synchronisation.
+struct NmSide { int dev; hipStream_t main, side; hipEvent_t fork, join; };
+static bool nm_side_for(hipStream_t main, NmSide* out) {
+    static std::mutex mu;
+    static std::vector<NmSide> pool;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& e : pool)
+        if (e.dev == dev && e.main == main) { *out = e; return true; }
+    if (pool.size() >= 64) return false;
+    NmSide e;
+    e.dev = dev;
+    e.main = main;
+    if (hipStreamCreateWithFlags(&e.side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    pool.push_back(e);
+    *out = e;
+    return true;
+}
+
 // work budget of small launches: the build's constant unless the index was given its own (nm_grid_set_option)
 static int nm_defer_budget(nm_grid_t g) {
     const int b = g->defer_budget.load(std::memory_order_relaxed);
@@ -416,7 +444,7 @@ static int nm_launch_distance(nm_grid_t g, const NmPointSrc& src_in, long long Q
     NmProfScope prof(NM_K_DISTANCE, counted ? 0 : Q, stream, counted ? NM_CNT_MID : NM_CNT_NONE);
     NmPointSrc src = src_in;
     src.budget = 0;
-    if (ov && ov->y && src.mode != 0) {   // pull form: one-wave workgroups draw the launch's packets from a counter
+    if (nm_pull_ok(ov) && src.mode != 0) {   // pull form: one-wave workgroups draw the launch's packets from a counter
         const long long packets = (long long)nm_query_blocks(src, Q) * 4;
         const NmPull pl = nm_pull_for(ov, packets);
         if (nm_chain_len(src) > 1)
@@ -1114,7 +1142,7 @@ struct NmWorkspace {
     NmScratch pts;    // compact records of the mid-point pass
     float *nab_rot, *dirn_rot;             // texture editing with a rotated reference frame: nablas [pos][3], directions [R][3]
     float *rgb_ref, *edit_w, *edit_share;  // texture editing: reference colours [R][N][3], renormalised painted weights [pos][8], (rest, paint) shares [pos][2]
-    unsigned long long* pull_counters;     // packet counters of the call's pull-form K-NN launches (nm_render_cfg.overlap), NM_PULL_COUNTERS of them
+    unsigned long long* pull_counters;     // (packet counter, waves at work) of the call's pull-form K-NN launches (nm_render_cfg.overlap), NM_PULL_COUNTERS pairs
     size_t bytes;
 };
 static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) {
@@ -1123,7 +1151,7 @@ static NmWorkspace nm_carve_ws(void* base, const nm_render_cfg* c, long long R) 
     char* p = (char*)base;
     size_t o = 0;
     auto take = [&](size_t bytes) { char* r = p + o; o += nm_align(bytes); return r; };
-    w.pull_counters = (unsigned long long*)take(NM_PULL_COUNTERS * sizeof(unsigned long long));
+    w.pull_counters = (unsigned long long*)take(2 * NM_PULL_COUNTERS * sizeof(unsigned long long));
     w.rays_o_s = (float*)take((size_t)R * 12);
     w.rays_d_s = (float*)take((size_t)R * 12);
     w.key_in = (unsigned*)take((size_t)R * 4);
@@ -1230,7 +1258,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
         ov_state.counters = ws.pull_counters;
         ov_state.cap = c->knn_keep > 0 ? c->knn_keep : 1;
         ov_state.prio = c->mlp_prio;
-        NM_HIP(hipMemsetAsync(ws.pull_counters, 0, NM_PULL_COUNTERS * sizeof(unsigned long long), stream));
+        NM_HIP(hipMemsetAsync(ws.pull_counters, 0, 2 * NM_PULL_COUNTERS * sizeof(unsigned long long), stream));
         ov = &ov_state;
     }
     const dim3 rblock_io(NM_RAY_IO_THREADS);   // upsample / finalize: 64 rays per workgroup, every thread moves rows between HBM and LDS
@@ -1263,7 +1291,7 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
         if (!(c->flags & NM_RENDER_FULL_PROBES)) {  // first / last hit only (nm_probe_bounds_kernel)
             NmProfScope prof(NM_K_DISTANCE, 0, stream, NM_CNT_PROBE);  // units = probes actually searched (device counter)
             static_assert(NM_PROBE_STEP == 8, "launch geometry below is for 8 probes per ray and step");
-            if (ov) {
+            if (nm_pull_ok(ov)) {
                 const long long packets = (R + 7) / 8;
                 hipLaunchKernelGGL(nm_probe_bounds_pull_kernel<8>, dim3(nm_pull_grid(ov, packets, NM_KNN_WAVES_PROBE)), dim3(64), 0, stream, g->view, nm_pull_for(ov, packets),
                                    rays_o, ws.dirn, ws.nf0, (long long)R, c->probe_grid, c->probe_thresh, g->verts, t->indicator_vector, t->indicator_weight, ws.nf,
@@ -1418,10 +1446,20 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     // the list's (ray, j) entries are exactly the sample points that need a nabla.  Their K-NN records sit in the slot
     // arrays of the sampling passes (which therefore ran the forward-only MLP: 64 instead of 32 points per tile, no
     // tangent rows); the tangent kernel reads them through the slot permutation and writes nab_pts[ray][j].
+    // The sample points' nabla launch (matrix pipe) and the mid-points' search (vector issue) are independent: the search goes to a side stream
+    // of this call and runs in what the MLP workgroups leave free (cfg.flags & NM_RENDER_NO_FORK: in order, as before; same results either way).
+    NmSide sd;
+    const bool fork = want_grad && !eager_nabla && !ov && !(c->flags & NM_RENDER_NO_FORK) && nm_side_for(stream, &sd);
     if (want_grad && !eager_nabla) {
         if (!(use_order && skip_zero)) return nm_fail("nm_render_rays: internal: lazy nablas need the zero-weight list");
+        if (fork) NM_HIP(hipEventRecord(sd.fork, stream));
         const NmRecMap rm = {N - 1, cap, 0, ws.slot, 1};
         if (nm_launch_geo(f, ws.slots.fg, ws.slots.ds, ws.slots.grad, mid_pts, true, nullptr, 1, N, 0, ws.nab_pts, stream, rm, 1, smap, true, ov)) return 1;
+    }
+    hipStream_t knn_stream = stream;
+    if (fork) {
+        NM_HIP(hipStreamWaitEvent(sd.side, sd.fork, 0));
+        knn_stream = sd.side;
     }
     src.mode = 1;
     src.P = N - 1;
@@ -1434,7 +1472,11 @@ int nm_render_rays(nm_field_t f, nm_grid_t g, const nm_field_tables* t, const fl
     {
         const NmGather ga_mid = {t->geometry_features, f->geo.gdim, ws.pts.fg, t->color_features, f->col.cdim, ws.pts.ft};
         if (nm_launch_distance(g, src, (long long)R * (N - 1), t->indicator_vector, t->indicator_weight, ws.pts.ds, c->n_edit > 0 ? ws.pts.idx : nullptr, nullptr,
-                               c->n_edit > 0 ? ws.pts.w : nullptr, ws.pts.grad, stream, nullptr, ga_mid, skip_zero, ov)) return 1;
+                               c->n_edit > 0 ? ws.pts.w : nullptr, ws.pts.grad, knn_stream, nullptr, ga_mid, skip_zero, ov)) return 1;
+    }
+    if (fork) {
+        NM_HIP(hipEventRecord(sd.join, sd.side));
+        NM_HIP(hipStreamWaitEvent(stream, sd.join, 0));
     }
     if (nm_launch_geo(f, ws.pts.fg, ws.pts.ds, ws.pts.grad, mid_pts, true, nullptr, 1, 1, 0, ws.nab_mid, stream, NM_COMPACT, 0, smap, skip_zero, ov)) return 1;
     if (nm_launch_col(f, ws.pts.ft, ws.pts.ds, ws.nab_mid, ws.dirn, N - 1, mid_pts, ws.rgb_mid, stream, smap, skip_zero, ov)) return 1;
@@ -1758,6 +1800,35 @@ int nm_profile_enable(int on) {
         NM_HIP(hipMemset(g_prof.counters, 0, NM_CNT_N * sizeof(unsigned long long)));
         g_prof.on.store(true);
     }
+    return 0;
+}
+
+// Shader clock right now: one wave counts its own clock (s_memtime) against the constant 100 MHz counter (s_memrealtime) for `micros`
+// microseconds.  Launched on a stream of its own beside a running workload it reads the clock the chip holds UNDER THAT LOAD -- the
+// figure a roofline fraction priced at the nominal 2.4 GHz needs beside it.  Synchronises `stream`.
+__global__ void nm_clock_probe_kernel(unsigned long long* out, int ticks100) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_readcyclecounter();
+    unsigned long long r1 = r0;
+    while ((long long)(r1 - r0) < (long long)ticks100) {
+        __builtin_amdgcn_s_sleep(16);
+        r1 = __builtin_amdgcn_s_memrealtime();
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter();
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+}
+int nm_profile_clock(int micros, float* mhz, nm_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!mhz || micros < 1 || micros > 100000) return nm_fail("nm_profile_clock: bad arguments");
+    unsigned long long* d = nullptr;
+    unsigned long long h[2] = {0, 0};
+    NM_HIP(hipMalloc((void**)&d, sizeof(h)));
+    hipLaunchKernelGGL(nm_clock_probe_kernel, dim3(1), dim3(64), 0, stream, d, micros * 100);
+    hipError_t e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return nm_fail("nm_profile_clock: %s", hipGetErrorString(e));
+    *mhz = h[1] ? (float)((double)h[0] / ((double)h[1] / 100.0)) : 0.f;   // shader ticks per microsecond
     return 0;
 }
 

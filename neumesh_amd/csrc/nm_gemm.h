@@ -322,8 +322,15 @@ __global__ __launch_bounds__(NM_G3_THREADS) void nm_gemm3_kernel(NmGemm g) {
 // C = A . B with the operand layouts of `g`; split_k > 1: K is cut into that many chunks whose partial products are added
 // atomically (C must have been zeroed, or hold the value to accumulate onto).
 // bf16x3 = true: the bf16 x 3 kernel above; false: the fp32-pipe kernel.
+// Shape contract of the bf16 x 3 kernel: it moves and masks operands as float4 along each operand's contiguous axis, testing the
+// FIRST element of the four only -- so that axis' extent must be a multiple of 4: K for a k-contiguous operand (a_kc / b_kc), M (A) or N (B)
+// otherwise.  The training path pads accordingly (K0p, Kc0p, W % 16); anything else is refused here instead of being read out of bounds.
+static inline bool nm_gemm3_shape_ok(const NmGemm& g) {
+    return (g.a_kc ? g.K % 4 == 0 : g.M % 4 == 0) && (g.b_kc ? g.K % 4 == 0 : g.N % 4 == 0);
+}
 static inline int nm_gemm_launch(NmGemm g, int split_k, hipStream_t stream, bool bf16x3 = false) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return 0;
+    if (bf16x3 && !nm_gemm3_shape_ok(g)) return 2;
     long long chunks = split_k > 1 ? split_k : 1;
     long long kchunk = ((g.K + chunks - 1) / chunks + NM_G_BK - 1) / NM_G_BK * NM_G_BK;
     chunks = (g.K + kchunk - 1) / kchunk;

@@ -632,7 +632,8 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_W
 //   * NmYield (one per device, shared by all streams): `wanted` = MLP launches queued or running (raised / lowered by one-thread kernels around
 //     them), occ[simd] = pull waves resident on that SIMD (from HW_REG_HW_ID / HW_REG_XCC_ID);
 //   * while wanted > 0 a SIMD keeps at most `cap` pull waves: the others exit before their next packet, a wave that arrives on a full SIMD exits at
-//     once -- so the MLP workgroups find room within one packet's time (~0.1 ms), wherever the launch order put them;
+//     once -- so the MLP workgroups find room within one packet's time (~0.1 ms), wherever the launch order put them; a launch never gives up
+//     its last `min_alive` waves (the SIMD counts are shared by every K-NN launch in flight);
 //   * with wanted == 0 the launch fills the chip like the grid-mapped form.
 // Which wave evaluates which packet changes no result bit (every packet's outputs depend on its own queries only).
 struct NmYield {
@@ -641,10 +642,12 @@ struct NmYield {
     int occ[2048 * 4];   // pull waves per SIMD, index = nm_simd_key()
 };
 struct NmPull {
-    unsigned long long* next;   // packet counter of THIS launch (zeroed by the host, stream-ordered)
+    unsigned long long* next;   // next[0]: packet counter of THIS launch, next[1]: its waves still at work (both zeroed by the host, stream-ordered)
     long long npackets;
     NmYield* y;                 // nullptr: never yield
     int cap;                    // pull waves a SIMD keeps while MLP launches want room
+    int min_alive;              // a wave only leaves while at least this many waves of its launch stay at work: the SIMD counts are shared by every K-NN
+                                // launch in flight, and a launch whose waves all sat beside another launch's must not be left without workers
 };
 // (xcc, se, sh, cu, simd) of the calling wave -> [0, 8192)
 __device__ __forceinline__ int nm_simd_key() {
@@ -652,14 +655,18 @@ __device__ __forceinline__ int nm_simd_key() {
     const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));   // HW_REG_XCC_ID [3:0]
     return (int)((((xcc & 7u) << 8 | ((hw >> 13) & 7u) << 5 | ((hw >> 12) & 1u) << 4 | ((hw >> 8) & 15u)) << 2) | ((hw >> 4) & 3u));
 }
-// true: this wave leaves (its occ entry is already given back)
+// true: this wave leaves (its occ entry and its share of the launch's alive count are already given back)
 __device__ __forceinline__ bool nm_pull_should_leave(const NmPull& pl, int key) {
     if (!pl.y) return false;
     int leave = 0;
     if ((threadIdx.x & 63) == 0 && __hip_atomic_load(&pl.y->wanted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0 &&
         __hip_atomic_load(&pl.y->occ[key], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > pl.cap) {
-        if (atomicSub(&pl.y->occ[key], 1) > pl.cap) leave = 1;
-        else atomicAdd(&pl.y->occ[key], 1);
+        unsigned long long* alive = pl.next + 1;
+        if ((long long)atomicAdd(alive, ~0ull) - 1 >= (long long)pl.min_alive) {   // (atomicAdd of -1)
+            if (atomicSub(&pl.y->occ[key], 1) > pl.cap) leave = 1;
+            else atomicAdd(&pl.y->occ[key], 1);
+        }
+        if (!leave) atomicAdd(alive, 1ull);
     }
     return __builtin_amdgcn_readfirstlane(leave) != 0;
 }
@@ -671,14 +678,20 @@ __device__ __forceinline__ long long nm_pull_next(const NmPull& pl) {
 }
 #define NM_PULL_LOOP(BODY)                                                                           \
     const int nm_key_ = pl.y ? nm_simd_key() : 0;                                                     \
-    if (pl.y && (threadIdx.x & 63) == 0) atomicAdd(&pl.y->occ[nm_key_], 1);                           \
+    if (pl.y && (threadIdx.x & 63) == 0) {                                                            \
+        atomicAdd(&pl.y->occ[nm_key_], 1);                                                            \
+        atomicAdd(pl.next + 1, 1ull);                                                                 \
+    }                                                                                                 \
     for (;;) {                                                                                        \
         if (nm_pull_should_leave(pl, nm_key_)) return;                                                \
         const long long wave = nm_pull_next(pl);                                                      \
         if (wave >= pl.npackets) break;                                                               \
         BODY;                                                                                         \
     }                                                                                                 \
-    if (pl.y && (threadIdx.x & 63) == 0) atomicSub(&pl.y->occ[nm_key_], 1);
+    if (pl.y && (threadIdx.x & 63) == 0) {                                                            \
+        atomicSub(&pl.y->occ[nm_key_], 1);                                                            \
+        atomicAdd(pl.next + 1, ~0ull);                                                                \
+    }
 
 template <bool CHAIN>
 __global__ __launch_bounds__(64, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_WAVES) void nm_distance_pull_kernel(NmGridView g, NmPointSrc src, long long Q, NmPull pl,
@@ -1256,7 +1269,7 @@ __global__ __launch_bounds__(256) void nm_rays_finalize_kernel(float* __restrict
 // Rounds 1-3 sorted the keys exactly (bitonic network in LDS, ~80 passes over up to 8192 keys: 6.5 ms per frame, the
 // largest per-ray kernel after round 4's other changes).  A wave only needs its 64 samples to be NEAR each other in depth, so
 // round 4 orders by BUCKET: 1024 depth buckets between the group's smallest and largest kept depth (finer than the vertex
-// spacing on the benchmark scene), histogram + scan + scatter, ids ascending inside a bucket (deterministic list).
+// spacing on the benchmark scene), histogram + scan + scatter, ids ascending inside EVERY bucket (the list is the same on every run).
 // wgt (optional, [R][cap]): samples with wgt == 0 are dropped (padding behind the kept ones); counter (optional): += kept.
 #define NM_ORDER_BUCKETS 1024
 static inline size_t nm_order_lds_bytes(int n) { return (size_t)((n + 63) & ~63) * (4 + 2) + 64; }   // depth + id per list entry
@@ -1285,10 +1298,12 @@ __global__ __launch_bounds__(256) void nm_rays_order_kernel(const float* __restr
             const long long g = r * cap + off + (i - rl * P);
             if (!(wgt && wgt[g] == 0.0f)) {
                 v = d[g];
-                if (v != v) v = 3.0e38f;                                     // (a NaN depth still gets a place: last bucket)
-                const unsigned k = nm_float_key(v);
-                lo = k < lo ? k : lo;
-                hi = k > hi ? k : hi;
+                if (v != v) v = 3.0e38f;                                     // (a NaN depth still gets a place: the last bucket -- but it must not
+                else {                                                       //  stretch the bucket range and collapse every real depth into bucket 0)
+                    const unsigned k = nm_float_key(v);
+                    lo = k < lo ? k : lo;
+                    hi = k > hi ? k : hi;
+                }
             }
         }
         dep[i] = v;
@@ -1343,16 +1358,22 @@ __global__ __launch_bounds__(256) void nm_rays_order_kernel(const float* __restr
         if (v == v) ids[atomicAdd(&nm_hist[bucket(v)], 1u)] = (unsigned short)i;
     }
     __syncthreads();
-    // ids ascending inside a bucket (the scatter above lands in atomic order): buckets hold a handful of entries
+    // ids ascending inside a bucket (the scatter above lands in atomic order, which differs from run to run): buckets hold a handful of
+    // entries -- insertion sort; a crowded bucket (many samples at one depth) gets a shell sort by its thread, so that the list, and with it
+    // which lane evaluates which sample, is the same on every run
     for (int b = t; b < NM_ORDER_BUCKETS; b += 256) {
-        const unsigned s0 = nm_start[b], s1 = nm_hist[b];
-        if (s1 - s0 > 1u && s1 - s0 <= 64u)
-            for (unsigned a = s0 + 1; a < s1; ++a) {
+        const unsigned s0 = nm_start[b], s1 = nm_hist[b], cnt = s1 - s0;
+        unsigned gap = 1u;
+        while (cnt > 64u && gap < cnt / 3u) gap = 3u * gap + 1u;
+        for (; gap >= 1u; gap /= 3u) {
+            for (unsigned a = s0 + gap; a < s1; ++a) {
                 const unsigned short x = ids[a];
                 unsigned q = a;
-                while (q > s0 && ids[q - 1] > x) { ids[q] = ids[q - 1]; --q; }
+                while (q >= s0 + gap && ids[q - gap] > x) { ids[q] = ids[q - gap]; q -= gap; }
                 ids[q] = x;
             }
+            if (gap == 1u) break;
+        }
     }
     __syncthreads();
     for (int i = t; i < E; i += 256) order[grp * E + i] = (unsigned)i < kept ? ids[i] : (unsigned short)0xffffu;

@@ -45,7 +45,7 @@ def alpha_to_w(alpha):
 # measurement script can flip them without touching the caller (none of them changes a result bit).
 _ENV_FLAGS = (("NEUMESH_FULL_PROBES", _lib.RENDER_FULL_PROBES), ("NEUMESH_NO_ZERO_SKIP", _lib.RENDER_NO_ZERO_SKIP),
               ("NEUMESH_NO_RAY_SORT", _lib.RENDER_NO_RAY_SORT), ("NEUMESH_NO_MID_ORDER", _lib.RENDER_NO_MID_ORDER),
-              ("NEUMESH_EAGER_NABLAS", _lib.RENDER_EAGER_NABLAS))
+              ("NEUMESH_EAGER_NABLAS", _lib.RENDER_EAGER_NABLAS), ("NEUMESH_NO_FORK", _lib.RENDER_NO_FORK))
 _ENV_TUNING = (("NEUMESH_CHAIN_TILES", "chain_tiles"), ("NEUMESH_FINE_GROUP", "fine_group_rays"), ("NEUMESH_MID_GROUP", "mid_group_rays"))
 
 
@@ -146,7 +146,7 @@ def release_workspaces():
         _POOLS.clear()
 
 
-DEFAULT_LANES = 2
+DEFAULT_LANES = 3            # (measured round 5, tools/overlap_sweep.py: 65 536-ray chunks on 2 / 3 / 4 / 6 lanes 346 / 334 / 342 / 337 ms per frame)
 
 
 def _env_int(name: str, default: int) -> int:

@@ -410,7 +410,7 @@ def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=8
     )
 
 
-def gen_surf_sensitivity(tag="render_v140k_surf", mlp_state=None, s_value=400.0, n_seeds=8, n_time=3):
+def gen_surf_sensitivity(tag="render_v140k_surf", mlp_state=None, s_value=400.0, n_seeds=8, n_time=3, timing=True):
     """The reference's OWN spread on the headline fixture, and its own speed.
 
     (a) `n_seeds` independent last-bit perturbations of the fixture's ray directions -- seed 0: every component one ulp up (the run
@@ -462,23 +462,35 @@ def gen_surf_sensitivity(tag="render_v140k_surf", mlp_state=None, s_value=400.0,
             counts.append(int((e > 1e-4).sum()))
             maxes.append(float(e.max()))
             print(f"    seed {seed}: {counts[-1]}/{n_rays} rays > 1e-4, max {maxes[-1]:.2e}, median {np.median(e):.1e}")
-        assert np.array_equal(errs[0], f["self_err_1ulp"]), "seed 0 is the fixture's own 1-ulp run"
-        n_t = min(512, n_rays)
-        render(rays_d, 8)
-        times = []
-        for _ in range(n_time):
-            t0 = time.perf_counter()
-            render(rays_d, n_t)
-            times.append(time.perf_counter() - t0)
+        assert not n_seeds or np.array_equal(errs[0], f["self_err_1ulp"]), "seed 0 is the fixture's own 1-ulp run"
+        if timing:
+            step = max(1, n_rays // 512)                     # 512 rays strided over the whole frame, like bench.py's CPU baselines
+            to, td = np.ascontiguousarray(rays_o[::step][:512]), np.ascontiguousarray(rays_d[::step][:512])
+            n_t = to.shape[0]
+
+            def timed_call(n):
+                with torch.no_grad():
+                    renderer(torch.from_numpy(to[:n])[None], torch.from_numpy(td[:n])[None], detailed_output=False, **dict(kw, rayschunk=n))
+
+            timed_call(8)
+            times = []
+            for _ in range(n_time):
+                t0 = time.perf_counter()
+                timed_call(n_t)
+                times.append(time.perf_counter() - t0)
     finally:
         frnn_stub.KNN_FN[0] = old_knn
-    med = float(np.median(times))
-    REPORT["reference_timing"] = {"rays_per_s": n_t / med, "rays": n_t, "repeats": n_time, "seconds": [float(t) for t in times], "cores": os.cpu_count(),
-                                  "torch_threads": int(torch.get_num_threads()), "V": V, "samples_per_ray": n_s + n_i,
-                                  "scene": tag, "call": "models/renderer.py SingleRenderer.forward(rays, detailed_output=False, **render_kwargs_test), unmodified; "
-                                  "FRNN stand-in: scipy cKDTree candidates + declared fp32 re-rank (oracle/knn.py)"}
+    if timing:
+        med = float(np.median(times))
+        REPORT["reference_timing"] = {"rays_per_s": n_t / med, "rays": n_t, "repeats": n_time, "seconds": [float(t) for t in times], "cores": os.cpu_count(),
+                                      "torch_threads": int(torch.get_num_threads()), "V": V, "samples_per_ray": n_s + n_i,
+                                      "scene": tag, "rays_are": f"every {step}th of the fixture's {n_rays} rays (strided over frame 0 of the 800x800 orbit)",
+                                      "call": "models/renderer.py SingleRenderer.forward(rays, detailed_output=False, **render_kwargs_test), unmodified; "
+                                      "FRNN stand-in: scipy cKDTree candidates + declared fp32 re-rank (oracle/knn.py)"}
+        print(f"    reference timing: {n_t} rays, median of {n_time}: {med:.2f} s = {n_t / med:.1f} rays/s ({os.cpu_count()} cores, {torch.get_num_threads()} torch threads)")
+    if not n_seeds:
+        return
     REPORT[f"{tag}.reference_self_sensitivity_seeds"] = {"rays_gt_1e-4": counts, "max": maxes, "n_rays": n_rays}
-    print(f"    reference timing: {n_t} rays, median of {n_time}: {med:.2f} s = {n_t / med:.1f} rays/s ({os.cpu_count()} cores, {torch.get_num_threads()} torch threads)")
     np.savez_compressed(os.path.join(GOLDEN, f"{tag}_sens.npz"), self_err=np.stack(errs), rays_gt_1e_4=np.asarray(counts, np.int64),
                         max_err=np.asarray(maxes, np.float32), state_sha256=np.array(state_digest(mlp_state) if mlp_state is not None else ""))
 
@@ -1112,7 +1124,7 @@ def gen_rays_fixture():
                         rays_o=ro[0].numpy(), rays_d=rd[0].numpy())
 
 
-KNOWN = ("scale", "train", "surface", "surf", "surfsens", "surf3", "trace", "paint", "edit", "deform", "surface140k", "train140k", "perturb", "edit140k", "trainloop")
+KNOWN = ("scale", "train", "surface", "surf", "surfsens", "reftime", "surf3", "trace", "paint", "edit", "deform", "surface140k", "train140k", "perturb", "edit140k", "trainloop")
 
 
 def main():
@@ -1127,6 +1139,8 @@ def main():
             gen_scale_fixture("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0)
         elif sys.argv[1] == "surfsens":   # the reference's own spread over 8 last-bit perturbations of the surf fixture's rays + its speed (reads render_v140k_surf.npz)
             gen_surf_sensitivity("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0)
+        elif sys.argv[1] == "reftime":    # only the timing record of surfsens (REPORT.json "reference_timing"); run it on an otherwise idle machine
+            gen_surf_sensitivity("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0, n_seeds=0)
         elif sys.argv[1] == "surf3":  # BASELINE configs[3] shape (32 + 32 samples, white background) on the same scene, at headline scale
             gen_scale_fixture("render_v140k_surf_c3", n_rays=1024, mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0,
                               n_samples=32, n_importance=32, white_bkgd=True)

@@ -641,8 +641,9 @@ def surf_scale(cuda_device):
     return mesh, state, common.make_model(mesh, state, cuda_device)
 
 
-@pytest.mark.parametrize("fixture", ["render_v140k_surf", "render_v140k_surf_c3"])
-def test_render_surface_scene_matches_reference_fixture(surf_scale, cuda_device, torch_mod, fixture):
+@pytest.mark.parametrize("fixture,precision", [("render_v140k_surf", "f16x2s"), ("render_v140k_surf", "f16x2"), ("render_v140k_surf", "fp32"),
+                                               ("render_v140k_surf_c3", "f16x2s")])
+def test_render_surface_scene_matches_reference_fixture(surf_scale, cuda_device, torch_mod, fixture, precision):
     """(render_v140k_surf_c3: the same scene in BASELINE configs[3]'s shape -- 32 + 32 samples, white background -- 1024 rays, so that
     config 3 is pinned to the reference at headline scale too; VERDICT r2 weak #1.)
     The headline shape on a scene WITH A SURFACE: tests/golden/render_v140k_surf.npz = 1536 strided
@@ -652,13 +653,18 @@ def test_render_surface_scene_matches_reference_fixture(surf_scale, cuda_device,
     render with directions nudged by 1 ulp moves 18 rays by > 1e-4, one by 1.6e-3), so the gates are
       (1) everything behind the sampler, on the REFERENCE'S OWN 128 depths per ray (render_at_depths): rgb / acc /
           normals <= 1e-4 and depth <= 2e-4 on EVERY ray;
-      (2) end to end: median <= 1e-6, rays beyond 1e-4 no more than the reference's own 1-ulp share + 1 %, near/far <= 2e-6,
-          coverage classes (acc == 0 / partial / opaque) of every ray equal to the reference's;
+      (2) end to end: median <= 1e-6, near/far <= 2e-6, coverage classes (acc == 0 / partial / opaque) of every ray equal to the
+          reference's, and the tail INSIDE THE REFERENCE'S OWN SPREAD: tests/golden/render_v140k_surf_sens.npz holds the
+          imported reference against itself under 8 independent last-bit perturbations of the ray directions (15 ... 26 of 1536 rays
+          beyond 1e-4, largest move 1.1e-3 ... 3.7e-2 per seed); every MLP arithmetic of the product (f16x2s, f16x2, fp32: one test each)
+          must have no more rays beyond 1e-4 than the worst seed and no ray further off than twice the worst seed's largest move
+          (the c3 fixture, which has one perturbation run only: that run's share + 1 %, and twice its largest move);
       (3) production call (ray sort, first/last-hit probe walk, zero-weight skip) == detailed call, bit for bit;
       (4) the field on the reference's own sample points: |sdf| <= 3e-6."""
     torch = torch_mod
     from neumesh_amd.renderer import make_render_cfg, render_at_depths, volume_render
     mesh, state, model = surf_scale
+    model.mlp_precision = precision
     f = common.golden(fixture)
     ns, ni, white = (int(f["N_samples"]), int(f["N_importance"]), bool(f["white_bkgd"])) if "N_samples" in f.files else (64, 64, False)
     assert int(f["V"]) == mesh.num_vertices and str(f["state_sha256"]) == common.state_digest(
@@ -719,7 +725,18 @@ def test_render_surface_scene_matches_reference_fixture(surf_scale, cuda_device,
     assert np.array_equal(acc_g == 0, acc_r == 0)
     assert np.abs(g["near_far"] - f["near_far"]).max() <= 2e-6
     assert np.median(err) <= 1e-6
-    assert (err > 1e-4).mean() <= (self_err > 1e-4).mean() + 0.01
+    sens_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture + "_sens.npz")
+    if os.path.exists(sens_path):     # the reference's own spread over 8 perturbation seeds (oracle/gen_golden.py surfsens)
+        sens = np.load(sens_path)
+        assert str(sens["state_sha256"]) == str(f["state_sha256"]) and np.array_equal(sens["self_err"][0], self_err)
+        n_max, e_max = int(sens["rays_gt_1e_4"].max()), float(sens["max_err"].max())
+        print(f"  [{precision}] rays beyond 1e-4: {int((err > 1e-4).sum())} (reference's own seeds: {sens['rays_gt_1e_4'].tolist()}), "
+              f"max {err.max():.2e} (seeds: {[float(f'{x:.2e}') for x in sens['max_err']]})")
+        assert int((err > 1e-4).sum()) <= n_max, (precision, int((err > 1e-4).sum()), n_max)
+        assert float(err.max()) <= 2.0 * e_max, (precision, float(err.max()), e_max)
+    else:
+        assert (err > 1e-4).mean() <= (self_err > 1e-4).mean() + 0.01
+        assert float(err.max()) <= max(2.0 * float(self_err.max()), 2e-3), (float(err.max()), float(self_err.max()))
     for key, tol in (("depth_volume", 2e-4), ("mask_volume", 1e-4), ("normals_volume", 1e-4)):
         e = np.abs(g[key] - f[key]).reshape(n, -1).max(-1)
         assert np.median(e) <= 1e-6, key
@@ -736,6 +753,8 @@ def test_render_surface_scene_matches_reference_fixture(surf_scale, cuda_device,
           f"{err[same].max() if same.any() else 0.0:.2e}; calm rays beyond 1e-4: {int((err[calm] > 1e-4).sum())}")
     assert same.sum() >= 20 and err[same].max() <= 1e-4, (int(same.sum()), float(err[same].max()) if same.any() else None)
     assert calm.sum() >= 0.15 * n and (err[calm] > 1e-4).mean() <= 0.01, (int(calm.sum()), int((err[calm] > 1e-4).sum()))
+    assert err[calm].max() <= 1e-3, float(err[calm].max())    # (an absolute cap on the calm rays' outliers, in every arithmetic)
+    model.mlp_precision = "f16x2s"
 
 
 @pytest.mark.gpu

@@ -54,10 +54,16 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / args.steps * 1e3, out0
 
-    ms_ref, ref = variant(H * W, 1, 0, 0, 0)
-    ms_ref, ref = variant(H * W, 1, 0, 0, 0)
-    rows = [dict(chunk=H * W, lanes=1, overlap=0, keep=0, prio=0, ms=round(ms_ref, 2), identical=True)]
-    print(f"one call, one stream: {ms_ref:.1f} ms", flush=True)
+    from neumesh_amd import _lib
+    cfg.flags = _lib.RENDER_NO_FORK
+    variant(H * W, 1, 0, 0, 0)
+    ms_nofork, ref = variant(H * W, 1, 0, 0, 0)
+    cfg.flags = 0
+    ms_ref, out = variant(H * W, 1, 0, 0, 0)
+    same = all(torch.equal(out[k], ref[k]) for k in ref)
+    rows = [dict(chunk=H * W, lanes=1, overlap=0, keep=0, prio=0, ms=round(ms_nofork, 2), identical=True, note="NM_RENDER_NO_FORK"),
+            dict(chunk=H * W, lanes=1, overlap=0, keep=0, prio=0, ms=round(ms_ref, 2), identical=bool(same))]
+    print(f"one call, one stream, no fork: {ms_nofork:.1f} ms; with the mid-point search on the side stream: {ms_ref:.1f} ms {'identical' if same else 'PIXELS DIFFER'}", flush=True)
     if args.variants:
         todo = [tuple(int(x) for x in v.split(":")) for v in args.variants.split(",")]
     else:
