@@ -356,8 +356,10 @@ def clock_under_load(lib, dev, work, micros=300, pause_s=0.02):
             time.sleep(pause_s)
 
     th = threading.Thread(target=sampler, daemon=True)
-    work()                       # enqueue first: the sampler's kernels then run beside it
-    th.start()
+    th.start()                   # (the render call below blocks until its frame is done -- it polls the fp16-range flag -- so the sampler runs beside it)
+    time.sleep(0.05)
+    samples.clear()              # (what was measured before the work started does not count)
+    work()
     torch.cuda.current_stream(dev).synchronize()
     stop.set()
     th.join(timeout=5)
@@ -638,17 +640,26 @@ def main():
             return ret
 
         rgb0 = None
+        # The warm-up runs exactly what the timed region runs, the in-stream kernel timing included: on a cold box the first use of the event
+        # path costs the HIP runtime about a second ONCE (measured round 5: first timed frame 1302 ms, the next two 335), which does not
+        # belong to a frame.  nm_profile_enable(1) before the timed region clears what the warm-up logged.
+        lib.nm_profile_enable(1)
+        rgb0_dev = None
         for i in range(warmup):
             ret = step(i)
             if i == 0 and keep_frame0 and rank == 0:
-                rgb0 = ret["rgb"].cpu().numpy()
+                rgb0_dev = ret["rgb"].clone()   # (brought to the host AFTER the timed region: on a cold box a device-to-host copy here was followed by
+                                                #  a 1-2 s stall inside the next frame -- tools/stall_diag.py, round 5 -- which is no part of a frame)
         fence()
         lib.nm_profile_enable(1)
+        stamps = []
         t0 = time.perf_counter()
         for i in range(warmup, total):
             step(i)
+            stamps.append(time.perf_counter() - t0)   # (host time at which step i's call returned: no synchronisation added)
         torch.cuda.synchronize()
         own = time.perf_counter() - t0     # this rank's own work (+ the collectives it took part in), before the closing barrier
+        run.last_step_returns_ms = [round(x * 1e3, 1) for x in stamps]
         fence()
         elapsed = time.perf_counter() - t0
         per_rank = [own]
@@ -662,6 +673,8 @@ def main():
             per_rank = [float(x) for x in allr.tolist()]
         prof = read_prof(lib)
         lib.nm_profile_enable(0)
+        if rgb0_dev is not None:
+            rgb0 = rgb0_dev.cpu().numpy()
         return elapsed, prof, rgb0, (rays[0] if (keep_frame0 and rays) else None), per_rank
 
     head_flags = (_lib.RENDER_FULL_PROBES | _lib.RENDER_NO_ZERO_SKIP) if args.data_independent else 0
@@ -755,6 +768,7 @@ def main():
                          "all_mlp_kernels_tflops": mlp_flop / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0,
                          "share_of_step_time": {k: prof[k]["ms"] / (elapsed * 1e3) for k in prof}},
             "per_rank_ms_per_step": [x / args.steps * 1e3 for x in per_rank],
+            "step_returns_ms": getattr(run, "last_step_returns_ms", None),   # host clock when each timed step's call returned, from the start of the timed region
             "knn_kernel": {"kernels": "nm_distance_kernel<chain> + nm_probe_bounds_kernel",
                            "bound": "instruction issue + scalar-load latency (index is L2/scalar-cache resident; not HBM)",
                            "searched_points_per_s": searched_per_s, "searched_points_per_frame": kd["points"] / max(n_frames, 1),

@@ -244,10 +244,10 @@ typedef struct nm_render_cfg {
  *                 dbg->d_all (required), dbg->near_far and dbg->sdf_all are written; rgb / depth / acc / normals may be NULL.
  *                 The training renderer places its samples with this call and queries the field with autograd afterwards. */
 #define NM_RENDER_SAMPLE_ONLY 32u
-/*   NO_FORK       (calc_normal) keep the mid-points' K-NN launch behind the sample points' nabla launch on the caller's stream instead of
- *                 running it beside that launch on a side stream of the call (two independent kernels, one bound by vector issue, one by
- *                 the matrix pipe) */
-#define NM_RENDER_NO_FORK 64u
+/*   FORK_MID      (calc_normal) run the mid-points' K-NN launch beside the sample points' nabla launch on a side stream of the call (two
+ *                 independent kernels, one bound by vector issue, one by the matrix pipe) instead of behind it.  Measured neutral for a
+ *                 one-call frame and slower with several chunk lanes: an A/B switch, not a default */
+#define NM_RENDER_FORK_MID 64u
 
 int64_t nm_render_workspace_bytes(const nm_render_cfg* cfg, int64_t R);
 

@@ -52,7 +52,7 @@ class RenderCfg(C.Structure):
 
 GRID_DEFER_BUDGET, GRID_TRIM = 1, 2   # nm_grid_set_option
 # nm_render_cfg.flags (include/neumesh_hip.h)
-RENDER_FULL_PROBES, RENDER_NO_ZERO_SKIP, RENDER_NO_RAY_SORT, RENDER_NO_MID_ORDER, RENDER_EAGER_NABLAS, RENDER_SAMPLE_ONLY, RENDER_NO_FORK = 1, 2, 4, 8, 16, 32, 64
+RENDER_FULL_PROBES, RENDER_NO_ZERO_SKIP, RENDER_NO_RAY_SORT, RENDER_NO_MID_ORDER, RENDER_EAGER_NABLAS, RENDER_SAMPLE_ONLY, RENDER_FORK_MID = 1, 2, 4, 8, 16, 32, 64
 
 
 class Camera(C.Structure):

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(CSRC, "libneumesh_hip.so")
 # of the MFMA tile code, phase stamps).  Loaded by a few tests and by the measurement tools only -- never by the package.
 TESTING_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(CSRC)), "tests", "_build", "libneumesh_hip_testing.so")
 SOURCES = ["nm_api.hip"]
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "neumesh_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [os.path.join("..", "..", "include", "neumesh_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wno-unused-value"]
 

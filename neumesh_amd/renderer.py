@@ -45,7 +45,7 @@ def alpha_to_w(alpha):
 # measurement script can flip them without touching the caller (none of them changes a result bit).
 _ENV_FLAGS = (("NEUMESH_FULL_PROBES", _lib.RENDER_FULL_PROBES), ("NEUMESH_NO_ZERO_SKIP", _lib.RENDER_NO_ZERO_SKIP),
               ("NEUMESH_NO_RAY_SORT", _lib.RENDER_NO_RAY_SORT), ("NEUMESH_NO_MID_ORDER", _lib.RENDER_NO_MID_ORDER),
-              ("NEUMESH_EAGER_NABLAS", _lib.RENDER_EAGER_NABLAS), ("NEUMESH_NO_FORK", _lib.RENDER_NO_FORK))
+              ("NEUMESH_EAGER_NABLAS", _lib.RENDER_EAGER_NABLAS), ("NEUMESH_FORK_MID", _lib.RENDER_FORK_MID))
 _ENV_TUNING = (("NEUMESH_CHAIN_TILES", "chain_tiles"), ("NEUMESH_FINE_GROUP", "fine_group_rays"), ("NEUMESH_MID_GROUP", "mid_group_rays"))
 
 
