@@ -859,8 +859,11 @@ def main():
             short("two_half_frame_chunks_on_two_streams (rayschunk = half a frame: the low-occupancy per-ray kernels of one chunk run beside the other chunk's "
                   "kernels; identical pixels; the per-kernel event times of this run overlap, so the roofline figures are taken from the one-stream headline run)",
                   chunk=(n_rays + 1) // 2, keep_frame0=True)
-            r = short("library_default_chunks (rayschunk = 65536, the value volume_render uses when the caller names none -- ~4 GB of workspace per lane instead "
-                      "of 40 --, chunks alternating between two streams; identical pixels)", chunk=65536, keep_frame0=True)
+            from neumesh_amd import renderer as _rmod
+            r = short(f"library_default_chunks (rayschunk = {_rmod.DEFAULT_RAYSCHUNK}, the value volume_render uses when the caller names none -- ~10 GB of workspace per lane instead "
+                      f"of 40 --, chunks alternating between {_rmod.DEFAULT_LANES} streams; identical pixels)", chunk=_rmod.DEFAULT_RAYSCHUNK, keep_frame0=True)
+            r65 = short("chunks_of_65536_rays (the round-4 library default; identical pixels)", chunk=65536)
+            cfgd["rayschunk_65536_ms_per_frame"] = r65.get("ms_per_frame")
             cfgd["default_rayschunk_ms_per_frame"] = r.get("ms_per_frame")
             # what a caller of volume_render gets without naming a chunk (render.py:211-218 passes 4096: a lower bound here), beside the one-call headline
             out["value_library_default_chunks"], out["ms_per_frame_library_default_chunks"] = r.get("value"), r.get("ms_per_frame")

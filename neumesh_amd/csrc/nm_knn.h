@@ -503,8 +503,8 @@ __device__ __forceinline__ void nm_distance_body(const NmGridView& g, const NmPo
 #endif
 }
 
-template <bool CHAIN, bool BUDGET = false>
-__global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_WAVES) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
+template <bool CHAIN, bool BUDGET = false, int BLK = NM_KNN_BLOCK>
+__global__ __launch_bounds__(BLK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_WAVES) void nm_distance_kernel(NmGridView g, NmPointSrc src, long long Q,
                                                           const float* __restrict__ verts,
                                                           const float* __restrict__ indicator, float w1,
                                                           float* __restrict__ ds_out, int* __restrict__ idx32_out,
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(NM_KNN_BLOCK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_W
                                                           float* __restrict__ radius_out,
                                                           const float* __restrict__ geo_table, int gdim, float* __restrict__ fg_out,
                                                           const float* __restrict__ col_table, int cdim, float* __restrict__ ft_out) {
-    nm_distance_body<CHAIN, BUDGET, NM_KNN_BLOCK>(g, src, Q, nm_launch_wave(), verts, indicator, w1, ds_out, idx32_out, idx64_out, w_out, grad_out, radius_out,
+    nm_distance_body<CHAIN, BUDGET, BLK>(g, src, Q, nm_launch_wave(), verts, indicator, w1, ds_out, idx32_out, idx64_out, w_out, grad_out, radius_out,
                                                   geo_table, gdim, fg_out, col_table, cdim, ft_out);
 }
 
@@ -821,14 +821,14 @@ __device__ __forceinline__ void nm_probe_bounds_body(const NmGridView& g, long l
     }
     if (searched && lane == 0 && n_searched) atomicAdd(searched, (unsigned long long)n_searched);
 }
-template <int S>
-__global__ __launch_bounds__(NM_KNN_BLOCK, NM_KNN_WAVES_PROBE) void nm_probe_bounds_kernel(NmGridView g, const float* __restrict__ rays_o,
+template <int S, int BLK = NM_KNN_BLOCK>
+__global__ __launch_bounds__(BLK, NM_KNN_WAVES_PROBE) void nm_probe_bounds_kernel(NmGridView g, const float* __restrict__ rays_o,
                                                                  const float* __restrict__ dirn, const float* __restrict__ nearfar0,
                                                                  long long R, int P, float thresh, const float* __restrict__ verts,
                                                                  const float* __restrict__ indicator, float w1,
                                                                  float* __restrict__ nearfar,
                                                                  unsigned long long* __restrict__ searched) {
-    nm_probe_bounds_body<S, NM_KNN_BLOCK>(g, nm_launch_wave(), rays_o, dirn, nearfar0, R, P, thresh, verts, indicator, w1, nearfar, searched);
+    nm_probe_bounds_body<S, BLK>(g, nm_launch_wave(), rays_o, dirn, nearfar0, R, P, thresh, verts, indicator, w1, nearfar, searched);
 }
 // pull form (see nm_distance_pull_kernel)
 template <int S>

@@ -119,8 +119,12 @@ class _Workspace:
 # NEUMESH_RENDER_STREAMS=1 restores the single-stream order.
 # Workspaces and side streams belong to one (device, caller stream) pair: calls issued on the same
 # stream are ordered by it (fork/join below), calls on different streams or devices never share scratch.
-DEFAULT_RAYSCHUNK = 1 << 16   # rays per nm_render_rays call unless NEUMESH_RAYSCHUNK says otherwise (_fused_chunk)
-WS_KEEP_BYTES = int(float(os.environ.get("NEUMESH_WS_KEEP_GB", "10")) * (1 << 30))   # pooled workspaces above this are returned after the call
+# rays per nm_render_rays call unless NEUMESH_RAYSCHUNK says otherwise (_fused_chunk).  Round 5, tools/overlap_sweep.py (800x800 frame, one call
+# 328-333 ms): chunks of 65 536 rays 338-352 ms on two lanes (and no better on 3 / 4 / 6: 332-361), 106 667: 334-345, 160 000: 324-326 on 2 / 3 / 4
+# lanes = the one-call time -- a chunk is ~26 launches plus their tails, and four of them per frame are few enough.  160 Ki rays = 10.3 GB of
+# workspace per lane (63 KB per ray), two lanes; still a quarter of what a one-call frame pins, halved when memory is short.
+DEFAULT_RAYSCHUNK = 160 * 1024
+WS_KEEP_BYTES = int(float(os.environ.get("NEUMESH_WS_KEEP_GB", "12")) * (1 << 30))   # pooled workspaces above this are returned after the call
 MAX_LANES = 8               # chunk lanes (streams with a workspace each) a call may use
 _POOLS = OrderedDict()      # (device, caller stream) -> its lanes' workspaces; least recently used first
 _POOLS_LOCK = threading.Lock()
@@ -146,7 +150,7 @@ def release_workspaces():
         _POOLS.clear()
 
 
-DEFAULT_LANES = 3            # (measured round 5, tools/overlap_sweep.py: 65 536-ray chunks on 2 / 3 / 4 / 6 lanes 346 / 334 / 342 / 337 ms per frame)
+DEFAULT_LANES = 2            # (more lanes measured no better, see DEFAULT_RAYSCHUNK)
 
 
 def _env_int(name: str, default: int) -> int:
@@ -164,7 +168,8 @@ def _n_lanes() -> int:
 def _overlap_settings(n_lanes: int):
     """(overlap, knn_keep, mlp_prio) of nm_render_cfg for a call cut into chunks on n_lanes streams.  With more than one chunk in flight the
     K-NN kernels of a chunk take the pull form and make room for the other chunks' MLP kernels (NEUMESH_OVERLAP=0 keeps the plain launches)."""
-    if n_lanes < 2 or not _env_int("NEUMESH_OVERLAP", DEFAULT_OVERLAP):
+    mode = _env_int("NEUMESH_OVERLAP", DEFAULT_OVERLAP)   # 2: the pull form also for a call on one lane (A/B of the kernel form itself)
+    if not mode or (n_lanes < 2 and mode != 2):
         return 0, 0, 0
     return 1, max(0, min(8, _env_int("NEUMESH_KNN_KEEP", 0))), max(0, min(3, _env_int("NEUMESH_MLP_PRIO", DEFAULT_MLP_PRIO)))
 
@@ -231,9 +236,9 @@ def _fused_chunk(lib, cfg, R: int, rayschunk: int, dev, extra_per_ray: int = 0) 
     """Rays per nm_render_rays call.  The reference's `rayschunk` (render.py passes 4096) bounds ITS memory; here every chunk is ~26 kernel
     launches whose cost is latency, not work, below ~10^5 rays (800x800 frame: 806 ms in chunks of 4096 rays, 362 ms at 65 536, 354 ms in
     one call) and the pixels do not depend on the chunking (bit-identical, tested), so the caller's value is only a LOWER bound: the call is
-    cut into chunks of NEUMESH_RAYSCHUNK rays.  The default is 65 536: ~2 % slower than one call for ~10 x less pooled
-    workspace (63 KB per ray: 4 GB per lane instead of 40 GB for an 800x800 call), so a validation render during training or a shared
-    GPU keeps its memory; it is halved while the two lanes' workspaces plus what the call itself allocates per ray (`extra_per_ray`:
+    cut into chunks of NEUMESH_RAYSCHUNK rays.  The default is DEFAULT_RAYSCHUNK = 163 840 (round 5: as fast as one call, a quarter of its
+    workspace: 63 KB per ray = 10 GB per lane instead of 40 GB for an 800x800 call; 65 536, the round-4 default, measured 3-5 % slower), so a
+    validation render during training or a shared GPU keeps its memory; it is halved while the lanes' workspaces plus what the call itself allocates per ray (`extra_per_ray`:
     the detailed-output tensors) would take more than half of the free device memory.  NEUMESH_RAYSCHUNK=0 honours the caller's value
     exactly; a larger value (bench.py: the whole frame) trades memory for the last 2 %."""
     want = max(1, min(int(rayschunk), R))

@@ -280,7 +280,7 @@ def test_data_parallel_replicas_never_free_the_parents_field_handle(monkeypatch)
 
 def test_fused_chunk_policy_lower_bound_and_memory_guard(monkeypatch):
     """renderer._fused_chunk (host logic, no GPU): the caller's rayschunk is a lower bound, the library's own chunk (NEUMESH_RAYSCHUNK,
-    default 65 536) is halved while two workspaces would take more than half of the free device memory, never below the caller's value;
+    default 163 840) is halved while two workspaces would take more than half of the free device memory, never below the caller's value;
     NEUMESH_RAYSCHUNK=0 honours the caller exactly."""
     import ctypes as C
     import torch
@@ -294,8 +294,8 @@ def test_fused_chunk_policy_lower_bound_and_memory_guard(monkeypatch):
     free = [int(400e9)]
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (free[0], int(288e9)))
     monkeypatch.delenv("NEUMESH_RAYSCHUNK", raising=False)
-    assert renderer.DEFAULT_RAYSCHUNK == 1 << 16                                        # ~4 GB of workspace per lane, not 40
-    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 1 << 16            # render.py's 4096: the library's chunk
+    assert renderer.DEFAULT_RAYSCHUNK == 160 * 1024                                     # ~10 GB of workspace per lane, not 40 (round 5: as fast as one call)
+    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 160 * 1024         # render.py's 4096: the library's chunk
     assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0", extra_per_ray=int(400e9) // 640000) == 4096   # the call's own tensors count
     monkeypatch.setenv("NEUMESH_RAYSCHUNK", str(1 << 20))
     assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 640000            # opt-in: whole frame in one call

@@ -43,18 +43,25 @@ def main():
     def variant(chunk, lanes, overlap, keep, prio):
         os.environ["NEUMESH_RAYSCHUNK"] = "0"
         os.environ["NEUMESH_RENDER_STREAMS"] = str(lanes)
-        os.environ["NEUMESH_OVERLAP"] = str(overlap)
+        os.environ["NEUMESH_OVERLAP"] = str(2 if (overlap and lanes == 1) else overlap)
         os.environ["NEUMESH_KNN_KEEP"] = str(keep)
         os.environ["NEUMESH_MLP_PRIO"] = str(prio)
         out0 = frame(0, chunk)
         torch.cuda.synchronize()
+        lib.nm_profile_enable(1)
         t0 = time.perf_counter()
         for i in range(1, total):
             frame(i, chunk)
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / args.steps * 1e3, out0
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        prof = bench.read_prof(lib)
+        lib.nm_profile_enable(0)
+        variant.knn_ms = prof["knn_distance"]["ms"] / args.steps
+        variant.mlp_ms = sum(prof[k]["ms"] for k in ("geo_mlp", "geo_mlp_tangent", "color_mlp")) / args.steps
+        return ms, out0
 
     from neumesh_amd import _lib
+    lib = _lib.load()
     variant(H * W, 1, 0, 0, 0)
     ms_ref, ref = variant(H * W, 1, 0, 0, 0)
     cfg.flags = _lib.RENDER_FORK_MID
@@ -80,7 +87,8 @@ def main():
             release_workspaces()
             continue
         rows.append(dict(chunk=chunk, lanes=lanes, overlap=overlap, keep=keep, prio=prio, ms=round(ms, 2), identical=bool(same)))
-        print(f"chunk {chunk:7d} lanes {lanes} overlap {overlap} keep {keep} prio {prio}: {ms:7.1f} ms  {'identical' if same else 'PIXELS DIFFER'}", flush=True)
+        rows[-1].update(knn_ms=round(variant.knn_ms, 2), mlp_ms=round(variant.mlp_ms, 2))
+        print(f"chunk {chunk:7d} lanes {lanes} overlap {overlap} keep {keep} prio {prio}: {ms:7.1f} ms  (K-NN kernels {variant.knn_ms:.1f}, MLP kernels {variant.mlp_ms:.1f})  {'identical' if same else 'PIXELS DIFFER'}", flush=True)
         if chunk * lanes > 400_000:
             release_workspaces()
     ms_end, _ = variant(H * W, 1, 0, 0, 0)
