@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <rocprim/block/block_radix_sort.hpp>   // stable block-level radix sort of the depth-bucket lists (nm_rays_order_sort_kernel)
+
 #include "nm_rays.h"
 
 // Where the query points of a launch come from.
@@ -28,7 +30,7 @@ struct NmPointSrc {
     // where the per-point outputs go: record index = q (compact) if out_stride == 0,
     // else r*out_stride + out_off + p (per-ray slots, so later stages can address them by slot)
     int out_stride, out_off;
-    // lane -> (ray, sample) assignment by depth buckets (optional, see nm_rays_order_kernel): groups of
+    // lane -> (ray, sample) assignment by depth buckets (optional, see nm_rays_order_sort_kernel): groups of
     // order_rays adjacent rays, E = roundup(order_rays*P, 64) entries per group,
     // order[group*E + j] = (ray - group*order_rays)*P + p of the j-th sample of the group (0xFFFF = padding)
     const unsigned short* order;
@@ -343,118 +345,81 @@ __global__ __launch_bounds__(256) void nm_rays_finalize_kernel(float* __restrict
 // final sorted samples (16 rays x 4 consecutive ones: 828 + 1452; the 2032 mid-points of 16 rays
 // ordered by depth: 559 + 856).  One workgroup per group of G rays; which lane evaluates which sample
 // changes no value.
-// Rounds 1-3 sorted the keys exactly (bitonic network in LDS, ~80 passes over up to 8192 keys: 6.5 ms per frame, the
-// largest per-ray kernel after round 4's other changes).  A wave only needs its 64 samples to be NEAR each other in depth, so
-// round 4 orders by BUCKET: 1024 depth buckets between the group's smallest and largest kept depth (finer than the vertex
-// spacing on the benchmark scene), histogram + scan + scatter, ids ascending inside EVERY bucket (the list is the same on every run).
+// A wave only needs its 64 samples to be NEAR each other in depth, so the list is ordered by BUCKET: 1024 depth buckets between the
+// group's smallest and largest kept depth (finer than the vertex spacing on the benchmark scene), ids ascending inside a bucket.
 // wgt (optional, [R][cap]): samples with wgt == 0 are dropped (padding behind the kept ones); counter (optional): += kept.
 #define NM_ORDER_BUCKETS 1024
-static inline size_t nm_order_lds_bytes(int n) { return (size_t)((n + 63) & ~63) * (4 + 2) + 64; }   // depth + id per list entry
-__global__ __launch_bounds__(256) void nm_rays_order_kernel(const float* __restrict__ d, long long R, int cap, int off,
-                                                            int P, int G, unsigned short* __restrict__ order,
-                                                            const float* __restrict__ wgt, unsigned long long* __restrict__ counter) {
-    extern __shared__ float nm_order_smem[];
-    __shared__ unsigned nm_hist[NM_ORDER_BUCKETS];    // counts, then running scatter positions
-    __shared__ unsigned nm_start[NM_ORDER_BUCKETS];   // first list position of each bucket
-    __shared__ unsigned nm_lo, nm_hi;                 // order-preserving keys of the smallest / largest kept depth
-    __shared__ unsigned nm_wsum[4];
+// The list -- buckets ascending, ids ascending inside every bucket -- by a STABLE block radix sort of the 11-bit bucket keys with the entries'
+// ids as values (thread t holds ids [t * IPT, (t + 1) * IPT): id order, which a stable sort keeps inside a bucket).  Deterministic by
+// construction (the same list on every run: ADVICE r4), and faster than what it replaces: rounds 1-3 sorted (depth, id) keys bitonically (6.5 ms
+// per frame), round 4 built the buckets by histogram + atomic scatter and re-ordered small buckets only (2.1 ms, but the importance passes
+// CROWD their buckets -- the new samples of a patch of adjacent rays cluster at the surface's depth, hundreds per bucket -- and those stayed in
+// atomic order, different from run to run; ranking them as well cost 5.0 ms).  This kernel: 1.4 ms per frame (rocprofv3, round 5).
+// IPT = entries per thread: E <= 256 * IPT (groups hold at most 8192 entries: nm_fine_group_rays / nm_mid_group_rays).
+template <int IPT>
+__global__ __launch_bounds__(256) void nm_rays_order_sort_kernel(const float* __restrict__ d, long long R, int cap, int off,
+                                                                 int P, int G, unsigned short* __restrict__ order,
+                                                                 const float* __restrict__ wgt, unsigned long long* __restrict__ counter) {
+    using Sort = rocprim::block_radix_sort<unsigned short, 256, IPT, unsigned short>;
+    __shared__ typename Sort::storage_type nm_sort_st;
+    __shared__ unsigned nm_lo, nm_hi, nm_kept;
     const long long grp = blockIdx.x;
     const int n = G * P, E = (n + 63) & ~63;
-    float* dep = nm_order_smem;                                              // [E] depth of entry i (NaN bit pattern = dropped)
-    unsigned short* ids = reinterpret_cast<unsigned short*>(dep + E);        // [E] the list
     const int t = threadIdx.x;
-    for (int b = t; b < NM_ORDER_BUCKETS; b += 256) nm_hist[b] = 0u;
-    if (t == 0) { nm_lo = 0xffffffffu; nm_hi = 0u; }
+    if (t == 0) { nm_lo = 0xffffffffu; nm_hi = 0u; nm_kept = 0u; }
     __syncthreads();
-    unsigned lo = 0xffffffffu, hi = 0u;
-    for (int i = t; i < E; i += 256) {
+    float dep[IPT];
+    unsigned lo = 0xffffffffu, hi = 0u, kept = 0u;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const int i = t * IPT + k;
         const int rl = i / P;
         const long long r = grp * G + rl;
-        float v = __int_as_float(0x7fc00000);
+        float v = __int_as_float(0x7fc00000);                                // NaN bit pattern = dropped
         if (i < n && r < R) {
             const long long g = r * cap + off + (i - rl * P);
             if (!(wgt && wgt[g] == 0.0f)) {
                 v = d[g];
-                if (v != v) v = 3.0e38f;                                     // (a NaN depth still gets a place: the last bucket -- but it must not
-                else {                                                       //  stretch the bucket range and collapse every real depth into bucket 0)
-                    const unsigned k = nm_float_key(v);
-                    lo = k < lo ? k : lo;
-                    hi = k > hi ? k : hi;
+                ++kept;
+                if (v != v) v = 3.0e38f;                                     // (a NaN depth still gets a place: the last bucket, outside the range)
+                else {
+                    const unsigned key = nm_float_key(v);
+                    lo = key < lo ? key : lo;
+                    hi = key > hi ? key : hi;
                 }
             }
         }
-        dep[i] = v;
+        dep[k] = v;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned l2 = (unsigned)__shfl_xor((int)lo, o), h2 = (unsigned)__shfl_xor((int)hi, o);
         lo = l2 < lo ? l2 : lo;
         hi = h2 > hi ? h2 : hi;
+        kept += (unsigned)__shfl_xor((int)kept, o);
     }
-    if ((t & 63) == 0) { atomicMin(&nm_lo, lo); atomicMax(&nm_hi, hi); }
+    if ((t & 63) == 0) { atomicMin(&nm_lo, lo); atomicMax(&nm_hi, hi); atomicAdd(&nm_kept, kept); }
     __syncthreads();
     const unsigned klo = nm_lo, khi = nm_hi;
-    // bucket of a depth: linear in the order-preserving key space would follow the float spacing, so go through the values
     const unsigned ulo = klo ^ ((klo >> 31) ? 0x80000000u : 0xffffffffu), uhi = khi ^ ((khi >> 31) ? 0x80000000u : 0xffffffffu);
     const float dlo = __uint_as_float(ulo), dhi = klo <= khi ? __uint_as_float(uhi) : dlo;
     const float scale = (float)NM_ORDER_BUCKETS / fmaxf(dhi - dlo, 1e-30f);
-    auto bucket = [&](float v) -> int {
+    unsigned short keys[IPT], ids[IPT];
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) {
+        const float v = dep[k];
         const float x = (v - dlo) * scale;
-        return x >= (float)(NM_ORDER_BUCKETS - 1) ? NM_ORDER_BUCKETS - 1 : (x > 0.f ? (int)x : 0);
-    };
-    for (int i = t; i < E; i += 256) {
-        const float v = dep[i];
-        if (v == v) atomicAdd(&nm_hist[bucket(v)], 1u);
+        const int b = x >= (float)(NM_ORDER_BUCKETS - 1) ? NM_ORDER_BUCKETS - 1 : (x > 0.f ? (int)x : 0);   
+        keys[k] = (v == v) ? (unsigned short)b : (unsigned short)NM_ORDER_BUCKETS;                           // dropped entries behind every bucket
+        ids[k] = (unsigned short)(t * IPT + k);
     }
-    __syncthreads();
-    {   // exclusive scan of the bucket counts: 4 buckets per thread, wave scan, 4 wave totals
-        unsigned c[4], tot = 0;
+    Sort().sort(keys, ids, nm_sort_st, 0, 11);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { c[u] = nm_hist[4 * t + u]; tot += c[u]; }
-        unsigned incl = tot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned up = (unsigned)__shfl_up((int)incl, o);
-            if ((t & 63) >= o) incl += up;
-        }
-        if ((t & 63) == 63) nm_wsum[t >> 6] = incl;
-        __syncthreads();
-        unsigned base = incl - tot;
-        for (int w = 0; w < (t >> 6); ++w) base += nm_wsum[w];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            nm_start[4 * t + u] = base;
-            nm_hist[4 * t + u] = base;
-            base += c[u];
-        }
+    for (int k = 0; k < IPT; ++k) {
+        const int pos = t * IPT + k;
+        if (pos < E) order[grp * E + pos] = keys[k] < NM_ORDER_BUCKETS ? ids[k] : (unsigned short)0xffffu;
     }
-    __syncthreads();
-    const unsigned kept = nm_wsum[0] + nm_wsum[1] + nm_wsum[2] + nm_wsum[3];
-    for (int i = t; i < E; i += 256) {
-        const float v = dep[i];
-        if (v == v) ids[atomicAdd(&nm_hist[bucket(v)], 1u)] = (unsigned short)i;
-    }
-    __syncthreads();
-    // ids ascending inside a bucket (the scatter above lands in atomic order, which differs from run to run): buckets hold a handful of
-    // entries -- insertion sort; a crowded bucket (many samples at one depth) gets a shell sort by its thread, so that the list, and with it
-    // which lane evaluates which sample, is the same on every run
-    for (int b = t; b < NM_ORDER_BUCKETS; b += 256) {
-        const unsigned s0 = nm_start[b], s1 = nm_hist[b], cnt = s1 - s0;
-        unsigned gap = 1u;
-        while (cnt > 64u && gap < cnt / 3u) gap = 3u * gap + 1u;
-        for (; gap >= 1u; gap /= 3u) {
-            for (unsigned a = s0 + gap; a < s1; ++a) {
-                const unsigned short x = ids[a];
-                unsigned q = a;
-                while (q >= s0 + gap && ids[q - gap] > x) { ids[q] = ids[q - gap]; q -= gap; }
-                ids[q] = x;
-            }
-            if (gap == 1u) break;
-        }
-    }
-    __syncthreads();
-    for (int i = t; i < E; i += 256) order[grp * E + i] = (unsigned)i < kept ? ids[i] : (unsigned short)0xffffu;
-    if (counter && t == 0 && kept) atomicAdd(counter, (unsigned long long)kept);
+    if (counter && t == 0 && nm_kept) atomicAdd(counter, (unsigned long long)nm_kept);
 }
 
 // sample points of a ray batch as an explicit [R,P,3] array (staged renderer: the field is queried

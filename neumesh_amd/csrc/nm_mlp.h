@@ -104,7 +104,7 @@ __device__ __forceinline__ long long nm_rec_index_local(const NmRecMap& m, const
     return r * m.stride + (m.slot ? (long long)m.slot[r * m.stride + m.off + p] : m.off + p);
 }
 
-// Point lists addressed through a depth-bucket order (nm_rays_order_kernel): point q = position in
+// Point lists addressed through a depth-bucket order (nm_rays_order_sort_kernel): point q = position in
 // the list; groups of G rays own E consecutive positions, valid entries first, 0xFFFF = no point.
 // order == nullptr: plain lists (every q < npts is a point).
 struct NmSlotMap {
