@@ -607,7 +607,7 @@ def main():
         torch.cuda.synchronize()
 
     def run(steps, warmup, precision=None, samples=128, normals=True, white=False, flags=0, keep_frame0=False, gather=True, hw=None,
-            weight_eps=0.0, chunk=None, mdl=None):
+            weight_eps=0.0, chunk=None, mdl=None, library_policy=False):
         """warmup + `steps` timed frames of one variant; returns (elapsed s [max over ranks], profile dict, rgb of frame 0 or None,
         rays of frame 0 or None, per-rank seconds up to the end of the rank's own work)."""
         m = mdl or model
@@ -621,6 +621,13 @@ def main():
         rc = chunk or args.rayschunk or n_rays
 
         def render(ro, rd):
+            if library_policy:   # what render.py gets: its rayschunk = 4096 (a lower bound here), the chunking chosen by renderer._fused_chunk
+                saved = os.environ.pop("NEUMESH_RAYSCHUNK", None)
+                try:
+                    return render_rays_fused(m, ro, rd, cfg, 4096, tables=tables)
+                finally:
+                    if saved is not None:
+                        os.environ["NEUMESH_RAYSCHUNK"] = saved
             return render_rays_fused(m, ro, rd, cfg, rc, tables=tables)   # hw frames: chunks of one headline frame
 
         if one_frame:   # ONE frame per step over all ranks: every rank builds and renders the rays of its interleaved tiles
@@ -860,8 +867,8 @@ def main():
                   "kernels; identical pixels; the per-kernel event times of this run overlap, so the roofline figures are taken from the one-stream headline run)",
                   chunk=(n_rays + 1) // 2, keep_frame0=True)
             from neumesh_amd import renderer as _rmod
-            r = short(f"library_default_chunks (rayschunk = {_rmod.DEFAULT_RAYSCHUNK}, the value volume_render uses when the caller names none -- ~10 GB of workspace per lane instead "
-                      f"of 40 --, chunks alternating between {_rmod.DEFAULT_LANES} streams; identical pixels)", chunk=_rmod.DEFAULT_RAYSCHUNK, keep_frame0=True)
+            r = short(f"library_default_chunks (the caller passes render.py's rayschunk = 4096, the library cuts the call into equal chunks of at most {_rmod.DEFAULT_RAYSCHUNK} rays "
+                      f"-- ~10 GB of workspace per lane instead of 40 --, alternating between {_rmod.DEFAULT_LANES} streams; identical pixels)", library_policy=True, keep_frame0=True)
             r65 = short("chunks_of_65536_rays (the round-4 library default; identical pixels)", chunk=65536)
             cfgd["rayschunk_65536_ms_per_frame"] = r65.get("ms_per_frame")
             cfgd["default_rayschunk_ms_per_frame"] = r.get("ms_per_frame")

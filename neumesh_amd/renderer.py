@@ -256,7 +256,11 @@ def _fused_chunk(lib, cfg, R: int, rayschunk: int, dev, extra_per_ray: int = 0) 
         if 0 <= need <= free // 2:
             break
         chunk = max(want, chunk // 2)
-    return chunk
+    if os.environ.get("NEUMESH_RAYSCHUNK"):
+        return chunk                              # a size the user named is taken as named
+    # the built-in default: equal chunks -- 640 000 rays are four chunks of 160 000, not three of 163 840 and one of 148 480 (the lanes finish together)
+    balanced = -(-R // -(-R // chunk))
+    return balanced if balanced >= want else chunk
 
 
 def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress, u_blocks=None):

@@ -295,11 +295,12 @@ def test_fused_chunk_policy_lower_bound_and_memory_guard(monkeypatch):
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (free[0], int(288e9)))
     monkeypatch.delenv("NEUMESH_RAYSCHUNK", raising=False)
     assert renderer.DEFAULT_RAYSCHUNK == 160 * 1024                                     # ~10 GB of workspace per lane, not 40 (round 5: as fast as one call)
-    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 160 * 1024         # render.py's 4096: the library's chunk
+    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 160000             # render.py's 4096: the library's chunk (four EQUAL chunks of <= 163 840 rays)
+    assert renderer._fused_chunk(lib, cfg, 163841, 4096, "cuda:0") == 81921              # two chunks, balanced
     assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0", extra_per_ray=int(400e9) // 640000) == 4096   # the call's own tensors count
     monkeypatch.setenv("NEUMESH_RAYSCHUNK", str(1 << 20))
     assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 640000            # opt-in: whole frame in one call
-    assert renderer._fused_chunk(lib, cfg, 1920000, 4096, "cuda:0") == 1 << 20          # config 4: two chunks of <= 2^20 rays
+    assert renderer._fused_chunk(lib, cfg, 1920000, 4096, "cuda:0") == 1 << 20          # config 4: two chunks of <= 2^20 rays (a named size is taken as named)
     assert renderer._fused_chunk(lib, cfg, 500, 4096, "cuda:0") == 500
     free[0] = int(16e9)                                                                 # a nearly full device: halve until two workspaces fit
     c = renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0")
