@@ -18,6 +18,10 @@
 //     its last `min_alive` waves (the SIMD counts are shared by every K-NN launch in flight);
 //   * with wanted == 0 the launch fills the chip like the grid-mapped form.
 // Which wave evaluates which packet changes no result bit (every packet's outputs depend on its own queries only).
+// MEASURED (round 5, profiles/r05_overlap_sweep.txt, 70 variants in one call, identical pixels throughout): yielding makes the frame 5-15 % SLOWER --
+// one K-NN wave per SIMD beside two MLP workgroups runs at ~20 % of the kernels' full rate (its dependent chain issues an instruction every ~11 cycles
+// even alone) while the MLP kernels lose issue slots to it -- so the mode is opt-in (nm_render_cfg.overlap) and the default launches are the
+// grid-mapped one-wave workgroups of nm_knn.h.  Two K-NN waves per SIMD beside the MLP would need <= 64-register traversal kernels.
 struct NmYield {
     int wanted;          // MLP launches that want room (queued or running)
     int pad[15];
