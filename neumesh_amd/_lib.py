@@ -137,6 +137,8 @@ TESTING_SIGNATURES = {
     "nm_selfcheck_field": (C.c_int, [_P, _P, C.POINTER(FieldTables), _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "nm_debug_last_deferred": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
     "nm_debug_simd_keys": (C.c_int, [_P, C.c_int, _P]),
+    "nm_debug_knn_pull": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
+    "nm_debug_yield_add": (C.c_int, [C.c_int]),
     "nm_debug_gemm": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int,
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
 }

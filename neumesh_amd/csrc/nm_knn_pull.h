@@ -93,3 +93,29 @@ __global__ __launch_bounds__(64, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_WAVES) void
                                                      geo_table, gdim, fg_out, col_table, cdim, ft_out)))
 }
 __global__ void nm_yield_add_kernel(NmYield* y, int delta) { atomicAdd(&y->wanted, delta); }
+
+#ifdef NM_TESTING
+// Test / measurement library only (tools/coresidency_probe.py): the PLAIN K-NN traversal -- no projection, no gathers: 62 registers, so that
+// TWO of its waves fit beside two MLP workgroups on a SIMD -- in the pull form, to measure what a <= 64-register traversal kernel would get
+// under the MLP kernels before anyone builds the split traversal / epilogue pair.
+__device__ __forceinline__ void nm_knn_plain_body(const NmGridView& g, const NmPointSrc& src, long long Q, long long wave, long long* __restrict__ idx_out,
+                                                  float* __restrict__ d2_out) {
+    long long q, r;
+    int p;
+    const bool active = nm_lane_query(src, Q, q, r, p, 0, wave);
+    float x = 0.f, y = 0.f, z = 0.f, dep = 0.f;
+    if (active) nm_fetch_point(src, r, p, x, y, z, dep);
+    unsigned long long kk[8];
+    nm_knn_wave<8, false, 64>(g, x, y, z, active, kk);
+    if (!active) return;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        idx_out[q * 8 + k] = (long long)nm_key_idx(kk[k]);
+        d2_out[q * 8 + k] = nm_key_d2(kk[k]);
+    }
+}
+__global__ __launch_bounds__(64, 8) void nm_knn_pull_kernel(NmGridView g, NmPointSrc src, long long Q, NmPull pl, long long* __restrict__ idx_out,
+                                                            float* __restrict__ d2_out) {
+    NM_PULL_LOOP((nm_knn_plain_body(g, src, Q, wave, idx_out, d2_out)))
+}
+#endif
