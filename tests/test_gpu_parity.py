@@ -1619,3 +1619,47 @@ def test_chunks_in_flight_with_pull_form_knn_render_identical_pixels(surf_scale,
         assert torch.equal(rgb_a, rgb_b) and torch.equal(dep_a, dep_b) and torch.equal(ex_a["mask_volume"], ex_b["mask_volume"])
         if kw["calc_normal"]:
             assert torch.equal(ex_a["normals_volume"], ex_b["normals_volume"])
+
+
+# --------------------------------------------------------------------- fp16-range fall-back of the split-half MLP modes
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f16x2s", "f16x2"])
+def test_fp16_range_overflow_falls_back_to_fp32(small, cuda_device, torch_mod, precision):
+    """A weight set whose activations leave the fp16 range (a checkpoint the split-half format does not fit): the kernels raise the device flag,
+    the renderer notices after the call, warns, switches the model to the fp32 kernels and renders the call AGAIN -- what the caller gets is the
+    fp32 render bit for bit, never the Inf / NaN-affected first attempt.  Here: the second colour layer's weight-norm gain x 3e5 (the ReLU
+    activations behind it reach ~1e6; the sigmoid output stays finite in fp32)."""
+    import warnings
+    torch = torch_mod
+    from neumesh_amd import renderer as rmod
+    from neumesh_amd import synthetic
+    mesh, state, _ = small
+    model = common.make_model(mesh, state, cuda_device)     # (its own model: the weights are edited below)
+    H = W = 48
+    o, d = synthetic.camera_rays(synthetic.orbit_pose(5), synthetic.pinhole_intrinsics(H, W), H, W)
+    o, d = _t(o, cuda_device), _t(d, cuda_device)
+    kw = dict(calc_normal=True, perturb=False, detailed_output=False, rayschunk=H * W)
+    lin = [m for m in model.modules() if hasattr(m, "weight_g") and m.weight_g.shape[0] == 256][-1]    # the last 256-wide weight-normed layer: colour network
+    with torch.no_grad():
+        lin.weight_g.mul_(3e5)
+    model.mlp_precision = "fp32"
+    with torch.no_grad():
+        rgb_ref, dep_ref, ex_ref = rmod.volume_render(o, d, model, **kw)
+    assert bool(torch.isfinite(rgb_ref).all())
+    model.mlp_precision = precision
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            rgb, dep, ex = rmod.volume_render(o, d, model, **kw)
+    assert any("fp16 range" in str(w.message) for w in caught), [str(w.message)[:80] for w in caught]
+    assert model.mlp_precision == "fp32"                                   # the model stays on the fp32 kernels from here on
+    assert torch.equal(rgb, rgb_ref) and torch.equal(dep, dep_ref) and torch.equal(ex["normals_volume"], ex_ref["normals_volume"])
+    model.mlp_precision = precision                                        # point-wise calls notice too
+    xyz = _t(np.asarray(mesh.vertices[:512], np.float32) * 1.01, cuda_device)
+    dirs = torch.nn.functional.normalize(torch.ones_like(xyz), dim=-1)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            model.forward(xyz, dirs)
+            model.check_fp16_range(force=True)
+    assert model.mlp_precision == "fp32" and any("fp16 range" in str(w.message) for w in caught)
