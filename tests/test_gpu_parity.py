@@ -1326,7 +1326,7 @@ def test_texture_editable_wrapper_forward_and_render(small, cuda_device, torch_m
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_ref,rotated", [(1, False), (2, False), (2, True)])
-def test_texture_editing_inside_the_fused_renderer(small, cuda_device, torch_mod, n_ref, rotated):
+def test_texture_editing_inside_the_fused_renderer(small, cuda_device, torch_mod, monkeypatch, n_ref, rotated):
     """nm_render_cfg.n_edit: a TextureEditableNeuMesh without a rigid transform is rendered by nm_render_rays itself (painted
     shares, reference colour from the edited table, blend -- editing/texture_neumesh/texture_neumesh.py:79-121) and must
     give the staged renderer's image, which evaluates the wrapper's forward() through the model methods: colours to 2e-6
@@ -1366,7 +1366,13 @@ def test_texture_editing_inside_the_fused_renderer(small, cuda_device, torch_mod
         img_c, depth_c, _ = volume_render(ro, rd, wrap, rayschunk=17, **kw)
         st_out = render_rays_staged(wrap, ro, rd, make_render_cfg(calc_normal=True), 4096, 1 << 20)
         img0, depth0, _ = volume_render(ro, rd, model, rayschunk=4096, **kw)
-    assert torch.equal(img, img_c) and torch.equal(depth, depth_c)
+        # ... and with three chunks in flight, K-NN kernels in the pull form (the mid-point pass hands its neighbour lists to the blend)
+        monkeypatch.setenv("NEUMESH_RENDER_STREAMS", "3")
+        monkeypatch.setenv("NEUMESH_OVERLAP", "1")
+        img_o, depth_o, _ = volume_render(ro, rd, wrap, rayschunk=17, **kw)
+        monkeypatch.delenv("NEUMESH_RENDER_STREAMS")
+        monkeypatch.delenv("NEUMESH_OVERLAP")
+    assert torch.equal(img, img_c) and torch.equal(depth, depth_c) and torch.equal(img, img_o) and torch.equal(depth, depth_o)
     assert torch.equal(depth, st_out["depth_volume"]) and torch.equal(ex["mask_volume"], st_out["mask_volume"]) and torch.equal(depth, depth0)
     assert torch.equal(ex["normals_volume"], st_out["normals_volume"])
     np.testing.assert_allclose(img.cpu().numpy(), st_out["rgb"].cpu().numpy(), atol=2e-6)
