@@ -343,8 +343,8 @@ __device__ __forceinline__ float nm_bound_from_neighbours_lds(const float* __res
 }
 
 // ----------------------------------------------------------------------------- plain K-NN
-template <int K>
-__global__ __launch_bounds__(NM_KNN_BLOCK) void nm_knn_kernel(NmGridView g, NmPointSrc src, long long Q, int Kout,
+template <int K, int BLK = NM_KNN_BLOCK>
+__global__ __launch_bounds__(BLK) void nm_knn_kernel(NmGridView g, NmPointSrc src, long long Q, int Kout,
                                                      long long* __restrict__ idx_out, float* __restrict__ d2_out) {
     long long q, r;
     int p;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(NM_KNN_BLOCK) void nm_knn_kernel(NmGridView g, NmPo
     float x = 0.f, y = 0.f, z = 0.f, dep = 0.f;
     if (active) nm_fetch_point(src, r, p, x, y, z, dep);
     unsigned long long kk[K];
-    nm_knn_wave<K>(g, x, y, z, active, kk);
+    nm_knn_wave<K, false, BLK>(g, x, y, z, active, kk);
     if (!active) return;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
