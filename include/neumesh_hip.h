@@ -184,8 +184,8 @@ typedef struct nm_render_cfg {
     float probe_thresh;          /* 0.1 (distance_thresh) */
     float near_bypass, far_bypass; /* < 0 => unset */
     uint32_t flags;              /* NM_RENDER_* bits, 0 = defaults */
-    int32_t chain_tiles;         /* regular-grid passes: max 4-sample tiles a wave chains; 0 = default (32) */
-    int32_t fine_group_rays;     /* rays per depth-bucket group of an importance pass: 64/128/256/512; 0 = default (128) */
+    int32_t chain_tiles;         /* regular-grid passes: max 4-sample tiles a wave chains; 0 = default (8) */
+    int32_t fine_group_rays;     /* rays per depth-bucket group of an importance pass: 64/128/256/512; 0 = default (512) */
     int32_t mid_group_rays;      /* rays per depth-bucket group of the mid-point pass: 16/32/64; 0 = default (64) */
     float weight_eps;            /* 0 = exact (default).  > 0: a mid-point (and the nabla of a sample) whose visibility
                                     weight is below weight_eps is treated like one of weight 0 in the radiance / normal
