@@ -25,7 +25,9 @@
 #include "nm_edit.h"
 #include "nm_train.h"
 
+#ifndef NM_PROBE_STEP
 #define NM_PROBE_STEP 8  // probes per ray and step of nm_probe_bounds_kernel: 8 = 8 rays per wave (measured: K-NN per frame 99.9 ms with 4, 97.2 with 8, 101.7 with 16)
+#endif
 
 // ------------------------------------------------------------------------------ error state
 static thread_local std::string g_err;
