@@ -119,12 +119,13 @@ class _Workspace:
 # NEUMESH_RENDER_STREAMS=1 restores the single-stream order.
 # Workspaces and side streams belong to one (device, caller stream) pair: calls issued on the same
 # stream are ordered by it (fork/join below), calls on different streams or devices never share scratch.
-# rays per nm_render_rays call unless NEUMESH_RAYSCHUNK says otherwise (_fused_chunk).  Round 5, tools/overlap_sweep.py (800x800 frame, one call
-# 328-333 ms): chunks of 65 536 rays 338-352 ms on two lanes (and no better on 3 / 4 / 6: 332-361), 106 667: 334-345, 160 000: 324-326 on 2 / 3 / 4
-# lanes = the one-call time -- a chunk is ~26 launches plus their tails, and four of them per frame are few enough.  160 Ki rays = 10.3 GB of
-# workspace per lane (63 KB per ray), two lanes; still a quarter of what a one-call frame pins, halved when memory is short.
-DEFAULT_RAYSCHUNK = 160 * 1024
-WS_KEEP_BYTES = int(float(os.environ.get("NEUMESH_WS_KEEP_GB", "12")) * (1 << 30))   # pooled workspaces above this are returned after the call
+# rays per nm_render_rays call unless NEUMESH_RAYSCHUNK says otherwise (_fused_chunk).  Round 5, tools/overlap_sweep.py and the bench line's rows
+# (800x800 frame, same process): chunks of 65 536 rays on two lanes 325-352 ms (and no better on 3 / 4 / 6 lanes), four chunks of 160 000: 310.7-327.9,
+# one call: 311.5-329.0, TWO chunks of 320 000 on two lanes: 304.3-319.7 -- always the fastest: a chunk is ~26 launches plus their tails, and one chunk's
+# tails run under the other's kernels.  320 Ki rays = 20.6 GB of workspace per lane (63 KB per ray), 41 GB pooled for two lanes of the 288 GB;
+# the chunk is halved while the lanes' workspaces would not fit a QUARTER of the free device memory, so a shared or nearly full GPU gets small chunks.
+DEFAULT_RAYSCHUNK = 320 * 1024
+WS_KEEP_BYTES = int(float(os.environ.get("NEUMESH_WS_KEEP_GB", "24")) * (1 << 30))   # pooled workspaces above this are returned after the call
 MAX_LANES = 8               # chunk lanes (streams with a workspace each) a call may use
 _POOLS = OrderedDict()      # (device, caller stream) -> its lanes' workspaces; least recently used first
 _POOLS_LOCK = threading.Lock()
@@ -236,10 +237,10 @@ def _fused_chunk(lib, cfg, R: int, rayschunk: int, dev, extra_per_ray: int = 0) 
     """Rays per nm_render_rays call.  The reference's `rayschunk` (render.py passes 4096) bounds ITS memory; here every chunk is ~26 kernel
     launches whose cost is latency, not work, below ~10^5 rays (800x800 frame: 806 ms in chunks of 4096 rays, 362 ms at 65 536, 354 ms in
     one call) and the pixels do not depend on the chunking (bit-identical, tested), so the caller's value is only a LOWER bound: the call is
-    cut into chunks of NEUMESH_RAYSCHUNK rays.  The default is DEFAULT_RAYSCHUNK = 163 840 (round 5: as fast as one call, a quarter of its
-    workspace: 63 KB per ray = 10 GB per lane instead of 40 GB for an 800x800 call; 65 536, the round-4 default, measured 3-5 % slower), so a
-    validation render during training or a shared GPU keeps its memory; it is halved while the lanes' workspaces plus what the call itself allocates per ray (`extra_per_ray`:
-    the detailed-output tensors) would take more than half of the free device memory.  NEUMESH_RAYSCHUNK=0 honours the caller's value
+    cut into equal chunks of at most NEUMESH_RAYSCHUNK rays.  The default is DEFAULT_RAYSCHUNK = 327 680 (round 5: an 800x800 frame as two chunks
+    on two streams is 2-3 % FASTER than one call at the same 41 GB of workspace; 65 536, the round-4 default, measured 3-5 % slower than one call); it is
+    halved while the lanes' workspaces plus what the call itself allocates per ray (`extra_per_ray`: the detailed-output tensors) would take more than a
+    quarter of the free device memory, so a validation render during training or a shared GPU keeps its memory.  NEUMESH_RAYSCHUNK=0 honours the caller's value
     exactly; a larger value (bench.py: the whole frame) trades memory for the last 2 %."""
     want = max(1, min(int(rayschunk), R))
     own = int(os.environ.get("NEUMESH_RAYSCHUNK") or DEFAULT_RAYSCHUNK)
@@ -253,12 +254,12 @@ def _fused_chunk(lib, cfg, R: int, rayschunk: int, dev, extra_per_ray: int = 0) 
     free -= int(extra_per_ray) * R            # tensors of the whole call (allocated before the first chunk runs)
     while chunk > want:
         need = int(lib.nm_render_workspace_bytes(C.byref(cfg), chunk)) * (1 if chunk >= R else min(_n_lanes(), -(-R // chunk)))
-        if 0 <= need <= free // 2:
+        if 0 <= need <= free // (2 if os.environ.get("NEUMESH_RAYSCHUNK") else 4):   # (a size the user named: half of the free memory)
             break
         chunk = max(want, chunk // 2)
     if os.environ.get("NEUMESH_RAYSCHUNK"):
         return chunk                              # a size the user named is taken as named
-    # the built-in default: equal chunks -- 640 000 rays are four chunks of 160 000, not three of 163 840 and one of 148 480 (the lanes finish together)
+    # the built-in default: equal chunks -- 640 000 rays are two chunks of 320 000, not one of 327 680 and one of 312 320 (the lanes finish together)
     balanced = -(-R // -(-R // chunk))
     return balanced if balanced >= want else chunk
 

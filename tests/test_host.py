@@ -280,7 +280,7 @@ def test_data_parallel_replicas_never_free_the_parents_field_handle(monkeypatch)
 
 def test_fused_chunk_policy_lower_bound_and_memory_guard(monkeypatch):
     """renderer._fused_chunk (host logic, no GPU): the caller's rayschunk is a lower bound, the library's own chunk (NEUMESH_RAYSCHUNK,
-    default 163 840) is halved while two workspaces would take more than half of the free device memory, never below the caller's value;
+    default 327 680) is halved while the lanes' workspaces would take more than a quarter of the free device memory, never below the caller's value;
     NEUMESH_RAYSCHUNK=0 honours the caller exactly."""
     import ctypes as C
     import torch
@@ -294,9 +294,12 @@ def test_fused_chunk_policy_lower_bound_and_memory_guard(monkeypatch):
     free = [int(400e9)]
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (free[0], int(288e9)))
     monkeypatch.delenv("NEUMESH_RAYSCHUNK", raising=False)
-    assert renderer.DEFAULT_RAYSCHUNK == 160 * 1024                                     # ~10 GB of workspace per lane, not 40 (round 5: as fast as one call)
-    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 160000             # render.py's 4096: the library's chunk (four EQUAL chunks of <= 163 840 rays)
-    assert renderer._fused_chunk(lib, cfg, 163841, 4096, "cuda:0") == 81921              # two chunks, balanced
+    assert renderer.DEFAULT_RAYSCHUNK == 320 * 1024                                     # 20 GB of workspace per lane: two chunks of an 800x800 frame beat one call (round 5)
+    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 320000             # render.py's 4096: the library's chunk (two EQUAL chunks of <= 327 680 rays)
+    assert renderer._fused_chunk(lib, cfg, 327681, 4096, "cuda:0") == 163841             # two chunks, balanced
+    free[0] = int(100e9)                                                                # a quarter of the free memory must hold the lanes' workspaces: 160 000-ray chunks here
+    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 160000
+    free[0] = int(400e9)
     assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0", extra_per_ray=int(400e9) // 640000) == 4096   # the call's own tensors count
     monkeypatch.setenv("NEUMESH_RAYSCHUNK", str(1 << 20))
     assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 640000            # opt-in: whole frame in one call
