@@ -882,6 +882,9 @@ def main():
             cfgd["default_rayschunk_ms_per_frame"] = r.get("ms_per_frame")
             # what a caller of volume_render gets without naming a chunk (render.py:211-218 passes 4096: a lower bound here), beside the one-call headline
             out["value_library_default_chunks"], out["ms_per_frame_library_default_chunks"] = r.get("value"), r.get("ms_per_frame")
+            out["value_is"] = ("`value` / `roofline`: the frame as ONE nm_render_rays call on one stream (every kernel launch alone on the chip: the per-kernel event times are "
+                               "the kernels' own).  `value_library_default_chunks`: the same frame through the library's own chunking -- equal chunks of <= 327 680 rays "
+                               "alternating between two streams, what render.py's renderer(...) call gets -- whose kernels overlap across the two streams (identical pixels)")
             short("weight_eps_1e-10 (mid-points of visibility weight < 1e-10 not evaluated: the one variant that is not bit-identical; "
                   "rgb / normals move by < 127e-10, depth / acc not at all)", weight_eps=1e-10, keep_frame0=True)
             short("config3_shape (64 samples/ray, white background)", samples=64, white=True)
