@@ -425,6 +425,9 @@ def gen_surf_sensitivity(tag="render_v140k_surf", mlp_state=None, s_value=400.0,
     import torch
     from scipy.spatial import cKDTree
     from oracle import knn as oknn
+    load_before = os.getloadavg()      # before this process has done any work of its own
+    if timing and not n_seeds and load_before[0] > 1.0:   # the timing-only mode writes a RECORD: refuse on a busy machine
+        raise SystemExit(f"reftime: load average {load_before[0]:.2f} > 1 -- run it on an otherwise idle machine")
     f = np.load(os.path.join(GOLDEN, f"{tag}.npz"))
     V, n_rays = int(f["V"]), f["rays_o"].shape[0]
     print(f"[{tag}_sens] V={V} rays={n_rays}, {n_seeds} perturbation seeds")
@@ -484,6 +487,7 @@ def gen_surf_sensitivity(tag="render_v140k_surf", mlp_state=None, s_value=400.0,
         med = float(np.median(times))
         REPORT["reference_timing"] = {"rays_per_s": n_t / med, "rays": n_t, "repeats": n_time, "seconds": [float(t) for t in times], "cores": os.cpu_count(),
                                       "torch_threads": int(torch.get_num_threads()), "V": V, "samples_per_ray": n_s + n_i,
+                                      "loadavg_before_start": [float(x) for x in load_before], "loadavg_after": [float(x) for x in os.getloadavg()],
                                       "scene": tag, "rays_are": f"every {step}th of the fixture's {n_rays} rays (strided over frame 0 of the 800x800 orbit)",
                                       "call": "models/renderer.py SingleRenderer.forward(rays, detailed_output=False, **render_kwargs_test), unmodified; "
                                       "FRNN stand-in: scipy cKDTree candidates + declared fp32 re-rank (oracle/knn.py)"}
