@@ -77,10 +77,10 @@ class _Mesh:
 # 800x800 frame per chunk for config 4): the library's own policy -- the caller's rayschunk is only a lower bound, renderer._fused_chunk --
 # is switched off so that each row measures what its label says.
 os.environ.setdefault("NEUMESH_RAYSCHUNK", "0")
-# The one-call frame's 40 GB workspace stays pooled between frames: handed back after every call (the library's policy above 12 GB) it can
+# The one-call frame's 40 GB workspace stays pooled between frames: handed back after every call (the library's policy above 24 GB, NEUMESH_WS_KEEP_GB) it can
 # come back SPLIT by the small tensors allocated in between, the next frame then takes a fresh 40 GB from the driver, and on a box whose memory
 # was just released by another process that costs 1-2 s inside ONE frame (round 5: first timed frame 1302-1918 ms, the rest 335;
-# tools/stall_diag.py).  Nothing of a frame's work; the library's default chunks (10 GB per lane) are below the limit and never handed back.
+# tools/stall_diag.py).  Nothing of a frame's work; the library's default chunks (20.6 GB per lane) are below the limit and never handed back.
 os.environ.setdefault("NEUMESH_WS_KEEP_GB", "64")
 
 
@@ -600,7 +600,7 @@ def main():
     mesh, model = build_scene(args.V, dev, scene=args.scene)
     from neumesh_amd import synthetic
     from neumesh_amd.rays import make_rays
-    from neumesh_amd.sharded import render_frame_sharded
+    from neumesh_amd.sharded import all_gather_rows_async, render_frame_sharded_async
     n_rays = args.H * args.W
     intr = synthetic.pinhole_intrinsics(args.H, args.W)
     one_frame = world > 1 and args.shard == "frame"
@@ -642,13 +642,27 @@ def main():
             rays = [make_rays(synthetic.orbit_pose(s * world + rank), r_intr, H, W, dev) for s in range(total)]
         do_gather = world > 1 and gather and not one_frame
 
+        # The path's only collective -- final pixels -- is POSTED after a frame's render and waited for after the NEXT frame's kernels have been
+        # queued (round 6: the renderer returns without a host sync), so frame i's all-gather and assembly run beside frame i + 1's kernels.
+        pending = [None]
+
+        def drain():
+            if pending[0] is not None:
+                pending[0]()
+                pending[0] = None
+
         def step(i):
             if one_frame:
-                return render_frame_sharded(render, poses[i], r_intr, H, W, dev)
+                nxt = render_frame_sharded_async(render, poses[i], r_intr, H, W, dev)
+                prev, pending[0] = pending[0], nxt
+                return prev() if prev is not None else None
             ret = render(rays[i][0], rays[i][1])
             if do_gather:
                 packed, _ = pack_outputs(ret)
-                _all_gather_rows(packed, world)   # the path's only collective: final pixels ([world * H * W, 5 or 8] on every rank)
+                nxt = all_gather_rows_async(packed, world).result   # ([world * H * W, 5 or 8] on every rank)
+                prev, pending[0] = pending[0], nxt
+                if prev is not None:
+                    prev()
             return ret
 
         rgb0 = None
@@ -659,12 +673,16 @@ def main():
         rgb0_dev = None
         if total > 0 and not one_frame and rays:
             step(0)              # set-up, not a warm-up step of the contract: the first frame of a process takes the workspace from the driver
+            drain()
             fence()              # (and whatever else is first-use); the W warm-up steps and the K timed steps follow
         for i in range(warmup):
             ret = step(i)
-            if i == 0 and keep_frame0 and rank == 0:
+            if i == 0 and keep_frame0 and one_frame:   # (pipelined form: frame 0 would come back one step later)
+                ret, pending[0] = pending[0](), None
+            if i == 0 and keep_frame0 and rank == 0 and ret is not None:
                 rgb0_dev = ret["rgb"].clone()   # (brought to the host AFTER the timed region: on a cold box a device-to-host copy here was followed by
                                                 #  a 1-2 s stall inside the next frame -- tools/stall_diag.py, round 5 -- which is no part of a frame)
+        drain()
         fence()
         lib.nm_profile_enable(1)
         stamps = []
@@ -672,6 +690,7 @@ def main():
         for i in range(warmup, total):
             step(i)
             stamps.append(time.perf_counter() - t0)   # (host time at which step i's call returned: no synchronisation added)
+        drain()                            # the last frame's collective + assembly belong to the timed region
         torch.cuda.synchronize()
         own = time.perf_counter() - t0     # this rank's own work (+ the collectives it took part in), before the closing barrier
         run.last_step_returns_ms = [round(x * 1e3, 1) for x in stamps]
@@ -876,7 +895,7 @@ def main():
                   chunk=(n_rays + 1) // 2, keep_frame0=True)
             from neumesh_amd import renderer as _rmod
             r = short(f"library_default_chunks (the caller passes render.py's rayschunk = 4096, the library cuts the call into equal chunks of at most {_rmod.DEFAULT_RAYSCHUNK} rays "
-                      f"-- ~10 GB of workspace per lane instead of 40 --, alternating between {_rmod.DEFAULT_LANES} streams; identical pixels)", library_policy=True, keep_frame0=True)
+                      f"-- 20.6 GB of workspace per lane, the same 41 GB in all as the one-call frame --, alternating between {_rmod.DEFAULT_LANES} streams; identical pixels)", library_policy=True, keep_frame0=True)
             r65 = short("chunks_of_65536_rays (the round-4 library default; identical pixels)", chunk=65536)
             cfgd["rayschunk_65536_ms_per_frame"] = r65.get("ms_per_frame")
             cfgd["default_rayschunk_ms_per_frame"] = r.get("ms_per_frame")

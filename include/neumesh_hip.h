@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define NM_ABI_VERSION 10
+#define NM_ABI_VERSION 11
 #define NM_MAX_K 32
 
 typedef struct nm_grid_s* nm_grid_t;    /* spatial index over the mesh vertices */
@@ -145,6 +145,11 @@ int nm_field_destroy(nm_field_t f);
  * outside the fp16 range (|v| >= 65504: the outputs of those launches are unusable, re-run with
  * mlp_precision 0), else 0.  Synchronises `stream`; resets the flag. */
 int nm_field_overflow(nm_field_t f, int* flag, nm_stream_t stream);
+/* ABI v11 -- the same flag with NO synchronisation ("no hidden sync", SURVEY 8b threading row; the reference's renderer returns
+ * unsynchronised tensors, models/renderer.py:353-368): queues a copy of the flag into *host_flag on `stream` and returns.  host_flag must be
+ * PINNED host memory that stays valid until the stream has passed this point; the caller reads it after an event of its own.  Nothing is
+ * reset: on reading 1 call nm_field_overflow (resets) and re-run with mlp_precision 0. */
+int nm_field_overflow_post(nm_field_t f, int* host_flag, nm_stream_t stream);
 
 /* Tables + scalars that change without re-packing (borrowed device pointers, [V,dim]). */
 typedef struct nm_field_tables {
@@ -212,17 +217,8 @@ typedef struct nm_render_cfg {
     const float* u_rand;         /* NULL: deterministic importance samples (sample_pdf(det=True), perturb=False).  Else device
                                     [N_upsample_iters][R][N_importance / N_upsample_iters] uniform numbers in [0,1): the stratum
                                     positions of sample_pdf(det=False) (rend_util.py:300-302), rows in the CALLER's ray order */
-    /* ABI v10: several ray chunks in flight on several streams (the caller's loop over renderer.py:353-363's chunks).  None of the
-       three changes a result bit. */
-    int32_t overlap;             /* 0 = every kernel is a plain grid launch (one chunk at a time: the right form).  1 = the call is one of
-                                    several chunks rendered concurrently on different streams: its K-NN kernels run in the pull form
-                                    (one-wave workgroups drawing packets from a counter) and make room for the MLP kernels of the OTHER
-                                    chunks whenever one is queued -- at most knn_keep K-NN waves stay on a SIMD then -- so that the
-                                    vector-issue-bound searches run under the matrix-pipe-bound MLPs instead of beside them */
-    int32_t knn_keep;            /* K-NN waves a SIMD keeps while an MLP launch wants room; 0 = default (1: what two MLP workgroups per CU
-                                    leave in registers and LDS) */
-    int32_t mlp_prio;            /* s_setprio level of the MLP kernels' waves (0..3; 0 = default): the pull waves live long and would otherwise
-                                    win the oldest-first issue arbitration against every MLP wave */
+    /* (ABI v11: the v10 fields overlap / knn_keep / mlp_prio -- K-NN kernels yielding to other chunks' MLP kernels -- are gone: the mode was
+       measured 5-15 % slower in every variant, profiles/r05_overlap_sweep.txt) */
 } nm_render_cfg;
 #define NM_MAX_EDIT 4
 
@@ -244,10 +240,6 @@ typedef struct nm_render_cfg {
  *                 dbg->d_all (required), dbg->near_far and dbg->sdf_all are written; rgb / depth / acc / normals may be NULL.
  *                 The training renderer places its samples with this call and queries the field with autograd afterwards. */
 #define NM_RENDER_SAMPLE_ONLY 32u
-/*   FORK_MID      (calc_normal) run the mid-points' K-NN launch beside the sample points' nabla launch on a side stream of the call (two
- *                 independent kernels, one bound by vector issue, one by the matrix pipe) instead of behind it.  Measured neutral for a
- *                 one-call frame and slower with several chunk lanes: an A/B switch, not a default */
-#define NM_RENDER_FORK_MID 64u
 
 int64_t nm_render_workspace_bytes(const nm_render_cfg* cfg, int64_t R);
 

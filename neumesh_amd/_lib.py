@@ -11,7 +11,7 @@ import os
 
 from . import build as _build
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_K = 32
 
 
@@ -46,13 +46,12 @@ class RenderCfg(C.Structure):
                 ("mid_group_rays", C.c_int32), ("weight_eps", C.c_float),
                 ("n_edit", C.c_int32), ("code_dims", C.c_int32), ("edit_field", C.c_void_p * 4),
                 ("edit_mask", C.c_void_p * 4), ("edit_color_features", C.c_void_p),
-                ("edit_use_rot", C.c_int32 * 4), ("edit_rot", (C.c_float * 9) * 4), ("u_rand", C.c_void_p),
-                ("overlap", C.c_int32), ("knn_keep", C.c_int32), ("mlp_prio", C.c_int32)]
+                ("edit_use_rot", C.c_int32 * 4), ("edit_rot", (C.c_float * 9) * 4), ("u_rand", C.c_void_p)]
 
 
 GRID_DEFER_BUDGET, GRID_TRIM = 1, 2   # nm_grid_set_option
 # nm_render_cfg.flags (include/neumesh_hip.h)
-RENDER_FULL_PROBES, RENDER_NO_ZERO_SKIP, RENDER_NO_RAY_SORT, RENDER_NO_MID_ORDER, RENDER_EAGER_NABLAS, RENDER_SAMPLE_ONLY, RENDER_FORK_MID = 1, 2, 4, 8, 16, 32, 64
+RENDER_FULL_PROBES, RENDER_NO_ZERO_SKIP, RENDER_NO_RAY_SORT, RENDER_NO_MID_ORDER, RENDER_EAGER_NABLAS, RENDER_SAMPLE_ONLY = 1, 2, 4, 8, 16, 32
 
 
 class Camera(C.Structure):
@@ -97,6 +96,7 @@ SIGNATURES = {
     "nm_field_update": (C.c_int, [_P, C.POINTER(FieldDesc), _P]),
     "nm_field_destroy": (C.c_int, [_P]),
     "nm_field_overflow": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
+    "nm_field_overflow_post": (C.c_int, [_P, _P, _P]),
     "nm_field_scratch_bytes": (C.c_int64, [C.c_int64]),
     "nm_field_density": (C.c_int, [_P, _P, C.POINTER(FieldTables), _P, C.c_int64, _P, _P, _P, _P]),
     "nm_field_forward": (C.c_int, [_P, _P, C.POINTER(FieldTables), _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -136,9 +136,6 @@ TESTING_SIGNATURES = {
     "nm_grid_debug_export": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64]),
     "nm_selfcheck_field": (C.c_int, [_P, _P, C.POINTER(FieldTables), _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "nm_debug_last_deferred": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
-    "nm_debug_simd_keys": (C.c_int, [_P, C.c_int, _P]),
-    "nm_debug_knn_pull": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
-    "nm_debug_yield_add": (C.c_int, [C.c_int]),
     "nm_debug_gemm": (C.c_int, [_P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int,
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P]),
 }

@@ -128,7 +128,7 @@ __device__ __forceinline__ bool nm_knn_search_packet(const NmGridView& g, float 
             // v_readlane broadcast 115.5; the leaf level keeps its optimum (~32 vertices per leaf: 101 vs 127-130 ms at ~120).
             __shared__ float4 nm_leaf_lds[BLK / 64][64];  // one stage per wave: every kernel that traverses is compiled
             float4* stage = nm_leaf_lds[threadIdx.x >> 6];
-            const nm_f32x2 qyz = {qy, qz};          // with __launch_bounds__(BLK) and launched with that block size (NM_KNN_BLOCK; 64 for the pull kernels)
+            const nm_f32x2 qyz = {qy, qz};          // with __launch_bounds__(BLK) and launched with that block size (NM_KNN_BLOCK)
             const uint32_t ln = threadIdx.x & 63u;
             if (BUDGET) work += single ? 8 * (int)((crec.end - crec.first + 63u) >> 6) : 7 * (int)(crec.end - crec.first);
             if (single) {
@@ -221,7 +221,7 @@ __device__ __forceinline__ bool nm_knn_wave(const NmGridView& g, float qx, float
 #endif
 #define NM_TILE_RAYS (64 / NM_TILE_SAMPLES)
 __host__ __device__ __forceinline__ int nm_chain_len(const NmPointSrc& s) { return (s.mode == 2 && !s.order && s.chain > 1) ? s.chain : 1; }
-// `wave`: index of the 64-query packet within the launch (nm_launch_wave(): the wave's position in the grid; the pull kernels draw it from a counter)
+// `wave`: index of the 64-query packet within the launch (nm_launch_wave(): the wave's position in the grid)
 __device__ __forceinline__ long long nm_launch_wave() { return ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; }
 __device__ __forceinline__ bool nm_lane_query(const NmPointSrc& s, long long Q, long long& q, long long& r, int& p, int it, long long wave) {
     const int lane = threadIdx.x & 63;
@@ -517,7 +517,6 @@ __global__ __launch_bounds__(BLK, CHAIN ? NM_KNN_WAVES_CHAIN : NM_KNN_WAVES) voi
                                                   geo_table, gdim, fg_out, col_table, cdim, ft_out);
 }
 
-#include "nm_knn_pull.h"   // pull form of the distance kernels + the device-wide yield state
 
 // ------------------------------------------------------------------------ the deferred queries of a small launch
 // A small launch (a training batch: 10^4 ... 10^5 points) lives as long as its slowest wave, and the slowest waves hold queries near the
@@ -829,14 +828,4 @@ __global__ __launch_bounds__(BLK, NM_KNN_WAVES_PROBE) void nm_probe_bounds_kerne
                                                                  float* __restrict__ nearfar,
                                                                  unsigned long long* __restrict__ searched) {
     nm_probe_bounds_body<S, BLK>(g, nm_launch_wave(), rays_o, dirn, nearfar0, R, P, thresh, verts, indicator, w1, nearfar, searched);
-}
-// pull form (see nm_distance_pull_kernel)
-template <int S>
-__global__ __launch_bounds__(64, NM_KNN_WAVES_PROBE) void nm_probe_bounds_pull_kernel(NmGridView g, NmPull pl, const float* __restrict__ rays_o,
-                                                                 const float* __restrict__ dirn, const float* __restrict__ nearfar0,
-                                                                 long long R, int P, float thresh, const float* __restrict__ verts,
-                                                                 const float* __restrict__ indicator, float w1,
-                                                                 float* __restrict__ nearfar,
-                                                                 unsigned long long* __restrict__ searched) {
-    NM_PULL_LOOP((nm_probe_bounds_body<S, 64>(g, wave, rays_o, dirn, nearfar0, R, P, thresh, verts, indicator, w1, nearfar, searched)))
 }

@@ -576,28 +576,19 @@ __device__ __forceinline__ void nm_h2_raise(int* overflow, float mx) {
     if (overflow && !(mx < NM_H2_FP16_MAX)) *overflow = 1;  // (benign race: every writer stores 1)
 }
 
-// Issue priority of the workgroup's waves (nm_render_cfg.mlp_prio).  The arbitration between the waves of a SIMD is priority first, then AGE: when
-// the long-lived pull waves of the K-NN kernels share the SIMDs (nm_kernels.h), every MLP wave is the younger one and would get the leftover slots.
-__device__ __forceinline__ void nm_h2_setprio(int prio) {
-    if (prio == 1) __builtin_amdgcn_s_setprio(1);
-    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
-    else if (prio >= 3) __builtin_amdgcn_s_setprio(3);
-}
-
 // ------------------------------------------------------------------ geometry MLP (split-half, v2)
 // Same contract as nm_geo_mlp_h_kernel.  FIXED: gdim = 32, multires_fg = 2, multires_d = 8 (Kpad0 = 192).
 template <bool NABLA, bool FIXED, int NP>
 __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_h2_kernel(
     NmGeoParamsH2 prm, const float* __restrict__ fg_rec, const float* __restrict__ ds, const float* __restrict__ grad, NmRecMap rmap,
     long long npts, float* __restrict__ sdf_out, int P, int stride, int off, float* __restrict__ nabla_out, int nabla_slotted,
-    NmSlotMap smap, int* __restrict__ overflow, int prio) {
+    NmSlotMap smap, int* __restrict__ overflow) {
     __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE];
     __shared__ __attribute__((aligned(16))) float cst[(NM_H2_BIAS_LAYERS + 1) * NM_W];  // biases of layers 0..3 | density weights
     __shared__ float red[4 * NM_ROWS];
     constexpr int PTS = NABLA ? 32 : 64;
     const long long base = (long long)blockIdx.x * PTS;
     if (smap.order && smap.order[base] == 0xffffu) return;  // no point in this tile (valid entries lead each group)
-    nm_h2_setprio(prio);
     const NmDivBase rdiv = nm_div_base(base, rmap.stride ? rmap.P : 1), odiv = nm_div_base(base, P);
     // by_list: records and outputs addressed by the (ray, sample) the list entry names (the nablas of the sample points
     // whose visibility weight is not zero, evaluated after the sampling passes from their slot records)
@@ -747,13 +738,12 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
 template <bool FIXED, int NP>
 __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_col_mlp_h2_kernel(
     NmColParamsH2 prm, const float* __restrict__ ft_rec, const float* __restrict__ ds, const float* __restrict__ nabla,
-    const float* __restrict__ dirs, int dir_div, long long npts, float* __restrict__ rgb_out, NmSlotMap smap, int* __restrict__ overflow, int prio) {
+    const float* __restrict__ dirs, int dir_div, long long npts, float* __restrict__ rgb_out, NmSlotMap smap, int* __restrict__ overflow) {
     __shared__ __attribute__((aligned(16))) _Float16 tile[2 * NM_H_PLANE];
     __shared__ __attribute__((aligned(16))) float cst[(NM_H2_BIAS_LAYERS + 3) * NM_W];  // biases of layers 0..3 | rgb weights [3][256]
     __shared__ float red[4 * NM_ROWS * 3];
     const long long base = (long long)blockIdx.x * NM_ROWS;
     if (smap.order && smap.order[base] == 0xffffu) return;  // no point in this tile
-    nm_h2_setprio(prio);
     const NmDivBase ddiv = nm_div_base(base, dir_div);
     const long long ray0 = smap.order ? (base / smap.E) * smap.G : 0;  // uniform: one division per workgroup
     nm_phase_stamp(0);

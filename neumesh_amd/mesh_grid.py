@@ -15,6 +15,8 @@ torch ops on the device so gradients w.r.t. xyz / indicator vectors flow as in t
 from __future__ import annotations
 
 import ctypes as C
+import os
+import threading
 
 import numpy as np
 import torch
@@ -46,14 +48,20 @@ class GridHandle:
         self.device = v.device
         self.num_vertices = int(v.shape[0])
         self._budget = None   # NEUMESH_KNN_BUDGET as last handed to the library (the library itself reads no environment)
+        self._budget_lock = threading.Lock()
 
     @property
     def handle(self):
-        import os
         b = os.environ.get("NEUMESH_KNN_BUDGET")   # tuning / test knob of the small-launch hand-over (nm_grid_set_option)
-        if b != self._budget:
-            _lib.check(_lib.load().nm_grid_set_option(self._h, _lib.GRID_DEFER_BUDGET, int(b) if b not in (None, "") else -1), "nm_grid_set_option")
-            self._budget = b
+        if b != self._budget:                       # (changed since it was last handed over: rare; one string compare per access otherwise)
+            with self._budget_lock:                 # nn.DataParallel threads may share a handle
+                if b != self._budget:
+                    try:
+                        value = int(b) if b not in (None, "") else -1
+                    except ValueError:              # a malformed value is "not set", as for every other NEUMESH_* knob
+                        value = -1
+                    _lib.check(_lib.load().nm_grid_set_option(self._h, _lib.GRID_DEFER_BUDGET, value), "nm_grid_set_option")
+                    self._budget = b
         return self._h
 
     def trim(self):

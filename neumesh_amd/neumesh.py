@@ -294,6 +294,7 @@ class NeuMesh(nn.Module):
         self._field_dev = None
         self._field_epoch = 0     # bumped by invalidate_field()
         self._range_checked = False
+        self._range_pending = []  # deferred fp16-range reads: (event, pinned host word) per fused call that returned without a sync
         # With autograd enabled (training): "hip" = forward AND backward on the HIP library (_HipField: nm_train_forward /
         # nm_train_backward, closed-form reverse pass); "recompute" = fused HIP forward + a backward that re-evaluates the
         # torch-op restatement (_FusedField); "torch" = the torch-op restatement end to end.  Same gradients.
@@ -385,6 +386,7 @@ class NeuMesh(nn.Module):
         replica = super()._replicate_for_data_parallel()
         replica._field, replica._field_key, replica._field_dev = None, None, None
         replica._scalars_key, replica._keep, replica._range_checked = None, None, False
+        replica._range_pending = []
         replica._is_replica = True
         return replica
 
@@ -393,7 +395,7 @@ class NeuMesh(nn.Module):
         g = self.mesh_grid
         return g if g.device == device else g.on_device(device)
 
-    def check_fp16_range(self, force: bool = False, every: int = 1) -> bool:
+    def check_fp16_range(self, force: bool = False, every: int = 1, deferred_calls: int = 0) -> bool:
         """Split-half modes only: ask the library whether any launch since the last check saw a value
         outside the fp16 range (nm_field_overflow; synchronises the stream).  Called once after the
         first fused call on a new weight set; returns True if the results of those launches are valid.
@@ -419,11 +421,59 @@ class NeuMesh(nn.Module):
         import warnings
         late = self._range_calls - getattr(self, "_range_last_read", 0)
         warnings.warn("NeuMesh: an MLP activation or input left the fp16 range (|v| >= 65504) in the split-half f16 mode; "
-                      "switching this model to mlp_precision='fp32' and re-running this call"
+                      + ("switching this model to mlp_precision='fp32' and re-running this call" if not deferred_calls else
+                         f"found by the deferred (sync-free) check: the outputs of up to {deferred_calls} EARLIER render call(s) on this model may hold "
+                         "Inf / NaN-affected values -- render them again; this model now runs mlp_precision='fp32' (NEUMESH_EAGER_RANGE_CHECK=1 checks "
+                         "every call before it returns)")
                       + (f" -- the flag is polled every {every} point-wise calls, so up to {late - 1} EARLIER calls since the last poll may hold "
                          "Inf / NaN-affected values: repeat the enclosing render / ray-casting call" if late > 1 else ""), RuntimeWarning)
         self.mlp_precision = "fp32"
         return False
+
+    def post_fp16_range_check(self) -> None:
+        """The sync-free form of check_fp16_range (nm_field_overflow_post, ABI v11): queue a copy of the device flag into a pinned host word
+        on the current stream, record an event behind it and return.  poll_fp16_range() reads the words whose events have completed -- the
+        renderer does so at its next entry, `synchronize_fp16_range()` on demand."""
+        if self.mlp_precision == "fp32" or self._field is None:
+            return
+        lib = _lib.load()
+        if getattr(self, "_range_words", None) is None:
+            self._range_words, self._range_slot = torch.zeros(64, dtype=torch.int32).pin_memory(), 0   # one pinned allocation per model, 64 words in rotation
+        if len(self._range_pending) >= 48:    # a caller that never comes back to poll: read what is ready, wait for the oldest if none is
+            self.poll_fp16_range(wait_oldest=len(self._range_pending) >= 63)
+        word = self._range_words[self._range_slot:self._range_slot + 1]
+        self._range_slot = (self._range_slot + 1) % 64
+        word.zero_()
+        with torch.cuda.device(self._field_dev):
+            _lib.check(lib.nm_field_overflow_post(self._field.h, C.c_void_p(word.data_ptr()), _lib.current_stream(self._field_dev)), "nm_field_overflow_post")
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self._field_dev))
+        self._range_pending.append((ev, word))
+
+    def poll_fp16_range(self, wait: bool = False, wait_oldest: bool = False) -> bool:
+        """Read the deferred fp16-range words that are ready (all of them with wait=True: blocks until the calls that posted them are done).
+        Returns False -- after a warning, with the model switched to mlp_precision='fp32' -- if one of those EARLIER calls saw a value outside
+        the fp16 range: its outputs may hold Inf / NaN-affected values and must be rendered again."""
+        bad, keep = False, []
+        for i, (ev, word) in enumerate(self._range_pending):
+            if wait or (wait_oldest and i == 0):
+                ev.synchronize()
+            if ev.query():
+                bad = bad or bool(int(word[0]))
+            else:
+                keep.append((ev, word))
+        n_read = len(self._range_pending) - len(keep)
+        self._range_pending = keep
+        if not bad:
+            return True
+        self._range_pending = []
+        if self.mlp_precision != "fp32":
+            self.check_fp16_range(force=True, deferred_calls=n_read)      # (synchronises, resets the device flag, warns, switches to fp32)
+        return False
+
+    def synchronize_fp16_range(self) -> bool:
+        """Wait for every fused call issued so far on this model and report whether all of them stayed inside the fp16 range."""
+        return self.poll_fp16_range(wait=True)
 
     def invalidate_field(self):
         """Force a re-pack of the MLP weights at the next use.  Needed only after edits that bypass

@@ -45,7 +45,7 @@ def alpha_to_w(alpha):
 # measurement script can flip them without touching the caller (none of them changes a result bit).
 _ENV_FLAGS = (("NEUMESH_FULL_PROBES", _lib.RENDER_FULL_PROBES), ("NEUMESH_NO_ZERO_SKIP", _lib.RENDER_NO_ZERO_SKIP),
               ("NEUMESH_NO_RAY_SORT", _lib.RENDER_NO_RAY_SORT), ("NEUMESH_NO_MID_ORDER", _lib.RENDER_NO_MID_ORDER),
-              ("NEUMESH_EAGER_NABLAS", _lib.RENDER_EAGER_NABLAS), ("NEUMESH_FORK_MID", _lib.RENDER_FORK_MID))
+              ("NEUMESH_EAGER_NABLAS", _lib.RENDER_EAGER_NABLAS))
 _ENV_TUNING = (("NEUMESH_CHAIN_TILES", "chain_tiles"), ("NEUMESH_FINE_GROUP", "fine_group_rays"), ("NEUMESH_MID_GROUP", "mid_group_rays"))
 
 
@@ -166,19 +166,6 @@ def _n_lanes() -> int:
     return max(1, min(MAX_LANES, _env_int("NEUMESH_RENDER_STREAMS", DEFAULT_LANES)))
 
 
-def _overlap_settings(n_lanes: int):
-    """(overlap, knn_keep, mlp_prio) of nm_render_cfg for a call cut into chunks on n_lanes streams.  With more than one chunk in flight the
-    K-NN kernels of a chunk take the pull form and make room for the other chunks' MLP kernels (NEUMESH_OVERLAP=0 keeps the plain launches)."""
-    mode = _env_int("NEUMESH_OVERLAP", DEFAULT_OVERLAP)   # 2: the pull form also for a call on one lane (A/B of the kernel form itself)
-    if not mode or (n_lanes < 2 and mode != 2):
-        return 0, 0, 0
-    return 1, max(0, min(8, _env_int("NEUMESH_KNN_KEEP", 0))), max(0, min(3, _env_int("NEUMESH_MLP_PRIO", DEFAULT_MLP_PRIO)))
-
-
-DEFAULT_OVERLAP = 0
-DEFAULT_MLP_PRIO = 0
-
-
 def fusable_edit_model(model) -> bool:
     """A TextureEditableNeuMesh whose texture blend nm_render_rays can do itself (nm_render_cfg.n_edit): plain NeuMesh main and
     reference models with the main model's colour configuration, at most 4 references (their rotations, if any, go along)."""
@@ -224,16 +211,31 @@ def render_rays_fused(model, rays_o, rays_d, cfg: _lib.RenderCfg, rayschunk: int
     models = [main] + (keep[2] if keep else [])
     u_blocks = {} if (perturb and cfg.N_importance > 0) else None   # (chunk start -> its numbers: drawn once, so that the fp32 re-run
                                                                      #  below, should it happen, places the same samples)
-    out = _render_rays_fused(main, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress, u_blocks)
-    if not all([m.check_fp16_range() for m in models]):   # a value left the fp16 range during this call (sticky device flag): fp32 kernels, once more
+    plan = {}                                                        # (and the chunk size chosen once: u_blocks is shaped by it)
+    # fp16-range flag of the split-half kernels (sticky on the device; depends on weights AND inputs).  No hidden sync (the reference
+    # returns unsynchronised tensors, models/renderer.py:353-368): the flag is read WITH a stream sync -- and the call repeated by the fp32
+    # kernels before it returns -- only on the first fused call on a weight set, under detailed_output, or with NEUMESH_EAGER_RANGE_CHECK=1.
+    # Every other call posts an asynchronous read (nm_field_overflow_post) that the next entry below, or model.synchronize_fp16_range(),
+    # evaluates: an overflow then costs a warning naming the earlier call(s) as invalid, and the model runs fp32 from there on.
+    for m in models:
+        if m._range_pending and not m.poll_fp16_range():
+            for i, r in enumerate(keep[2] if keep else []):     # (now fp32: new handles)
+                cfg.edit_field[i] = getattr(r.field_handle(), "value", r.field_handle())
+    eager_env = os.environ.get("NEUMESH_EAGER_RANGE_CHECK", "")
+    eager = eager_env == "1" or (eager_env != "0" and (detailed or not all(m._range_checked for m in models)))
+    out = _render_rays_fused(main, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress, u_blocks, plan)
+    if not eager:
+        for m in models:
+            m.post_fp16_range_check()
+    elif not all([m.check_fp16_range() for m in models]):   # a value left the fp16 range during this call: fp32 kernels, once more
         for i, r in enumerate(keep[2] if keep else []):
             cfg.edit_field[i] = getattr(r.field_handle(), "value", r.field_handle())
-        out = _render_rays_fused(main, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress, u_blocks)
+        out = _render_rays_fused(main, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress, u_blocks, plan)
     del keep
     return out
 
 
-def _fused_chunk(lib, cfg, R: int, rayschunk: int, dev, extra_per_ray: int = 0) -> int:
+def _fused_chunk(lib, cfg, R: int, rayschunk: int, dev, extra_per_ray: int = 0, held_bytes: int = 0) -> int:
     """Rays per nm_render_rays call.  The reference's `rayschunk` (render.py passes 4096) bounds ITS memory; here every chunk is ~26 kernel
     launches whose cost is latency, not work, below ~10^5 rays (800x800 frame: 806 ms in chunks of 4096 rays, 362 ms at 65 536, 354 ms in
     one call) and the pixels do not depend on the chunking (bit-identical, tested), so the caller's value is only a LOWER bound: the call is
@@ -251,6 +253,7 @@ def _fused_chunk(lib, cfg, R: int, rayschunk: int, dev, extra_per_ray: int = 0) 
         free = torch.cuda.mem_get_info(dev)[0]
     except Exception:
         return want
+    free += int(held_bytes)                   # workspaces this caller's pool already holds serve the call: they are not somebody else's memory
     free -= int(extra_per_ray) * R            # tensors of the whole call (allocated before the first chunk runs)
     while chunk > want:
         need = int(lib.nm_render_workspace_bytes(C.byref(cfg), chunk)) * (1 if chunk >= R else min(_n_lanes(), -(-R // chunk)))
@@ -264,7 +267,7 @@ def _fused_chunk(lib, cfg, R: int, rayschunk: int, dev, extra_per_ray: int = 0) 
     return balanced if balanced >= want else chunk
 
 
-def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress, u_blocks=None):
+def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed, tables, progress, u_blocks=None, plan=None):
     lib = _lib.load()
     dev = rays_o.device
     if dev.type != "cuda":
@@ -285,7 +288,15 @@ def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed,
             dbg_t["nablas_all"] = torch.empty((R, N, 3), device=dev)
     cfg.code_dims = int(model._cfg["geometry_dim"]) | (int(model._cfg["color_dim"]) << 16)   # K-NN records of the workspace sized for this field
     # detailed output: ~12 more [R, N]-sized tensors are derived from the debug arrays after the last chunk
-    chunk = _fused_chunk(lib, cfg, R, rayschunk, dev, extra_per_ray=4 * N * 12 if detailed else 0)
+    with torch.cuda.device(dev):
+        pool = _lanes_for(dev, torch.cuda.current_stream(dev).cuda_stream)
+    if plan is not None and "chunk" in plan:     # the fp32 re-run of a call: the SAME chunks (u_blocks is keyed and shaped by them)
+        chunk = plan["chunk"]
+    else:
+        held = sum(int(lane.buf.numel()) for lane in pool if lane.buf is not None and lane.buf.device == dev)   # (this pool's own workspaces are
+        chunk = _fused_chunk(lib, cfg, R, rayschunk, dev, extra_per_ray=4 * N * 12 if detailed else 0, held_bytes=held)   #  not "used" memory: ADVICE r5)
+        if plan is not None:
+            plan["chunk"] = chunk
     ws_bytes = int(lib.nm_render_workspace_bytes(C.byref(cfg), chunk))
     if ws_bytes < 0:
         _lib.check(1, "nm_render_workspace_bytes")
@@ -299,9 +310,8 @@ def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed,
     t, keep = tables if tables is not None else model.field_tables()
     with torch.cuda.device(dev):
         main = torch.cuda.current_stream(dev)
-        lanes = _lanes_for(dev, main.cuda_stream)[:min(_n_lanes(), len(starts))]
+        lanes = pool[:min(_n_lanes(), len(starts))]
         wss = [lane.get(ws_bytes, dev) for lane in lanes]
-        cfg.overlap, cfg.knn_keep, cfg.mlp_prio = _overlap_settings(len(lanes))
         if len(lanes) > 1:  # fork: the side streams start after everything already queued on the caller's stream
             side = [lane.side_stream(dev) for lane in lanes]
             for st in side:
@@ -332,6 +342,8 @@ def _render_rays_fused(model: NeuMesh, rays_o, rays_d, cfg, rayschunk, detailed,
         wss = ws = None   # (drop this call's references before the pools decide what to keep)
         for lane in lanes:   # (after the join: the block is handed back in the caller's stream order)
             lane.trim(WS_KEEP_BYTES)
+        for lane in pool[len(lanes):]:   # lanes this chunking did not use keep nothing pinned
+            lane.trim(0)
     del keep
     if detailed:
         s = model.forward_s().detach()

@@ -63,6 +63,35 @@ def _all_gather_rows(buf: torch.Tensor, world: int, group=None) -> torch.Tensor:
     return full
 
 
+class PendingGather:
+    """An all-gather of pixel rows that has been POSTED but not waited for (round 6: frame i's collective runs on the back end's own
+    stream while frame i + 1 renders -- the renderer no longer synchronises, renderer.py).  result() makes the CURRENT stream wait for the
+    collective (no host synchronisation under RCCL) and returns the gathered [world * per, C] rows."""
+
+    def __init__(self, work, full, host=None, keep=None):
+        self._work, self._full, self._host, self._keep = work, full, host, keep
+
+    def result(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+            if self._host is not None:      # host back end: the rows were gathered in host memory
+                self._full.copy_(self._host)
+                self._host = None
+            self._keep = None
+        return self._full
+
+
+def all_gather_rows_async(buf: torch.Tensor, world: int, group=None) -> PendingGather:
+    """_all_gather_rows with async_op=True: the collective is queued behind everything already on the current stream and the call returns;
+    kernels queued on the current stream AFTERWARDS (the next frame) do not wait for it."""
+    full = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype, device=buf.device)
+    if buf.is_cuda and dist.get_backend(group) != "nccl":
+        host, src = torch.empty(full.shape, dtype=buf.dtype), buf.cpu()
+        return PendingGather(dist.all_gather_into_tensor(host, src, group=group, async_op=True), full, host, src)
+    return PendingGather(dist.all_gather_into_tensor(full, buf, group=group, async_op=True), full, None, buf)
+
+
 def render_sharded(render_fn: Callable[[torch.Tensor, torch.Tensor], Dict[str, torch.Tensor]], rays_o: torch.Tensor,
                    rays_d: torch.Tensor, group=None) -> Dict[str, torch.Tensor]:
     """Every rank passes the SAME full [N,3] rays (or its rank could build them on device, rays
@@ -157,11 +186,46 @@ def render_frame_sharded(render_fn, c2w, intrinsics, H: int, W: int, device, gro
     return gather_tiles(ret, per, src, world, group)
 
 
+def render_frame_sharded_async(render_fn, c2w, intrinsics, H: int, W: int, device, group=None, tile: int = None):
+    """render_frame_sharded with the frame's all-gather only POSTED: returns a function that waits for the collective and assembles the
+    frame.  Call it after the NEXT frame's render has been queued and the two overlap (render_frames_sharded does exactly that)."""
+    from .rays import make_rays, make_rays_indexed
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world == 1:
+        ro, rd = make_rays(c2w, intrinsics, H, W, device)
+        ret = render_fn(ro, rd)
+        return lambda: ret
+    lists, per, src = _frame_tables(H, W, world, tile or pick_tile(H, W, world), torch.device(device))
+    ro, rd = make_rays_indexed(c2w, intrinsics, H, W, lists[rank])
+    return gather_tiles_async(render_fn(ro, rd), per, src, world, group)
+
+
 def gather_tiles(ret: Dict[str, torch.Tensor], per: int, src: torch.Tensor, world: int, group=None) -> Dict[str, torch.Tensor]:
     """This rank's per-ray outputs (in the order of its tile_shard_pixels list) -> the full frame in pixel order on
     every rank: rows padded to `per`, ONE all-gather, one index_select with the `src` table of _frame_tables."""
+    return gather_tiles_async(ret, per, src, world, group)()
+
+
+def gather_tiles_async(ret: Dict[str, torch.Tensor], per: int, src: torch.Tensor, world: int, group=None):
+    """gather_tiles with the collective only POSTED: returns a function that waits for it and assembles the frame."""
     packed, keys = pack_outputs(ret)
     buf = torch.zeros((per, packed.shape[1]), dtype=torch.float32, device=packed.device)
     buf[: packed.shape[0]] = packed
-    full = _all_gather_rows(buf, world, group)
-    return unpack_outputs(full[src], keys)
+    pending = all_gather_rows_async(buf, world, group)
+    return lambda: unpack_outputs(pending.result()[src], keys)
+
+
+def render_frames_sharded(render_fn, cameras, H: int, W: int, device, group=None, tile: int = None):
+    """A SEQUENCE of frames (render.py:294's 90-view spiral) over the ranks of `group`, pipelined: yields the full frame of camera i
+    (pixel order, on every rank) after camera i + 1's render has been queued, so frame i's all-gather -- on the back end's stream -- and its
+    assembly overlap the next frame's kernels instead of standing between two frames.  cameras: iterable of (c2w, intrinsics).
+    Same pixels as render_frame_sharded frame by frame."""
+    waiting = None
+    for c2w, intrinsics in cameras:
+        nxt = render_frame_sharded_async(render_fn, c2w, intrinsics, H, W, device, group, tile)
+        if waiting is not None:
+            yield waiting()
+        waiting = nxt
+    if waiting is not None:
+        yield waiting()

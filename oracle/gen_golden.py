@@ -279,7 +279,7 @@ def gen_grad_fixture(tag, render_tag, V, mlp_state):
 
 
 def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=800, mlp_state=None, s_value=200.0,
-                      n_samples=64, n_importance=64, white_bkgd=False):
+                      n_samples=64, n_importance=64, white_bkgd=False, ckpt=None):
     """Headline-scale pin (BASELINE configs[1] shape, SURVEY 8d scene S-DTU): `n_rays` strided rays of
     frame 0 of the 800x800 orbit rendered by the IMPORTED REFERENCE at V = 140 000, with the stages a
     diverging ray can be traced through (near/far, coarse SDF, sorted depths after every up-sampling
@@ -294,7 +294,9 @@ def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=8
     from oracle import knn as oknn
     print(f"[{tag}] V={V} rays={n_rays} of {H}x{W}")
     mesh = synthetic.fibonacci_blob(V)
-    model, kw, renderer, _ = harness.build_reference(mesh, seed=0, mlp_state=mlp_state, s_value=s_value)
+    model, kw, renderer, _ = harness.build_reference(mesh, seed=0, mlp_state=mlp_state, s_value=s_value, ckpt=ckpt)
+    if ckpt is not None:                     # (the digest the test checks its own copy of the checkpoint against)
+        mlp_state = ckpt_mlp_state(ckpt)
     import frnn as frnn_stub                 # oracle/refimport/stubs/frnn.py
     import models.renderer as ref_renderer   # reference
     tree = cKDTree(mesh.vertices.astype(np.float64))
@@ -410,7 +412,18 @@ def gen_scale_fixture(tag="render_v140k_dtu", V=140_000, n_rays=1536, H=800, W=8
     )
 
 
-def gen_surf_sensitivity(tag="render_v140k_surf", mlp_state=None, s_value=400.0, n_seeds=8, n_time=3, timing=True):
+def ckpt_mlp_state(path):
+    """EVERY tensor of a utils/checkpoints.py file's "model" entry (MLPs, code tables, indicator vectors, ln_s) as numpy: what state_digest
+    hashes for a checkpoint-backed fixture (the test loads its own copy of the file and must arrive at the same digest)."""
+    import torch
+    sd = torch.load(path, map_location="cpu")["model"]
+    return {k: v.numpy() for k, v in sd.items()}
+
+
+TRAINED_CKPT = os.path.join(GOLDEN, "trained_v140k.pt")
+
+
+def gen_surf_sensitivity(tag="render_v140k_surf", mlp_state=None, s_value=400.0, n_seeds=8, n_time=3, timing=True, ckpt=None):
     """The reference's OWN spread on the headline fixture, and its own speed.
 
     (a) `n_seeds` independent last-bit perturbations of the fixture's ray directions -- seed 0: every component one ulp up (the run
@@ -432,7 +445,9 @@ def gen_surf_sensitivity(tag="render_v140k_surf", mlp_state=None, s_value=400.0,
     V, n_rays = int(f["V"]), f["rays_o"].shape[0]
     print(f"[{tag}_sens] V={V} rays={n_rays}, {n_seeds} perturbation seeds")
     mesh = synthetic.fibonacci_blob(V)
-    model, kw, renderer, _ = harness.build_reference(mesh, seed=0, mlp_state=mlp_state, s_value=s_value)
+    model, kw, renderer, _ = harness.build_reference(mesh, seed=0, mlp_state=mlp_state, s_value=s_value, ckpt=ckpt)
+    if ckpt is not None:
+        mlp_state = ckpt_mlp_state(ckpt)
     import frnn as frnn_stub
     tree = cKDTree(mesh.vertices.astype(np.float64))
     old_knn = frnn_stub.KNN_FN[0]
@@ -1128,7 +1143,10 @@ def gen_rays_fixture():
                         rays_o=ro[0].numpy(), rays_d=rd[0].numpy())
 
 
-KNOWN = ("scale", "train", "surface", "surf", "surfsens", "reftime", "surf3", "trace", "paint", "edit", "deform", "surface140k", "train140k", "perturb", "edit140k", "trainloop")
+# perturbation seeds of the *_sens fixtures.  Round 6: 32 (was 8) -- a ray the reference moves by > 1e-4 under a fraction p of the seeds is in the
+# union of S seeds with probability 1 - (1 - p)^S; the paired gate (product-bad rays must be reference-unstable rays) needs that union close to complete.
+N_SENS_SEEDS = int(os.environ.get("NM_SENS_SEEDS", "32"))
+KNOWN = ("scale", "train", "surface", "surf", "surfsens", "surf3sens", "scalesens", "trained", "reftime", "surf3", "trace", "paint", "edit", "deform", "surface140k", "train140k", "perturb", "edit140k", "trainloop")
 
 
 def main():
@@ -1142,7 +1160,14 @@ def main():
         elif sys.argv[1] == "surf":   # the scene with a surface (neumesh_amd.synthetic.surface_mlp_state), s = 400
             gen_scale_fixture("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0)
         elif sys.argv[1] == "surfsens":   # the reference's own spread over 8 last-bit perturbations of the surf fixture's rays + its speed (reads render_v140k_surf.npz)
-            gen_surf_sensitivity("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0)
+            gen_surf_sensitivity("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0, n_seeds=N_SENS_SEEDS, timing=False)
+        elif sys.argv[1] == "trained":    # round 6: a TRAINED field (tools/train_field.py on the GPU box -> tests/golden/trained_v140k.pt), loaded as render.py:287-288 does
+            gen_scale_fixture("render_v140k_trained", ckpt=TRAINED_CKPT)
+            gen_surf_sensitivity("render_v140k_trained", n_seeds=N_SENS_SEEDS, timing=False, ckpt=TRAINED_CKPT)
+        elif sys.argv[1] == "surf3sens":  # the same spread for the configs[3]-shape fixture and for the noise-field fixture (round 6: every end-to-end gate is paired)
+            gen_surf_sensitivity("render_v140k_surf_c3", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0, n_seeds=N_SENS_SEEDS, timing=False)
+        elif sys.argv[1] == "scalesens":
+            gen_surf_sensitivity("render_v140k_dtu", mlp_state=sd, s_value=200.0, n_seeds=N_SENS_SEEDS, timing=False)
         elif sys.argv[1] == "reftime":    # only the timing record of surfsens (REPORT.json "reference_timing"); run it on an otherwise idle machine
             gen_surf_sensitivity("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0, n_seeds=0)
         elif sys.argv[1] == "surf3":  # BASELINE configs[3] shape (32 + 32 samples, white background) on the same scene, at headline scale

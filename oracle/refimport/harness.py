@@ -30,7 +30,7 @@ def _activate():
 
 
 def build_reference(mesh, seed: int = 0, s_value: float = 200.0, geometry_seed: int = 1,
-                    color_seed: int = 2, indicator_seed: int = 3, overrides=None, mlp_state=None):
+                    color_seed: int = 2, indicator_seed: int = 3, overrides=None, mlp_state=None, ckpt=None):
     """Returns (model, render_kwargs_test, renderer, args) built by the reference's own factory.
 
     mesh: neumesh_amd.synthetic.SyntheticMesh.  Weights: torch default init under
@@ -70,5 +70,10 @@ def build_reference(mesh, seed: int = 0, s_value: float = 200.0, geometry_seed: 
         model.color_features.copy_(torch.from_numpy(synthetic.random_codes(V, model.color_features.shape[1], color_seed)))
         model.indicator_vector.copy_(torch.from_numpy(synthetic.noisy_indicator(mesh.vertex_normals, indicator_seed)))
         model.ln_s.fill_(float(np.log(s_value) / model.speed_factor))
+    if ckpt is not None:
+        # a TRAINED weight set, loaded the way the reference's renderer does (render.py:287-288): the whole state dict -- MLPs,
+        # both code tables, indicator vectors, ln_s -- strictly, from the "model" entry of a utils/checkpoints.py file
+        state_dict = torch.load(ckpt, map_location="cpu")
+        model.load_state_dict(state_dict["model"])
     model.eval()
     return model, kw_test, renderer, args

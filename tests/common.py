@@ -119,3 +119,86 @@ def edit_model(mesh, state, n_ref: int, rotated: bool, device):
     T = None if T_list is None else [torch.from_numpy(t).to(device) for t in T_list]
     wrap = TextureEditableNeuMesh(main, refs, torch.from_numpy(masks).to(device), torch.from_numpy(feats).to(device), T)
     return wrap.eval(), main
+
+
+def trained_state(name: str = "trained_v140k") -> dict:
+    """Every tensor of the TRAINED checkpoint tests/golden/<name>.pt (tools/train_field.py; utils/checkpoints.py layout, read the way
+    render.py:287-288 does: the "model" entry) as numpy."""
+    import torch
+    sd = torch.load(os.path.join(GOLDEN, name + ".pt"), map_location="cpu")["model"]
+    return {k: v.numpy() for k, v in sd.items()}
+
+
+def field_margins(model, rays_o, rays_d, depths, max_points: int = 1 << 17) -> dict:
+    """What the split-half f16 kernels' operands look like on THIS weight set (VERDICT r5 item 1 iv), evaluated with torch ops in fp32 on the
+    sample points rays_o + normalize(rays_d) * depths (neighbours / weights from the product's compute_distance):
+      * value rows: the largest |operand| any k-loop reads -- embedded inputs, activations in the kernels' log2 units (S y, S = 100 / ln 2),
+        packed weights (layer 0 x S) -- against the fp16 range 65504;
+      * tangent rows (one-accumulator mode): the largest |2^-8 S d y_l / d ds| and 2^-8 x the embedding derivatives, against 65504 above and
+        the residual halves' absolute resolution 2^-25 below (NM_H2_TANGENT_SCALE_1ACC in nm_mlp_h2.h was chosen on untrained weights);
+      * the share of 4-dim code chunks whose sin / cos arguments leave the fast polynomial range (NM_SINCOS_FAST_MAX = 1e5, nm_mlp.h);
+      * s = exp(ln_s x speed_factor)."""
+    import torch
+    import torch.nn.functional as F
+    S, TS = 144.26950408889634, 2.0 ** -8
+    with torch.no_grad():
+        dn = F.normalize(rays_d, dim=-1)
+        xyz = (rays_o[:, None, :] + dn[:, None, :] * depths[..., None]).reshape(-1, 3)
+        if xyz.shape[0] > max_points:
+            xyz = xyz[:: -(-xyz.shape[0] // max_points)]
+        ds, idx, w = model.compute_distance(xyz)
+        fg = (model.geometry_features[idx] * w.unsqueeze(-1)).sum(-2)
+        ft = (model.color_features[idx] * w.unsqueeze(-1)).sum(-2)
+
+        def folded(m):   # weight_norm, dim 0
+            v, g = m.weight_v, m.weight_g
+            return g * v / v.norm(dim=1, keepdim=True)
+        d_emb, fg_emb = model.embed_fn_d(ds), model.embed_fn_fg(fg)
+        L = model.embed_fn_d.n_freqs
+        # d(embedding of ds) / d ds: [1, f cos(f ds), -f sin(f ds), ...]
+        t_parts = [torch.ones_like(ds)]
+        for j in range(L):
+            f = float(2 ** j)
+            t_parts += [f * torch.cos(ds * f), -f * torch.sin(ds * f)]
+        x = torch.cat([d_emb, fg_emb], -1)
+        t = torch.cat(t_parts + [torch.zeros_like(fg_emb)], -1)
+        out = {"s": float(model.forward_s()), "points": int(xyz.shape[0]),
+               "max_abs_code_interpolated": float(torch.maximum(fg.abs().max(), ft.abs().max())),
+               "max_abs_code_table": float(torch.maximum(model.geometry_features.abs().max(), model.color_features.abs().max()))}
+        op_v, op_t, t_min_scale = float(x.abs().max()), float((TS * t).abs().max()), []
+        layers = model._geo_layers()
+        for li, m in enumerate(layers):
+            W = folded(m)
+            op_v = max(op_v, float(W.abs().max()) * (S if li == 0 else 1.0))
+            z, tz = x @ W.t() + m.bias, t @ W.t()
+            y, g = F.softplus(z, beta=100), torch.sigmoid(100.0 * z)
+            ty = g * tz
+            out[f"geo_layer{li}_max_abs_activation_log2_units"] = float(S * y.abs().max())
+            out[f"geo_layer{li}_max_abs_tangent_operand"] = float(TS * S * ty.abs().max())
+            out[f"geo_layer{li}_weight_g_max"] = float(m.weight_g.abs().max())
+            if li + 1 < len(layers):                      # (the last hidden layer's activations feed the fp32 head, not a k-loop)
+                op_v = max(op_v, float(S * y.abs().max()))
+                op_t = max(op_t, float(TS * S * ty.abs().max()))
+                t_min_scale.append(float(TS * S * ty.abs().median()))
+            x, t = y, ty
+        Wd = folded(model.density_linear)
+        sdf = x @ Wd.t() + model.density_linear.bias
+        dsdf = t @ Wd.t()
+        out["max_abs_sdf"], out["max_abs_dsdf_dds"] = float(sdf.abs().max()), float(dsdf.abs().max())
+        out["median_tangent_operand_hidden"] = min(t_min_scale) if t_min_scale else 0.0
+        # colour network: nabla (|d sdf/d ds| bounds |nabla| up to the unit-ish gradient of ds), view embedding (<= 1), code embedding, relu activations
+        view = F.normalize(torch.randn(xyz.shape[0], 3, device=xyz.device, generator=torch.Generator(device=xyz.device).manual_seed(0)), dim=-1)
+        parts = ([dsdf.expand(-1, 3)] if model.enable_nablas_input else []) + [d_emb, model.embed_fn_view(view), model.embed_fn_ft(ft)]
+        xc = torch.cat(parts, -1)
+        op_c = float(xc.abs().max())
+        for li, m in enumerate(model._col_layers()):
+            op_c = max(op_c, float(m.weight.abs().max()))
+            xc = F.relu(xc @ m.weight.t() + m.bias)
+            out[f"col_layer{li}_max_abs_activation"] = float(xc.abs().max())
+            op_c = max(op_c, float(xc.abs().max()))
+        out["max_abs_operand_value_rows"] = max(op_v, op_c)
+        out["max_abs_operand_tangent_rows"] = op_t
+        chunks = torch.cat([fg.reshape(-1, 4), ft.reshape(-1, 4)], 0).abs().max(-1).values     # the kernels test one chunk of 4 dims at a time;
+        out["sincos_fast_range_exceeded_share"] = float((chunks > 1.0e5).float().mean())        # bands = 2: the largest directly evaluated frequency is 1
+        out["max_sincos_argument"] = float(chunks.max())
+    return out

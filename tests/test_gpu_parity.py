@@ -641,6 +641,125 @@ def surf_scale(cuda_device):
     return mesh, state, common.make_model(mesh, state, cuda_device)
 
 
+def _paired_tail_gate(err, sens, label, max_outside=2):
+    """The end-to-end tail against the reference's OWN spread, ray by ray.  sens["self_err"] [S, n]: the imported reference
+    against itself under S independent last-bit perturbations of the ray directions (oracle/gen_golden.py *sens).  own[r] = the largest
+    move of ray r over the seeds; `unstable` = rays the reference itself moves by more than 1e-4 under SOME seed.
+      (a) product rays beyond 1e-4 must be reference-unstable rays -- at most `max_outside` exceptions;
+      (b) per ray: error <= max(4 x own[r], 1e-3) -- a ray the reference holds still may not move by more than 1e-3 here, an unstable ray
+          by no more than four times what the reference itself does to it;
+      (c) no more rays beyond 1e-4 than the reference's worst seed.
+    Returns (unstable, stable_under_all_seeds)."""
+    own = sens["self_err"].max(0)
+    unstable = own > 1e-4
+    bad = err > 1e-4
+    outside = np.nonzero(bad & ~unstable)[0]
+    lim = np.maximum(4.0 * own, 1e-3)
+    over = np.nonzero(err > lim)[0]
+    counts = (sens["self_err"] > 1e-4).sum(1)
+    print(f"  [{label}] paired tail gate over {sens['self_err'].shape[0]} reference seeds: reference-unstable rays {int(unstable.sum())} (per seed {int(counts.min())}..{int(counts.max())}); "
+          f"product rays beyond 1e-4: {int(bad.sum())}, of them outside the unstable set: {len(outside)} {[(int(r), float(f'{err[r]:.1e}'), float(f'{own[r]:.1e}')) for r in outside[:8]]}; "
+          f"rays over their own limit max(4 x own, 1e-3): {len(over)} {[(int(r), float(f'{err[r]:.1e}'), float(f'{own[r]:.1e}')) for r in over[:8]]}; max {err.max():.2e}")
+    if os.environ.get("NEUMESH_PARITY_DUMP"):
+        os.makedirs(os.environ["NEUMESH_PARITY_DUMP"], exist_ok=True)
+        np.save(os.path.join(os.environ["NEUMESH_PARITY_DUMP"], f"parity_tail_{label}.npy"), err)
+    assert len(outside) <= max_outside, (label, [(int(r), float(err[r]), float(own[r])) for r in outside])
+    assert len(over) == 0, (label, [(int(r), float(err[r]), float(own[r])) for r in over])
+    assert int(bad.sum()) <= int(counts.max()), (label, int(bad.sum()), int(counts.max()))
+    return unstable, own <= 1e-6
+
+
+def _scene_against_reference_fixture(model, digest, fixture, precision, cuda_device, torch, classes=True):
+    """The gates of the headline-scale end-to-end tests (see test_render_surface_scene_matches_reference_fixture); `digest`: sha256 of the
+    weights the caller built `model` from -- it must be the one the fixture was rendered with."""
+    from neumesh_amd.renderer import make_render_cfg, render_at_depths, volume_render
+    f = common.golden(fixture)
+    sens = common.golden(fixture + "_sens")
+    ns, ni, white = (int(f["N_samples"]), int(f["N_importance"]), bool(f["white_bkgd"])) if "N_samples" in f.files else (64, 64, False)
+    assert str(f["state_sha256"]) == digest and str(sens["state_sha256"]) == digest
+    assert abs(float(model.forward_s()) - float(f["s"])) <= 1e-3 * max(1.0, float(f["s"]) / 400.0)
+    label = f"{fixture}.{precision}"
+    ro, rd = _t(f["rays_o"], cuda_device), _t(f["rays_d"], cuda_device)
+    n = len(f["rgb"])
+    old_precision = model.mlp_precision
+    model.mlp_precision = precision
+    try:
+        # (1) behind the sampler
+        with torch.no_grad():
+            tail = render_at_depths(model, ro, rd, _t(f["d_all"], cuda_device),
+                                    make_render_cfg(calc_normal=True, N_samples=ns, N_importance=ni, white_bkgd=white), detailed=True)
+        t = {k: v.cpu().numpy() for k, v in tail.items()}
+        worst = {}
+        for key, tol in (("rgb", 1e-4), ("mask_volume", 1e-4), ("normals_volume", 1e-4), ("depth_volume", 2e-4)):
+            e = np.abs(t[key] - f[key]).reshape(n, -1).max(-1)
+            worst[key] = float(e.max())
+            assert e.max() <= tol, (key, float(e.max()), int(e.argmax()))
+        sdf_err = float(np.abs(t["implicit_surface"] - f["sdf_all"]).max())
+        print(f"{label}, on the reference's own depths ({n} rays): max errors {worst}, |sdf| {sdf_err:.2e}")
+        assert sdf_err <= 3e-6
+        # (2), (3) end to end
+        kw = dict(calc_normal=True, N_samples=ns, N_importance=ni, white_bkgd=white, perturb=False, rayschunk=65536)
+        with torch.no_grad():
+            rgb, depth, ex = volume_render(ro, rd, model, detailed_output=True, **kw)
+            rgb_p, depth_p, ex_p = volume_render(ro, rd, model, detailed_output=False, **kw)
+        assert model.mlp_precision == precision, "the call left the fp16 range and fell back to the fp32 kernels"
+        assert torch.equal(rgb, rgb_p) and torch.equal(depth, depth_p) and torch.equal(ex["mask_volume"], ex_p["mask_volume"])
+        assert torch.equal(ex["normals_volume"], ex_p["normals_volume"])
+        g = {k: v.cpu().numpy() for k, v in ex.items()}
+        err = np.abs(g["rgb"] - f["rgb"]).max(-1)
+        self_err = f["self_err_1ulp"]
+        assert np.array_equal(sens["self_err"][0], self_err)
+        acc_r, acc_g = f["mask_volume"], g["mask_volume"]
+        print(f"{label} end to end: median {np.median(err):.1e}, max {err.max():.2e}, PSNR {compare.psnr(g['rgb'], f['rgb']):.1f} dB, "
+              f"rays > 1e-4: {int((err > 1e-4).sum())}; acc == 0: {int((acc_g == 0).sum())}, partial: {int(((acc_g >= 1e-3) & (acc_g <= 0.999)).sum())}, "
+              f"opaque: {int((acc_g > 0.999).sum())}")
+        bad = np.nonzero(err > 1e-4)[0]
+        if len(bad) and "d_iter1" in f.files:   # attribution (VERDICT r3 weak #1): the first stage at which a diverging ray leaves the reference's last bit
+            from neumesh_amd.renderer import render_rays_staged
+            tr = {}
+            with torch.no_grad():
+                render_rays_staged(model, ro[bad], rd[bad], make_render_cfg(calc_normal=True, N_samples=ns, N_importance=ni, white_bkgd=white), 65536, 1 << 20, trace=tr)
+            got = {"near_far": tr["near_far"][0].cpu().numpy(), "sdf_coarse": tr["sdf_coarse"][0].cpu().numpy()}
+            for i, dd in enumerate(tr["d_iter"][0]):
+                got[f"d_iter{i + 1}"] = dd.cpu().numpy()
+            want = {"near_far": f["near_far"][bad], "sdf_coarse": f["sdf_coarse"][bad], "d_iter1": f["d_iter1"][bad],
+                    "d_iter2": f["d_iter2"][bad], "d_iter3": f["d_iter3"][bad], "d_iter4": f["d_all"][bad]}
+            stages = {}
+            for j, r in enumerate(bad):
+                name, ulps, cnt = compare.first_divergent_stage(got, want, j)
+                stages[name] = stages.get(name, 0) + 1
+            print(f"  first divergent stage of the {len(bad)} rays beyond 1e-4: {stages}")
+            # (a ray listed under None has every sampling stage within the last bit / the field's 3e-6 of the reference's: its error is the
+            #  field tolerance times s at a crossing, bounded by gate (1) above; it must stay the exception)
+            assert stages.get(None, 0) <= max(2, len(bad) // 4), stages
+        if classes:
+            assert int((acc_r == 0).sum()) >= 0.2 * n and int(((acc_r >= 1e-3) & (acc_r <= 0.999)).sum()) >= 0.08 * n and int((acc_r > 0.999).sum()) >= 0.5 * n
+        assert float(f["rgb"].std()) > 0.1
+        assert np.array_equal(acc_g == 0, acc_r == 0)
+        assert np.abs(g["near_far"] - f["near_far"]).max() <= 2e-6
+        assert np.median(err) <= 1e-6
+        unstable, still = _paired_tail_gate(err, sens, label)
+        for key, tol in (("depth_volume", 2e-4), ("mask_volume", 1e-4), ("normals_volume", 1e-4)):
+            e = np.abs(g[key] - f[key]).reshape(n, -1).max(-1)
+            assert np.median(e) <= 1e-6, key
+            assert int((e[~unstable] > tol).sum()) <= 2, (key, int((e[~unstable] > tol).sum()))       # (paired, like the colour)
+        # Rays the reference holds still under EVERY seed: with sample depths IDENTICAL to the reference's the bound is north_star's 1e-4 on
+        # every such ray.  Depths that differ in the last bits are not enough for that: the reference's field is discontinuous where a
+        # point's 8-neighbour set changes (its own secant roots sit on jumps of up to 1.5e-3, tests/golden/surface_v140k_surf.npz), so a sample
+        # next to such a boundary can change sides under a 1-ulp move and s turns the jump into a visible alpha change.
+        dd = np.abs(g["d_all"] - f["d_all"]).max(-1)
+        calm = still & (dd <= 2e-6)
+        same = still & (dd == 0)
+        print(f"  calm rays (still under all {sens['self_err'].shape[0]} seeds, depths within 2e-6): {int(calm.sum())} (bit-identical depths: {int(same.sum())}), max error among them "
+              f"{err[calm].max():.2e} / {err[same].max() if same.any() else 0.0:.2e}; calm rays beyond 1e-4: {int((err[calm] > 1e-4).sum())}")
+        assert same.sum() >= 20 and err[same].max() <= 1e-4, (int(same.sum()), float(err[same].max()) if same.any() else None)
+        assert calm.sum() >= 0.15 * n and (err[calm] > 1e-4).mean() <= 0.01, (int(calm.sum()), int((err[calm] > 1e-4).sum()))
+        assert err[calm].max() <= 1e-3, float(err[calm].max())    # (ADVICE r4: an absolute cap on the calm rays' outliers, in every arithmetic)
+        return {"err": err, "g": g, "f": f}
+    finally:
+        model.mlp_precision = old_precision          # (ADVICE r5: a failing gate must not leave the shared model in another arithmetic)
+
+
 @pytest.mark.parametrize("fixture,precision", [("render_v140k_surf", "f16x2s"), ("render_v140k_surf", "f16x2"), ("render_v140k_surf", "fp32"),
                                                ("render_v140k_surf_c3", "f16x2s")])
 def test_render_surface_scene_matches_reference_fixture(surf_scale, cuda_device, torch_mod, fixture, precision):
@@ -654,107 +773,44 @@ def test_render_surface_scene_matches_reference_fixture(surf_scale, cuda_device,
       (1) everything behind the sampler, on the REFERENCE'S OWN 128 depths per ray (render_at_depths): rgb / acc /
           normals <= 1e-4 and depth <= 2e-4 on EVERY ray;
       (2) end to end: median <= 1e-6, near/far <= 2e-6, coverage classes (acc == 0 / partial / opaque) of every ray equal to the
-          reference's, and the tail INSIDE THE REFERENCE'S OWN SPREAD: tests/golden/render_v140k_surf_sens.npz holds the
-          imported reference against itself under 8 independent last-bit perturbations of the ray directions (15 ... 26 of 1536 rays
-          beyond 1e-4, largest move 1.1e-3 ... 3.7e-2 per seed); every MLP arithmetic of the product (f16x2s, f16x2, fp32: one test each)
-          must have no more rays beyond 1e-4 than the worst seed and no ray further off than twice the worst seed's largest move
-          (the c3 fixture, which has one perturbation run only: that run's share + 1 %, and twice its largest move);
+          reference's, and the tail PAIRED with the reference's own spread (round 6): tests/golden/<fixture>_sens.npz
+          holds the imported reference against itself under 32 independent last-bit perturbations of the ray directions; every MLP
+          arithmetic of the product (f16x2s, f16x2, fp32: one test each) must keep its rays beyond 1e-4 INSIDE the set of rays the
+          reference itself moves (_paired_tail_gate: <= 2 exceptions, per-ray limit 4 x the ray's own movement or 1e-3, count <= worst seed);
       (3) production call (ray sort, first/last-hit probe walk, zero-weight skip) == detailed call, bit for bit;
       (4) the field on the reference's own sample points: |sdf| <= 3e-6."""
-    torch = torch_mod
-    from neumesh_amd.renderer import make_render_cfg, render_at_depths, volume_render
     mesh, state, model = surf_scale
-    model.mlp_precision = precision
-    f = common.golden(fixture)
-    ns, ni, white = (int(f["N_samples"]), int(f["N_importance"]), bool(f["white_bkgd"])) if "N_samples" in f.files else (64, 64, False)
-    assert int(f["V"]) == mesh.num_vertices and str(f["state_sha256"]) == common.state_digest(
-        {k: v for k, v in state.items() if k not in ("geometry_features", "color_features", "indicator_vector")})
-    assert abs(float(model.forward_s()) - float(f["s"])) <= 1e-3
-    ro, rd = _t(f["rays_o"], cuda_device), _t(f["rays_d"], cuda_device)
-    n = len(f["rgb"])
-    # (1) behind the sampler
-    with torch.no_grad():
-        tail = render_at_depths(model, ro, rd, _t(f["d_all"], cuda_device),
-                                make_render_cfg(calc_normal=True, N_samples=ns, N_importance=ni, white_bkgd=white), detailed=True)
-    t = {k: v.cpu().numpy() for k, v in tail.items()}
-    worst = {}
-    for key, tol in (("rgb", 1e-4), ("mask_volume", 1e-4), ("normals_volume", 1e-4), ("depth_volume", 2e-4)):
-        e = np.abs(t[key] - f[key]).reshape(n, -1).max(-1)
-        worst[key] = float(e.max())
-        assert e.max() <= tol, (key, float(e.max()), int(e.argmax()))
-    sdf_err = float(np.abs(t["implicit_surface"] - f["sdf_all"]).max())
-    print(f"surface scene, on the reference's own depths ({n} rays): max errors {worst}, |sdf| {sdf_err:.2e}")
-    assert sdf_err <= 3e-6
-    # (2), (3) end to end
-    kw = dict(calc_normal=True, N_samples=ns, N_importance=ni, white_bkgd=white, perturb=False, rayschunk=65536)
-    with torch.no_grad():
-        rgb, depth, ex = volume_render(ro, rd, model, detailed_output=True, **kw)
-        rgb_p, depth_p, ex_p = volume_render(ro, rd, model, detailed_output=False, **kw)
-    assert torch.equal(rgb, rgb_p) and torch.equal(depth, depth_p) and torch.equal(ex["mask_volume"], ex_p["mask_volume"])
-    assert torch.equal(ex["normals_volume"], ex_p["normals_volume"])
-    g = {k: v.cpu().numpy() for k, v in ex.items()}
-    err = np.abs(g["rgb"] - f["rgb"]).max(-1)
-    self_err = f["self_err_1ulp"]
-    acc_r, acc_g = f["mask_volume"], g["mask_volume"]
-    print(f"surface scene end to end: median {np.median(err):.1e}, max {err.max():.2e}, PSNR {compare.psnr(g['rgb'], f['rgb']):.1f} dB, "
-          f"rays > 1e-4: {int((err > 1e-4).sum())} (reference vs itself + 1 ulp: {int((self_err > 1e-4).sum())}, max {self_err.max():.2e}); "
-          f"acc == 0: {int((acc_g == 0).sum())}, partial: {int(((acc_g >= 1e-3) & (acc_g <= 0.999)).sum())}, opaque: {int((acc_g > 0.999).sum())}")
-    bad = np.nonzero(err > 1e-4)[0]
-    if len(bad) and "d_iter1" in f.files:   # attribution (VERDICT r3 weak #1): the first stage at which a diverging ray leaves the reference's last bit
-        from neumesh_amd.renderer import render_rays_staged
-        tr = {}
-        with torch.no_grad():
-            render_rays_staged(model, ro[bad], rd[bad], make_render_cfg(calc_normal=True, N_samples=ns, N_importance=ni, white_bkgd=white), 65536, 1 << 20, trace=tr)
-        got = {"near_far": tr["near_far"][0].cpu().numpy(), "sdf_coarse": tr["sdf_coarse"][0].cpu().numpy()}
-        for i, dd in enumerate(tr["d_iter"][0]):
-            got[f"d_iter{i + 1}"] = dd.cpu().numpy()
-        want = {"near_far": f["near_far"][bad], "sdf_coarse": f["sdf_coarse"][bad], "d_iter1": f["d_iter1"][bad],
-                "d_iter2": f["d_iter2"][bad], "d_iter3": f["d_iter3"][bad], "d_iter4": f["d_all"][bad]}
-        stages = {}
-        for j, r in enumerate(bad):
-            name, ulps, cnt = compare.first_divergent_stage(got, want, j)
-            stages[name] = stages.get(name, 0) + 1
-            print(f"  ray {r}: |rgb| error {err[r]:.2e} (reference's own 1-ulp sensitivity {self_err[r]:.2e}); first divergent stage: "
-                  f"{name} ({cnt} entries, up to {ulps:.1f} last-place units)")
-        print(f"  first divergent stage of the {len(bad)} rays beyond 1e-4: {stages}")
-        # (a ray listed under None has every sampling stage within the last bit / the field's 3e-6 of the reference's: its error is the
-        #  field tolerance times s = 400 at a crossing, bounded by gate (1) above; it must stay the exception)
-        assert stages.get(None, 0) <= max(2, len(bad) // 4), stages
-    assert int((acc_r == 0).sum()) >= 0.2 * n and int(((acc_r >= 1e-3) & (acc_r <= 0.999)).sum()) >= 0.08 * n and int((acc_r > 0.999).sum()) >= 0.5 * n
-    assert float(f["rgb"].std()) > 0.1
-    assert np.array_equal(acc_g == 0, acc_r == 0)
-    assert np.abs(g["near_far"] - f["near_far"]).max() <= 2e-6
-    assert np.median(err) <= 1e-6
-    sens_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture + "_sens.npz")
-    if os.path.exists(sens_path):     # the reference's own spread over 8 perturbation seeds (oracle/gen_golden.py surfsens)
-        sens = np.load(sens_path)
-        assert str(sens["state_sha256"]) == str(f["state_sha256"]) and np.array_equal(sens["self_err"][0], self_err)
-        n_max, e_max = int(sens["rays_gt_1e_4"].max()), float(sens["max_err"].max())
-        print(f"  [{precision}] rays beyond 1e-4: {int((err > 1e-4).sum())} (reference's own seeds: {sens['rays_gt_1e_4'].tolist()}), "
-              f"max {err.max():.2e} (seeds: {[float(f'{x:.2e}') for x in sens['max_err']]})")
-        assert int((err > 1e-4).sum()) <= n_max, (precision, int((err > 1e-4).sum()), n_max)
-        assert float(err.max()) <= 2.0 * e_max, (precision, float(err.max()), e_max)
-    else:
-        assert (err > 1e-4).mean() <= (self_err > 1e-4).mean() + 0.01
-        assert float(err.max()) <= max(2.0 * float(self_err.max()), 2e-3), (float(err.max()), float(self_err.max()))
-    for key, tol in (("depth_volume", 2e-4), ("mask_volume", 1e-4), ("normals_volume", 1e-4)):
-        e = np.abs(g[key] - f[key]).reshape(n, -1).max(-1)
-        assert np.median(e) <= 1e-6, key
-        assert (e > tol).mean() <= (self_err > 1e-4).mean() + 0.01, key
-    # Rays the reference itself holds still under the 1-ulp nudge: with sample depths IDENTICAL to the reference's the bound is
-    # north_star's 1e-4 on every such ray.  Depths that differ in the last bits are not enough for that: the reference's field is
-    # discontinuous where a point's 8-neighbour set changes (its own secant roots sit on jumps of up to 1.5e-3,
-    # tests/golden/surface_v140k_surf.npz), so a sample next to such a boundary can change sides under a 1-ulp move and s = 400 turns
-    # the jump into a visible alpha change (seen: 3e-4 on one ray with all depths within 2e-6) -- those rays get the statistical gate.
-    dd = np.abs(g["d_all"] - f["d_all"]).max(-1)
-    calm = (self_err <= 1e-6) & (dd <= 2e-6)
-    same = (self_err <= 1e-6) & (dd == 0)
-    print(f"  calm rays: {int(calm.sum())} (bit-identical depths: {int(same.sum())}), max error among them {err[calm].max():.2e} / "
-          f"{err[same].max() if same.any() else 0.0:.2e}; calm rays beyond 1e-4: {int((err[calm] > 1e-4).sum())}")
-    assert same.sum() >= 20 and err[same].max() <= 1e-4, (int(same.sum()), float(err[same].max()) if same.any() else None)
-    assert calm.sum() >= 0.15 * n and (err[calm] > 1e-4).mean() <= 0.01, (int(calm.sum()), int((err[calm] > 1e-4).sum()))
-    assert err[calm].max() <= 1e-3, float(err[calm].max())    # (ADVICE r4: an absolute cap on the calm rays' outliers, in every arithmetic)
-    model.mlp_precision = "f16x2s"
+    assert int(common.golden(fixture)["V"]) == mesh.num_vertices
+    digest = common.state_digest({k: v for k, v in state.items() if k not in ("geometry_features", "color_features", "indicator_vector")})
+    _scene_against_reference_fixture(model, digest, fixture, precision, cuda_device, torch_mod)
+
+
+@pytest.fixture(scope="module")
+def trained_scale(cuda_device):
+    mesh = common.scene_mesh(140000)
+    state = common.trained_state()
+    return mesh, state, common.make_model(mesh, state, cuda_device)
+
+
+@pytest.mark.parametrize("precision", ["f16x2s", "f16x2", "fp32"])
+def test_render_trained_field_matches_reference_fixture(trained_scale, cuda_device, torch_mod, precision):
+    """A TRAINED field (VERDICT r5 missing #1 / item 1): tests/golden/trained_v140k.pt = 20 000 iterations of the reference's training
+    recipe on an analytic scene at V = 140 000 (tools/train_field.py: Adam 5e-4 warm-up + cosine, full loss set incl. distillation from the
+    analytic teacher, s = 1000 frozen as the teacher's; held-out PSNR 33 dB), in utils/checkpoints.py's layout.  The fixture
+    render_v140k_trained.npz is the IMPORTED REFERENCE on that file loaded as render.py:287-288 does (oracle/gen_golden.py `trained`), with
+    its 32-seed self-sensitivity.  Same gates as the hand-built surface scene, in all three precise arithmetics; in addition the call must
+    not trip the fp16-range flag (the split-half default would silently become the fp32 kernels), and the margins of the default
+    arithmetic on these weights are printed (largest activation per layer, tangent operands, sin/cos arguments)."""
+    torch = torch_mod
+    mesh, state, model = trained_scale
+    digest = common.state_digest(state)
+    out = _scene_against_reference_fixture(model, digest, "render_v140k_trained", precision, cuda_device, torch, classes=False)
+    assert abs(float(model.forward_s()) - 1000.0) <= 1.0
+    if precision == "f16x2s":
+        m = common.field_margins(model, _t(out["f"]["rays_o"], cuda_device), _t(out["f"]["rays_d"], cuda_device), _t(out["f"]["d_all"], cuda_device))
+        print("  margins of the split-half default on the trained field:", {k: (float(f"{v:.3g}") if isinstance(v, float) else v) for k, v in m.items()})
+        assert m["max_abs_operand_value_rows"] < 0.5 * 65504 and m["max_abs_operand_tangent_rows"] < 0.5 * 65504
+        assert m["sincos_fast_range_exceeded_share"] <= 0.01
 
 
 @pytest.mark.gpu
@@ -1366,12 +1422,10 @@ def test_texture_editing_inside_the_fused_renderer(small, cuda_device, torch_mod
         img_c, depth_c, _ = volume_render(ro, rd, wrap, rayschunk=17, **kw)
         st_out = render_rays_staged(wrap, ro, rd, make_render_cfg(calc_normal=True), 4096, 1 << 20)
         img0, depth0, _ = volume_render(ro, rd, model, rayschunk=4096, **kw)
-        # ... and with three chunks in flight, K-NN kernels in the pull form (the mid-point pass hands its neighbour lists to the blend)
+        # ... and with three chunks in flight
         monkeypatch.setenv("NEUMESH_RENDER_STREAMS", "3")
-        monkeypatch.setenv("NEUMESH_OVERLAP", "1")
         img_o, depth_o, _ = volume_render(ro, rd, wrap, rayschunk=17, **kw)
         monkeypatch.delenv("NEUMESH_RENDER_STREAMS")
-        monkeypatch.delenv("NEUMESH_OVERLAP")
     assert torch.equal(img, img_c) and torch.equal(depth, depth_c) and torch.equal(img, img_o) and torch.equal(depth, depth_o)
     assert torch.equal(depth, st_out["depth_volume"]) and torch.equal(ex["mask_volume"], st_out["mask_volume"]) and torch.equal(depth, depth0)
     assert torch.equal(ex["normals_volume"], st_out["normals_volume"])
@@ -1575,32 +1629,13 @@ def test_stochastic_sampler_matches_reference_fixture(small, cuda_device, torch_
     assert np.abs(f["d_all"] - rf["d_all"]).max() > 1e-3                           # ... which is not the deterministic one
 
 
-# --------------------------------------------------------------------- several chunks in flight (nm_render_cfg.overlap, ABI v10)
+# --------------------------------------------------------------------- several chunks in flight
 @pytest.mark.gpu
-def test_simd_keys_of_the_pull_kernels_cover_the_chip(cuda_device, torch_mod):
-    """The pull kernels count their resident waves per SIMD under a key built from HW_REG_HW_ID / HW_REG_XCC_ID (nm_simd_key): a launch
-    that fills the chip must show exactly 4 keys per CU, all inside the table (nm_kernels.h: NmYield.occ)."""
-    torch = torch_mod
-    from neumesh_amd import _lib
-    lib = _lib.load_testing()
-    n = 1 << 16
-    out = torch.full((n,), -1, dtype=torch.int32, device=cuda_device)
-    _lib.check(lib.nm_debug_simd_keys(_lib.ptr(out), n, _lib.current_stream(cuda_device)), "nm_debug_simd_keys", lib)
-    torch.cuda.synchronize()
-    keys = out.cpu().numpy()
-    assert keys.min() >= 0 and keys.max() < 8192
-    cus = torch.cuda.get_device_properties(cuda_device).multi_processor_count
-    uniq = np.unique(keys)
-    assert len(uniq) == 4 * cus, (len(uniq), cus)
-    assert len(np.unique(uniq >> 2)) == cus   # 4 SIMDs under every CU key
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("lanes,keep,prio", [(2, 0, 0), (3, 1, 2), (4, 2, 0)])
-def test_chunks_in_flight_with_pull_form_knn_render_identical_pixels(surf_scale, cuda_device, torch_mod, monkeypatch, lanes, keep, prio):
-    """A call cut into ray chunks on several streams with nm_render_cfg.overlap = 1 -- K-NN kernels in the pull form (one-wave workgroups
-    drawing packets from a counter, leaving their SIMD when an MLP launch of another chunk wants room) -- returns every output bit for
-    bit as the same call rendered in one piece with plain launches; also with a ragged last chunk, normals off and the lego shape."""
+@pytest.mark.parametrize("lanes", [2, 3, 4])
+def test_chunks_in_flight_render_identical_pixels(surf_scale, cuda_device, torch_mod, monkeypatch, lanes):
+    """A call cut into ray chunks on several streams (each lane with its own workspace) returns every output bit for bit as the same call
+    rendered in one piece; also with a ragged last chunk, normals off and the lego shape.  (Round 5's pull-form K-NN kernels that yielded
+    their SIMDs to the other chunks' MLP launches -- nm_render_cfg.overlap, ABI v10 -- were a measured loss and left the library in round 6.)"""
     torch = torch_mod
     from neumesh_amd import renderer as rmod
     from neumesh_amd import synthetic
@@ -1612,28 +1647,15 @@ def test_chunks_in_flight_with_pull_form_knn_render_identical_pixels(surf_scale,
         kw.update(perturb=False, detailed_output=False)
         monkeypatch.setenv("NEUMESH_RAYSCHUNK", "0")
         monkeypatch.setenv("NEUMESH_RENDER_STREAMS", "1")
-        monkeypatch.setenv("NEUMESH_OVERLAP", "0")
         with torch.no_grad():
             rgb_a, dep_a, ex_a = rmod.volume_render(o, d, model, rayschunk=H * W, **kw)
         monkeypatch.setenv("NEUMESH_RENDER_STREAMS", str(lanes))
-        monkeypatch.setenv("NEUMESH_OVERLAP", "1")
-        monkeypatch.setenv("NEUMESH_KNN_KEEP", str(keep))
-        monkeypatch.setenv("NEUMESH_MLP_PRIO", str(prio))
         with torch.no_grad():
             rgb_b, dep_b, ex_b = rmod.volume_render(o, d, model, rayschunk=5000, **kw)
         torch.cuda.synchronize()
         assert torch.equal(rgb_a, rgb_b) and torch.equal(dep_a, dep_b) and torch.equal(ex_a["mask_volume"], ex_b["mask_volume"])
         if kw["calc_normal"]:
             assert torch.equal(ex_a["normals_volume"], ex_b["normals_volume"])
-        if kw["calc_normal"] and lanes == 2:   # NM_RENDER_FORK_MID: the mid-point search on a side stream of the call, beside the sample points' nabla launch
-            monkeypatch.setenv("NEUMESH_RENDER_STREAMS", "1")
-            monkeypatch.setenv("NEUMESH_OVERLAP", "0")
-            monkeypatch.setenv("NEUMESH_FORK_MID", "1")
-            with torch.no_grad():
-                rgb_f, dep_f, ex_f = rmod.volume_render(o, d, model, rayschunk=H * W, **kw)
-            torch.cuda.synchronize()
-            monkeypatch.delenv("NEUMESH_FORK_MID")
-            assert torch.equal(rgb_a, rgb_f) and torch.equal(dep_a, dep_f) and torch.equal(ex_a["normals_volume"], ex_f["normals_volume"])
 
 
 @pytest.mark.gpu
@@ -1692,3 +1714,53 @@ def test_fp16_range_overflow_falls_back_to_fp32(small, cuda_device, torch_mod, p
             model.forward(xyz, dirs)
             model.check_fp16_range(force=True)
     assert model.mlp_precision == "fp32" and any("fp16 range" in str(w.message) for w in caught)
+
+
+@pytest.mark.gpu
+def test_render_call_returns_without_host_sync_and_reports_a_late_overflow(small, cuda_device, torch_mod, monkeypatch):
+    """SURVEY 8b "no hidden sync" (VERDICT r5 weak #6 / item 5).  The first fused call on a weight set reads the fp16-range flag with a stream
+    sync (and would re-render in fp32 before returning); every later call only POSTS an asynchronous read (nm_field_overflow_post) and returns
+    while its kernels are still running.  An overflow in such a call -- here caused by the INPUTS: a colour-code table scaled by 1e6, which does
+    not re-pack the weights -- is found at the next entry: a warning that names the earlier call as invalid, the model on the fp32 kernels from
+    there on, the new call's pixels equal to the fp32 render.  NEUMESH_EAGER_RANGE_CHECK=1 restores check-and-re-render inside every call."""
+    import warnings
+    torch = torch_mod
+    from neumesh_amd import renderer as rmod
+    from neumesh_amd import synthetic
+    mesh, state, _ = small
+    model = common.make_model(mesh, state, cuda_device)
+    H = W = 256
+    o, d = synthetic.camera_rays(synthetic.orbit_pose(5), synthetic.pinhole_intrinsics(H, W), H, W)
+    o, d = _t(o, cuda_device), _t(d, cuda_device)
+    kw = dict(calc_normal=True, perturb=False, detailed_output=False, rayschunk=H * W)
+    monkeypatch.delenv("NEUMESH_EAGER_RANGE_CHECK", raising=False)
+    with torch.no_grad():
+        rgb0, _, _ = rmod.volume_render(o, d, model, **kw)          # first call on this weight set: eager
+        assert model._range_checked and not model._range_pending
+        torch.cuda.synchronize()
+        rgb1, _, _ = rmod.volume_render(o, d, model, **kw)          # deferred
+        still_running = not torch.cuda.current_stream(cuda_device).query()
+        assert len(model._range_pending) == 1
+        assert model.synchronize_fp16_range() and not model._range_pending
+    assert still_running, "the deferred call returned only after its kernels had finished"
+    assert torch.equal(rgb0, rgb1) and model.mlp_precision == common.DEFAULT_PRECISION
+    with torch.no_grad():
+        model.color_features.data.mul_(1e6)                           # inputs outside the fp16 range; the packed weights are untouched
+        bad, _, _ = rmod.volume_render(o, d, model, **kw)           # deferred: returns whatever the f16 kernels made of it
+        assert model.mlp_precision == common.DEFAULT_PRECISION and len(model._range_pending) == 1
+        torch.cuda.synchronize()
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            rgb2, _, _ = rmod.volume_render(o, d, model, **kw)      # entry poll finds the flag of the EARLIER call
+        assert any("EARLIER render call" in str(w.message) for w in caught), [str(w.message)[:120] for w in caught]
+        assert model.mlp_precision == "fp32"
+        ref, _, _ = rmod.volume_render(o, d, model, **kw)
+        assert torch.equal(rgb2, ref) and bool(torch.isfinite(rgb2).all())
+        # eager on request: the overflowing call itself is repeated by the fp32 kernels
+        model.mlp_precision = common.DEFAULT_PRECISION
+        monkeypatch.setenv("NEUMESH_EAGER_RANGE_CHECK", "1")
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            rgb3, _, _ = rmod.volume_render(o, d, model, **kw)
+        assert any("re-running this call" in str(w.message) for w in caught) and model.mlp_precision == "fp32"
+        assert torch.equal(rgb3, ref)

@@ -26,7 +26,7 @@ import common
 from neumesh_amd import synthetic
 from neumesh_amd.renderer import volume_render
 from neumesh_amd.rays import make_rays
-from neumesh_amd.sharded import render_frame_sharded
+from neumesh_amd.sharded import render_frame_sharded, render_frames_sharded
 ndev = torch.cuda.device_count()
 dev = torch.device("cuda", rank % ndev)
 torch.cuda.set_device(dev)
@@ -48,6 +48,13 @@ o, d = make_rays(c2w, K, H, W, dev)      # the same device-side ray set-up the s
 want = render(o, d)
 ok = all(torch.equal(full[k], want[k]) for k in ("rgb", "depth_volume", "mask_volume", "normals_volume"))
 ok = ok and tuple(full["rgb"].shape) == (H * W, 3) and bool(torch.isfinite(full["rgb"]).all())
+# the pipelined sequence (frame i's all-gather waited for after frame i + 1's render has been queued) == frame by frame
+cams = [(synthetic.orbit_pose(11 + 3 * i), K) for i in range(3)]
+seq = list(render_frames_sharded(render, cams, H, W, dev))
+ok = ok and len(seq) == 3 and all(torch.equal(seq[0][k], full[k]) for k in ("rgb", "depth_volume", "mask_volume", "normals_volume"))
+for (c, _k), fr in zip(cams[1:], seq[1:]):
+    one = render_frame_sharded(render, c, K, H, W, dev)
+    ok = ok and all(torch.equal(fr[k], one[k]) for k in ("rgb", "depth_volume", "mask_volume", "normals_volume"))
 print("RANK", rank, "of", world, backend, "OK" if ok else "MISMATCH", flush=True)
 dist.barrier()
 dist.destroy_process_group()
@@ -84,8 +91,15 @@ def test_sharded_frame_world2_equals_unsharded(cuda_device, tmp_path):
     _run(tmp_path, 2, "nccl" if torch.cuda.device_count() >= 2 else "gloo")
 
 
+def test_sharded_frame_world8_equals_unsharded(cuda_device, tmp_path):
+    """The 8 ranks of the driver's scaling run, over RCCL where 8 devices are visible, else sharing cuda:0 under gloo."""
+    import torch
+    _run(tmp_path, 8, "nccl" if torch.cuda.device_count() >= 8 else "gloo")
+
+
+@pytest.mark.parametrize("n_ranks", [2, 8])
 @pytest.mark.parametrize("shard", ["frames", "frame"])
-def test_bench_two_ranks_both_partitions(cuda_device, shard):
+def test_bench_two_ranks_both_partitions(cuda_device, shard, n_ranks):
     """bench.py under torch.distributed.run with 2 ranks -- over RCCL on two devices, or (one GPU visible) with --backend gloo: the
     ranks share cuda:0 and the collectives are staged through the host; the partition, per-rank timing and JSON line are the same
     code either way.  --shard frames: one frame per rank and step (weak); --shard frame: one frame per step over both ranks (strong)."""
@@ -94,18 +108,18 @@ def test_bench_two_ranks_both_partitions(cuda_device, shard):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    backend = "nccl" if torch.cuda.device_count() >= n_ranks else "gloo"
     env = dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")},
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--H", "160", "--W", "160", "--V", "3000", "--cpu-rays", "0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(n_ranks), "--steps", "2", "--warmup", "1", "--H", "160", "--W", "160", "--V", "3000", "--cpu-rays", "0",
            "--no-extras", "--backend", backend, "--shard", shard]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["config"]["backend"] == backend
-    assert line["scaling"] == ("weak" if shard == "frames" else "strong") and len(line["per_rank_ms_per_step"]) == 2
-    rays_per_step = 160 * 160 * (2 if shard == "frames" else 1)
+    assert line["n_gpus"] == n_ranks and line["config"]["world_size"] == n_ranks and line["config"]["backend"] == backend
+    assert line["scaling"] == ("weak" if shard == "frames" else "strong") and len(line["per_rank_ms_per_step"]) == n_ranks
+    rays_per_step = 160 * 160 * (n_ranks if shard == "frames" else 1)
     assert abs(line["value"] - rays_per_step / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
 
 
