@@ -95,6 +95,13 @@ def build_scene(V, device, seed=0, s_value=None, scene="surf"):
     torch.manual_seed(seed)
     model = NeuMesh(MeshGrid(_Mesh(mesh), device), **MODEL_CFG)
     wpath = os.path.join(ROOT, "tests", "golden", "model_seed0.npz")
+    if scene == "trained":   # a TRAINED field (tools/train_field.py, 20 000 iterations of the reference's recipe on an analytic scene, s = 1000): the
+        # checkpoint in utils/checkpoints.py layout that tests/golden/render_v140k_trained.npz is the imported reference's render of
+        ck = os.path.join(ROOT, "tests", "golden", "trained_v140k.pt")
+        if V != 140_000 or not os.path.exists(ck):
+            raise SystemExit("scene 'trained' is tests/golden/trained_v140k.pt at V = 140000")
+        model.load_state_dict(torch.load(ck, map_location="cpu")["model"])     # render.py:287-288
+        return mesh, model.to(device).eval()
     if s_value is None:
         s_value = 400.0 if scene == "surf" else 200.0
     if os.path.exists(wpath):
@@ -286,7 +293,7 @@ def parity_blocks(gpu_rgb_frame0, H, W, V, oracle_rgb, sel, scene="surf", model=
     """(a) vs the committed REFERENCE output of the very same rays (fixture, 1536 rays of frame 0);
     (b) vs the oracle sample rendered for the CPU baseline."""
     out = {}
-    fname = "render_v140k_surf.npz" if scene == "surf" else "render_v140k_dtu.npz"
+    fname = {"surf": "render_v140k_surf.npz", "trained": "render_v140k_trained.npz"}.get(scene, "render_v140k_dtu.npz")
     fpath = os.path.join(ROOT, "tests", "golden", fname)
     if gpu_rgb_frame0 is not None and os.path.exists(fpath):
         f = np.load(fpath)
@@ -531,9 +538,10 @@ def main():
     ap.add_argument("--workload", choices=["frame", "stress5"], default="frame",
                     help="frame = BASELINE configs[1], the headline 800x800x128 render (default); stress5 = BASELINE configs[4], "
                          "the HBM-bound K-NN + 256-d gather stress (a second roofline, not the headline metric)")
-    ap.add_argument("--scene", choices=["surf", "noise"], default="surf",
+    ap.add_argument("--scene", choices=["surf", "noise", "trained"], default="surf",
                     help="surf = MLP weights with a surface (synthetic.surface_mlp_state: sdf = ds + code-driven bump, s = 400; rays miss / graze / "
-                         "hit); noise = the default-initialised weights of rounds 1-2 (every ray opaque, s = 200)")
+                         "hit); noise = the default-initialised weights of rounds 1-2 (every ray opaque, s = 200); trained = the checkpoint "
+                         "tests/golden/trained_v140k.pt (the reference's training recipe on an analytic scene, s = 1000)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -842,9 +850,13 @@ def main():
             if not (int(fixture["V"]) == args.V and int(fixture["H"]) == args.H and int(fixture["W"]) == args.W):
                 fixture = None
         if world == 1 and not args.no_extras and not args.data_independent and args.samples == 128 and not args.no_normals and not args.white_bkgd and args.mlp_precision == DEFAULT_PRECISION:
+            name_of_last_short = [None]
+
             def short(name, **kw):
+                name_of_last_short[0] = name
                 try:
                     e, pr, img, _, _ = run(2, 1, **kw)
+                    run.last_rgb0 = img
                     d, pp, a, pk, sp = mlp_summary(pr, kw.get("precision", args.mlp_precision))
                     nr = kw["hw"][0] * kw["hw"][1] if "hw" in kw else n_rays
                     extra[name] = {"value": nr * 2 / e, "unit": "rays/s", "ms_per_frame": e / 2 * 1e3, "steps": 2,
@@ -916,6 +928,25 @@ def main():
                 del model2
             except Exception as ex:
                 extra["other_scene"] = {"error": str(ex)}
+            try:   # the TRAINED field (round 6): same shape on tests/golden/trained_v140k.pt, with its parity against the imported reference's render
+                   # of these very rays and whether the call tripped the fp16-range flag (it would have fallen back to the fp32 kernels)
+                if args.V == 140_000 and args.scene != "trained":
+                    _, model3 = build_scene(args.V, dev, scene="trained")
+                    r = short("trained_scene (tests/golden/trained_v140k.pt: 20 000 iterations of the reference's training recipe on an analytic scene, s = 1000; "
+                              "loaded as render.py:287-288 does)", mdl=model3, keep_frame0=True)
+                    cfgd["trained_scene_rays_per_s"], cfgd["trained_scene_ms_per_frame"] = r.get("value"), r.get("ms_per_frame")
+                    cfgd["trained_scene_mlp_precision_after_render"] = model3.mlp_precision
+                    img3 = getattr(run, "last_rgb0", None)
+                    pb = parity_blocks(img3, args.H, args.W, args.V, None, None, "trained", model=model3).get("parity_vs_reference")
+                    if pb and name_of_last_short[0] in extra:
+                        extra[name_of_last_short[0]]["parity_vs_reference"] = pb
+                        cfgd["trained_scene_parity_max_abs_rgb_vs_reference"] = pb["max_abs_rgb"]
+                        cfgd["trained_scene_parity_frac_rays_within_1e-4"] = pb["frac_rays_within_1e-4"]
+                        cfgd["trained_scene_parity_on_reference_depths_max_abs_rgb"] = pb.get("on_reference_depths", {}).get("max_abs_rgb")
+                        cfgd["trained_scene_reference_self_1ulp_frac_rays_within_1e-4"] = pb["reference_self_sensitivity_1ulp"]["frac_rays_within_1e-4"]
+                    del model3
+            except Exception as ex:
+                extra["trained_scene"] = {"error": str(ex)[-300:]}
             model.mlp_precision = args.mlp_precision
             extra.update(consumer_rows(mesh, model, dev, args.H, args.W))
             for k_, v_ in extra.items():

@@ -46,7 +46,7 @@ class RenderCfg(C.Structure):
                 ("mid_group_rays", C.c_int32), ("weight_eps", C.c_float),
                 ("n_edit", C.c_int32), ("code_dims", C.c_int32), ("edit_field", C.c_void_p * 4),
                 ("edit_mask", C.c_void_p * 4), ("edit_color_features", C.c_void_p),
-                ("edit_use_rot", C.c_int32 * 4), ("edit_rot", (C.c_float * 9) * 4), ("u_rand", C.c_void_p)]
+                ("edit_use_rot", C.c_int32 * 4), ("edit_rot", (C.c_float * 9) * 4), ("u_rand", C.c_void_p), ("mid_passes", C.c_int32)]
 
 
 GRID_DEFER_BUDGET, GRID_TRIM = 1, 2   # nm_grid_set_option

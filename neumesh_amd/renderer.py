@@ -46,14 +46,15 @@ def alpha_to_w(alpha):
 _ENV_FLAGS = (("NEUMESH_FULL_PROBES", _lib.RENDER_FULL_PROBES), ("NEUMESH_NO_ZERO_SKIP", _lib.RENDER_NO_ZERO_SKIP),
               ("NEUMESH_NO_RAY_SORT", _lib.RENDER_NO_RAY_SORT), ("NEUMESH_NO_MID_ORDER", _lib.RENDER_NO_MID_ORDER),
               ("NEUMESH_EAGER_NABLAS", _lib.RENDER_EAGER_NABLAS))
-_ENV_TUNING = (("NEUMESH_CHAIN_TILES", "chain_tiles"), ("NEUMESH_FINE_GROUP", "fine_group_rays"), ("NEUMESH_MID_GROUP", "mid_group_rays"))
+_ENV_TUNING = (("NEUMESH_CHAIN_TILES", "chain_tiles"), ("NEUMESH_FINE_GROUP", "fine_group_rays"), ("NEUMESH_MID_GROUP", "mid_group_rays"),
+               ("NEUMESH_MID_PASSES", "mid_passes"))
 
 
 def make_render_cfg(obj_bounding_radius=1.0, N_samples=64, N_importance=64, N_upsample_iters=4, bounded_near_far=True,
                     calc_normal=False, white_bkgd=False, near_bypass=None, far_bypass=None, flags=None,
                     weight_eps=None, **tuning) -> _lib.RenderCfg:
     """nm_render_cfg for volume_render's arguments.  flags: NM_RENDER_* bits (None = take them from the
-    NEUMESH_* environment variables); tuning: chain_tiles / fine_group_rays / mid_group_rays (0 = default);
+    NEUMESH_* environment variables); tuning: chain_tiles / fine_group_rays / mid_group_rays / mid_passes (0 = default);
     weight_eps: visibility weights below it count as 0 (None = NEUMESH_WEIGHT_EPS, else 0 = exact; the only
     setting that changes pixels: by less than (N-1) * weight_eps)."""
     c = _lib.RenderCfg()

@@ -459,23 +459,33 @@ def gen_surf_sensitivity(tag="render_v140k_surf", mlp_state=None, s_value=400.0,
               white_bkgd=bool(f["white_bkgd"]) if "white_bkgd" in f.files else False)
     rays_o, rays_d = f["rays_o"], f["rays_d"]
 
-    def render(rd, n=None):
+    aux_keys = ("depth_volume", "mask_volume", "normals_volume")
+
+    def render(rd, n=None, aux=None):
         with torch.no_grad():
-            rgb, _, _ = renderer(torch.from_numpy(rays_o[:n])[None], torch.from_numpy(rd[:n])[None], detailed_output=False, **dict(kw, rayschunk=n or n_rays))
+            rgb, _, ex = renderer(torch.from_numpy(rays_o[:n])[None], torch.from_numpy(rd[:n])[None], detailed_output=False, **dict(kw, rayschunk=n or n_rays))
+        if aux is not None:
+            aux.update({k: ex[k][0].numpy() for k in aux_keys})
         return rgb[0].numpy()
 
     try:
-        base = render(rays_d)
+        base_aux = {}
+        base = render(rays_d, aux=base_aux)
         assert np.array_equal(base, f["rgb"]), "the unperturbed reference render does not reproduce the pinned fixture"
+        assert all(np.array_equal(base_aux[k], f[k]) for k in aux_keys)
         up, down = np.nextafter(rays_d, np.float32(10), dtype=np.float32), np.nextafter(rays_d, np.float32(-10), dtype=np.float32)
         errs, counts, maxes = [], [], []
+        aux_errs = {k: [] for k in aux_keys}     # the same for depth / acc / normals (round 6: their gates are paired too)
         for seed in range(n_seeds):
             if seed == 0:
                 rd = up
             else:
                 pick = np.random.default_rng(1000 + seed).integers(-1, 2, rays_d.shape)
                 rd = np.where(pick > 0, up, np.where(pick < 0, down, rays_d)).astype(np.float32)
-            e = np.abs(render(rd) - base).max(-1).astype(np.float32)
+            aux = {}
+            e = np.abs(render(rd, aux=aux) - base).max(-1).astype(np.float32)
+            for k in aux_keys:
+                aux_errs[k].append(np.abs(aux[k] - base_aux[k]).reshape(n_rays, -1).max(-1).astype(np.float32))
             errs.append(e)
             counts.append(int((e > 1e-4).sum()))
             maxes.append(float(e.max()))
@@ -511,6 +521,7 @@ def gen_surf_sensitivity(tag="render_v140k_surf", mlp_state=None, s_value=400.0,
         return
     REPORT[f"{tag}.reference_self_sensitivity_seeds"] = {"rays_gt_1e-4": counts, "max": maxes, "n_rays": n_rays}
     np.savez_compressed(os.path.join(GOLDEN, f"{tag}_sens.npz"), self_err=np.stack(errs), rays_gt_1e_4=np.asarray(counts, np.int64),
+                        **{"self_err_" + k: np.stack(v) for k, v in aux_errs.items()},
                         max_err=np.asarray(maxes, np.float32), state_sha256=np.array(state_digest(mlp_state) if mlp_state is not None else ""))
 
 
@@ -1146,7 +1157,7 @@ def gen_rays_fixture():
 # perturbation seeds of the *_sens fixtures.  Round 6: 32 (was 8) -- a ray the reference moves by > 1e-4 under a fraction p of the seeds is in the
 # union of S seeds with probability 1 - (1 - p)^S; the paired gate (product-bad rays must be reference-unstable rays) needs that union close to complete.
 N_SENS_SEEDS = int(os.environ.get("NM_SENS_SEEDS", "32"))
-KNOWN = ("scale", "train", "surface", "surf", "surfsens", "surf3sens", "scalesens", "trained", "reftime", "surf3", "trace", "paint", "edit", "deform", "surface140k", "train140k", "perturb", "edit140k", "trainloop")
+KNOWN = ("scale", "train", "surface", "surf", "surfsens", "surf3sens", "scalesens", "trained", "trainedsens", "reftime", "surf3", "trace", "paint", "edit", "deform", "surface140k", "train140k", "perturb", "edit140k", "trainloop")
 
 
 def main():
@@ -1163,6 +1174,8 @@ def main():
             gen_surf_sensitivity("render_v140k_surf", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0, n_seeds=N_SENS_SEEDS, timing=False)
         elif sys.argv[1] == "trained":    # round 6: a TRAINED field (tools/train_field.py on the GPU box -> tests/golden/trained_v140k.pt), loaded as render.py:287-288 does
             gen_scale_fixture("render_v140k_trained", ckpt=TRAINED_CKPT)
+            gen_surf_sensitivity("render_v140k_trained", n_seeds=N_SENS_SEEDS, timing=False, ckpt=TRAINED_CKPT)
+        elif sys.argv[1] == "trainedsens":
             gen_surf_sensitivity("render_v140k_trained", n_seeds=N_SENS_SEEDS, timing=False, ckpt=TRAINED_CKPT)
         elif sys.argv[1] == "surf3sens":  # the same spread for the configs[3]-shape fixture and for the noise-field fixture (round 6: every end-to-end gate is paired)
             gen_surf_sensitivity("render_v140k_surf_c3", mlp_state=synthetic.surface_mlp_state(sd), s_value=400.0, n_seeds=N_SENS_SEEDS, timing=False)

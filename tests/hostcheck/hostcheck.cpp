@@ -97,6 +97,7 @@ int hc_knn_stats(void* p, const float* q, int64_t Q, double* out) {
 int hc_knn_packet(void* p, const float* q, int64_t Q, int Wd, int64_t* idx, float* d2, double* out) {
     const NmGridView g = nm_host_view(((HostGridHandle*)p)->g);
     long long nodes_t = 0, verts_t = 0, packets = 0, insert_events = 0, deferred_rounds = 0, lane_inserts = 0, marked_sum = 0;
+    long long rejected_all = 0, scalar_sep = 0, scalar_box = 0;
     std::vector<unsigned long long> kk((size_t)Wd * 8);
     for (int64_t base = 0; base < Q; base += Wd) {
         const int n = (int)std::min<int64_t>(Wd, Q - base);
@@ -127,6 +128,25 @@ int hc_knn_packet(void* p, const float* q, int64_t Q, int Wd, int64_t* idx, floa
             const uint32_t mask = rec.info & 255u;
             const NmNode crec = g.nodes[rec.first + (uint32_t)nm_popc(mask & ((1u << c) - 1u))];
             ++nodes_t;
+            {   // out[6..8] (round 6 study): would a PACKET-level scalar pre-test have rejected this child without the 64-lane bound?
+                // axis-separating form (integer compares only -- gfx950 has no scalar float ALU): the child's box misses the packet's AABB grown by
+                // the largest K-th radius of the packet on some axis
+                float lo[3] = {NM_INF_F, NM_INF_F, NM_INF_F}, hi[3] = {-NM_INF_F, -NM_INF_F, -NM_INF_F}, r2 = 0.f;
+                for (int l = 0; l < n; ++l) {
+                    const float* ql = q + 3 * (base + l);
+                    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], ql[a]); hi[a] = std::max(hi[a], ql[a]); }
+                    r2 = std::max(r2, nm_key_d2(kk[(size_t)l * 8 + 7]));
+                }
+                const float rm = r2 < NM_INF_F ? std::sqrt(r2) * 1.00001f : NM_INF_F;
+                const bool sep = crec.lox > hi[0] + rm || crec.hix < lo[0] - rm || crec.loy > hi[1] + rm || crec.hiy < lo[1] - rm ||
+                                 crec.loz > hi[2] + rm || crec.hiz < lo[2] - rm;
+                // full box-to-box lower bound at packet level (what a scalar FLOAT unit could do)
+                const float ax = std::max(std::max(crec.lox - hi[0], lo[0] - crec.hix), 0.f), ay = std::max(std::max(crec.loy - hi[1], lo[1] - crec.hiy), 0.f),
+                            az = std::max(std::max(crec.loz - hi[2], lo[2] - crec.hiz), 0.f);
+                const bool boxbox = (ax * ax + ay * ay + az * az) * 0.99999f > r2;
+                scalar_sep += sep ? 1 : 0;
+                scalar_box += boxbox ? 1 : 0;
+            }
             bool any = false;
             std::vector<char> want((size_t)n);
             for (int l = 0; l < n; ++l) {
@@ -134,7 +154,7 @@ int hc_knn_packet(void* p, const float* q, int64_t Q, int Wd, int64_t* idx, floa
                 want[(size_t)l] = nm_box_lb2(crec, ql[0], ql[1], ql[2]) <= nm_key_d2(kk[(size_t)l * 8 + 7]);
                 any |= want[(size_t)l] != 0;
             }
-            if (!any) continue;
+            if (!any) { ++rejected_all; continue; }
             if ((crec.info & 255u) == 0u) {
                 verts_t += crec.end - crec.first;
                 // instruction-cost model of the leaf scan (out[2..4]): insert events of the one-vertex-at-a-time scan (a vertex costs the
@@ -190,6 +210,9 @@ int hc_knn_packet(void* p, const float* q, int64_t Q, int Wd, int64_t* idx, floa
     out[3] = (double)deferred_rounds / (double)(packets ? packets : 1);   // per packet: insertion rounds of the deferred (chunk-wise) scan
     out[4] = (double)lane_inserts / (double)(Q ? Q : 1);                  // per query: list insertions
     out[5] = (double)marked_sum / (double)(Q ? Q : 1);                    // per query: vertices below the chunk-entry threshold
+    out[6] = (double)rejected_all / (double)(packets ? packets : 1);      // per packet: node tests that NO lane passed
+    out[7] = (double)scalar_sep / (double)(packets ? packets : 1);        // ... of which an axis-separating packet pre-test would have caught
+    out[8] = (double)scalar_box / (double)(packets ? packets : 1);        // ... and a packet box-to-box lower bound
     return 0;
 }
 

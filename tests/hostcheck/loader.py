@@ -99,10 +99,11 @@ class HostGrid:
         q = np.ascontiguousarray(q, np.float32).reshape(-1, 3)
         idx = np.empty((len(q), 8), np.int64)
         d2 = np.empty((len(q), 8), np.float32)
-        out = (C.c_double * 6)()
+        out = (C.c_double * 9)()
         assert self.lib.hc_knn_packet(self.h, P(q), len(q), width, P(idx), P(d2), out) == 0
         self.last_packet_stats = {"insert_events_per_packet": out[2], "deferred_rounds_per_packet": out[3],
-                                  "inserts_per_query": out[4], "marked_per_query": out[5]}
+                                  "inserts_per_query": out[4], "marked_per_query": out[5], "node_tests_no_lane_passed_per_packet": out[6],
+                                  "caught_by_axis_separating_packet_test": out[7], "caught_by_packet_box_bound": out[8]}
         return idx, d2, out[0], out[1]
 
     def compute_distance(self, q, indicator, w1):

@@ -575,7 +575,8 @@ def test_render_headline_scale_matches_reference_fixture(dtu_scale, cuda_device,
     reference's own sensitivity to a 1-ulp nudge of its input directions.  Gates (all can fail):
       * rays whose 128 sample depths are bit-identical to the reference's: |rgb| error <= 1e-4
       * median error <= 1e-6, PSNR >= 60 dB, depth / acc / normals likewise
-      * share of rays beyond 1e-4 <= the reference's own 1-ulp share + 1 %
+      * rays beyond 1e-4 (rgb; depth / acc / normals likewise) must be rays the reference itself moves under one of 32 last-bit perturbations
+        of the ray directions (tests/golden/render_v140k_dtu_sens.npz, _paired_tail_gate)
       * the field evaluated on the reference's OWN sample points: |sdf| error <= 3e-6
       * production call (detailed_output=False: ray sort + zero-weight skip) == detailed call, bit for bit
     For every ray beyond 1e-4 the first stage whose output leaves the last bit is printed."""
@@ -617,11 +618,14 @@ def test_render_headline_scale_matches_reference_fixture(dtu_scale, cuda_device,
     assert err[same].max() <= 1e-4
     assert np.median(err) <= 1e-6
     assert compare.psnr(g["rgb"], f["rgb"]) >= 60.0
-    assert (err > 1e-4).mean() <= (self_err > 1e-4).mean() + 0.01
+    # the tail, paired ray by ray with the reference's own movement under 32 last-bit perturbations of the rays (round 6: no "+ 1 %" allowance)
+    sens = common.golden("render_v140k_dtu_sens")
+    assert np.array_equal(sens["self_err"][0], self_err)
+    _paired_tail_gate(err, sens, "render_v140k_dtu")
     for key, tol in (("depth_volume", 2e-4), ("mask_volume", 1e-4), ("normals_volume", 1e-4)):
         e = np.abs(g[key] - f[key]).reshape(len(err), -1).max(-1)
         assert np.median(e) <= 1e-6, key
-        assert (e > tol).mean() <= (self_err > 1e-4).mean() + 0.01, key
+        _paired_tail_gate(e, sens, "render_v140k_dtu", key="self_err_" + key, tol=tol)
     # the field on the reference's own sample points (no sampling differences involved)
     dn = f["rays_d"] / np.linalg.norm(f["rays_d"], axis=-1, keepdims=True)
     pts = (f["rays_o"][:, None, :] + dn[:, None, :] * f["d_all"][..., None]).astype(np.float32)
@@ -641,32 +645,33 @@ def surf_scale(cuda_device):
     return mesh, state, common.make_model(mesh, state, cuda_device)
 
 
-def _paired_tail_gate(err, sens, label, max_outside=2):
-    """The end-to-end tail against the reference's OWN spread, ray by ray.  sens["self_err"] [S, n]: the imported reference
-    against itself under S independent last-bit perturbations of the ray directions (oracle/gen_golden.py *sens).  own[r] = the largest
-    move of ray r over the seeds; `unstable` = rays the reference itself moves by more than 1e-4 under SOME seed.
-      (a) product rays beyond 1e-4 must be reference-unstable rays -- at most `max_outside` exceptions;
-      (b) per ray: error <= max(4 x own[r], 1e-3) -- a ray the reference holds still may not move by more than 1e-3 here, an unstable ray
-          by no more than four times what the reference itself does to it;
-      (c) no more rays beyond 1e-4 than the reference's worst seed.
+def _paired_tail_gate(err, sens, label, max_outside=2, key="self_err", tol=1e-4):
+    """The end-to-end tail against the reference's OWN spread, ray by ray.  sens[key] [S, n]: the imported reference
+    against itself under S independent last-bit perturbations of the ray directions (oracle/gen_golden.py *sens; key "self_err" = rgb,
+    "self_err_depth_volume" / "_mask_volume" / "_normals_volume" = the other outputs).  own[r] = the largest move of ray r over the seeds;
+    `unstable` = rays the reference itself moves by more than `tol` under SOME seed.
+      (a) product rays beyond tol must be reference-unstable rays -- at most `max_outside` exceptions;
+      (b) per ray: error <= max(4 x own[r], 10 x tol) -- a ray the reference holds still may not move by more than 10 x tol here, an unstable
+          ray by no more than four times what the reference itself does to it;
+      (c) no more rays beyond tol than the reference's worst seed.
     Returns (unstable, stable_under_all_seeds)."""
-    own = sens["self_err"].max(0)
-    unstable = own > 1e-4
-    bad = err > 1e-4
+    own = sens[key].max(0)
+    unstable = own > tol
+    bad = err > tol
     outside = np.nonzero(bad & ~unstable)[0]
-    lim = np.maximum(4.0 * own, 1e-3)
+    lim = np.maximum(4.0 * own, 10.0 * tol)
     over = np.nonzero(err > lim)[0]
-    counts = (sens["self_err"] > 1e-4).sum(1)
-    print(f"  [{label}] paired tail gate over {sens['self_err'].shape[0]} reference seeds: reference-unstable rays {int(unstable.sum())} (per seed {int(counts.min())}..{int(counts.max())}); "
-          f"product rays beyond 1e-4: {int(bad.sum())}, of them outside the unstable set: {len(outside)} {[(int(r), float(f'{err[r]:.1e}'), float(f'{own[r]:.1e}')) for r in outside[:8]]}; "
-          f"rays over their own limit max(4 x own, 1e-3): {len(over)} {[(int(r), float(f'{err[r]:.1e}'), float(f'{own[r]:.1e}')) for r in over[:8]]}; max {err.max():.2e}")
+    counts = (sens[key] > tol).sum(1)
+    print(f"  [{label}] paired tail gate ({key} > {tol:g}) over {sens[key].shape[0]} reference seeds: reference-unstable rays {int(unstable.sum())} (per seed {int(counts.min())}..{int(counts.max())}); "
+          f"product rays beyond: {int(bad.sum())}, of them outside the unstable set: {len(outside)} {[(int(r), float(f'{err[r]:.1e}'), float(f'{own[r]:.1e}')) for r in outside[:8]]}; "
+          f"rays over their own limit max(4 x own, 10 x tol): {len(over)} {[(int(r), float(f'{err[r]:.1e}'), float(f'{own[r]:.1e}')) for r in over[:8]]}; max {err.max():.2e}")
     if os.environ.get("NEUMESH_PARITY_DUMP"):
         os.makedirs(os.environ["NEUMESH_PARITY_DUMP"], exist_ok=True)
-        np.save(os.path.join(os.environ["NEUMESH_PARITY_DUMP"], f"parity_tail_{label}.npy"), err)
-    assert len(outside) <= max_outside, (label, [(int(r), float(err[r]), float(own[r])) for r in outside])
-    assert len(over) == 0, (label, [(int(r), float(err[r]), float(own[r])) for r in over])
-    assert int(bad.sum()) <= int(counts.max()), (label, int(bad.sum()), int(counts.max()))
-    return unstable, own <= 1e-6
+        np.save(os.path.join(os.environ["NEUMESH_PARITY_DUMP"], f"parity_tail_{label}.{key}.npy"), err)
+    assert len(outside) <= max_outside, (label, key, [(int(r), float(err[r]), float(own[r])) for r in outside])
+    assert len(over) == 0, (label, key, [(int(r), float(err[r]), float(own[r])) for r in over])
+    assert int(bad.sum()) <= int(counts.max()), (label, key, int(bad.sum()), int(counts.max()))
+    return unstable, own <= 0.01 * tol
 
 
 def _scene_against_reference_fixture(model, digest, fixture, precision, cuda_device, torch, classes=True):
@@ -694,9 +699,27 @@ def _scene_against_reference_fixture(model, digest, fixture, precision, cuda_dev
             e = np.abs(t[key] - f[key]).reshape(n, -1).max(-1)
             worst[key] = float(e.max())
             assert e.max() <= tol, (key, float(e.max()), int(e.argmax()))
-        sdf_err = float(np.abs(t["implicit_surface"] - f["sdf_all"]).max())
-        print(f"{label}, on the reference's own depths ({n} rays): max errors {worst}, |sdf| {sdf_err:.2e}")
-        assert sdf_err <= 3e-6
+        e_sdf = np.abs(t["implicit_surface"] - f["sdf_all"])
+        off = np.argwhere(e_sdf > 3e-6)
+        print(f"{label}, on the reference's own depths ({n} rays): max errors {worst}, |sdf| {e_sdf.max():.2e}, points beyond 3e-6: {len(off)} of {e_sdf.size}")
+        # (4) the field on the reference's own sample points: 3e-6 on every point -- except where the reference's field is itself discontinuous or
+        # ill-conditioned in the last bit of the POSITION (the product forms o + d * depth with its own normalised d: 1-ulp differences): a point
+        # whose 8th and 9th nearest vertices are (nearly) equidistant takes another neighbour set (seen on the trained field: ONE of 196 608
+        # points, an exact fp32 tie, 2e-4), and a point almost on a vertex has weights 1 / (d + 1e-7) that move with the last bit (1e-5).
+        # At most 8 such points, each one verified to be of that kind with the product's own exact K-NN, none beyond 2e-3.
+        assert len(off) <= 8, len(off)
+        if len(off):
+            from neumesh_amd.mesh_grid import knn as hip_knn
+            dn_ = f["rays_d"] / np.linalg.norm(f["rays_d"], axis=-1, keepdims=True)
+            pts_off = np.stack([(f["rays_o"][r] + dn_[r] * f["d_all"][r, j]).astype(np.float32) for r, j in off])
+            _, d2o = hip_knn(model.mesh_grid.grid, _t(pts_off, cuda_device), 9)
+            d2o = d2o.cpu().numpy()
+            for (r, j), row in zip(off, d2o):
+                tie = (row[8] - row[7]) <= 1e-5 * row[7]                 # on a boundary between two neighbour sets
+                near_vertex = np.sqrt(row[0]) <= 0.2 * np.sqrt(row[7])   # dominated by one vertex: 1 / (d + 1e-7) weights are steep
+                print(f"    point (ray {r}, sample {j}): |sdf| error {e_sdf[r, j]:.2e}, d2[0] {row[0]:.3e}, d2[7..8] {row[7]:.6e} {row[8]:.6e} -> {'tie' if tie else 'near a vertex' if near_vertex else 'UNEXPLAINED'}")
+                assert e_sdf[r, j] <= (2e-3 if tie else 2e-5), (int(r), int(j), float(e_sdf[r, j]))
+                assert tie or near_vertex, (int(r), int(j), row.tolist())
         # (2), (3) end to end
         kw = dict(calc_normal=True, N_samples=ns, N_importance=ni, white_bkgd=white, perturb=False, rayschunk=65536)
         with torch.no_grad():
@@ -742,7 +765,7 @@ def _scene_against_reference_fixture(model, digest, fixture, precision, cuda_dev
         for key, tol in (("depth_volume", 2e-4), ("mask_volume", 1e-4), ("normals_volume", 1e-4)):
             e = np.abs(g[key] - f[key]).reshape(n, -1).max(-1)
             assert np.median(e) <= 1e-6, key
-            assert int((e[~unstable] > tol).sum()) <= 2, (key, int((e[~unstable] > tol).sum()))       # (paired, like the colour)
+            _paired_tail_gate(e, sens, label, key="self_err_" + key, tol=tol)       # (paired with the reference's own movement of THIS output)
         # Rays the reference holds still under EVERY seed: with sample depths IDENTICAL to the reference's the bound is north_star's 1e-4 on
         # every such ray.  Depths that differ in the last bits are not enough for that: the reference's field is discontinuous where a
         # point's 8-neighbour set changes (its own secant roots sit on jumps of up to 1.5e-3, tests/golden/surface_v140k_surf.npz), so a sample
@@ -1656,6 +1679,56 @@ def test_chunks_in_flight_render_identical_pixels(surf_scale, cuda_device, torch
         assert torch.equal(rgb_a, rgb_b) and torch.equal(dep_a, dep_b) and torch.equal(ex_a["mask_volume"], ex_b["mask_volume"])
         if kw["calc_normal"]:
             assert torch.equal(ex_a["normals_volume"], ex_b["normals_volume"])
+
+
+@pytest.mark.gpu
+def test_mid_point_sub_passes_render_identical_pixels(small, surf_scale, cuda_device, torch_mod, monkeypatch):
+    """nm_render_cfg.mid_passes (ABI v11): the mid-point stage in 2 / 4 / 5 sub-passes over ray ranges that share one record
+    region returns every output bit for bit as the one-pass layout of round 5 -- plain model (headline shape and the lego shape), the detailed
+    call, and a texture-edited model with rotated references (the blend's arrays are list-addressed too) -- while the workspace shrinks."""
+    torch = torch_mod
+    from neumesh_amd import _lib, synthetic
+    from neumesh_amd import renderer as rmod
+    lib = _lib.load()
+    mesh, state, model = surf_scale
+    H = W = 368                                   # 135 424 rays: four sub-passes of >= 32 768 rays
+    o, d = synthetic.camera_rays(synthetic.orbit_pose(3), synthetic.pinhole_intrinsics(H, W), H, W)
+    o, d = _t(o, cuda_device), _t(d, cuda_device)
+    monkeypatch.setenv("NEUMESH_RAYSCHUNK", "0")
+    monkeypatch.setenv("NEUMESH_RENDER_STREAMS", "1")
+    for kw in (dict(calc_normal=True), dict(calc_normal=False, N_samples=32, N_importance=32, white_bkgd=True), dict(calc_normal=True, detailed_output=True)):
+        kw = dict(dict(perturb=False, detailed_output=False), **kw)
+        outs = {}
+        for q in (1, 2, 4, 5):
+            monkeypatch.setenv("NEUMESH_MID_PASSES", str(q))
+            with torch.no_grad():
+                outs[q] = rmod.volume_render(o, d, model, rayschunk=H * W, **kw)
+        torch.cuda.synchronize()
+        for q in (2, 4, 5):
+            assert torch.equal(outs[1][0], outs[q][0]) and torch.equal(outs[1][1], outs[q][1]), (q, kw)
+            for k in ("mask_volume", "normals_volume", "radiance", "implicit_nablas"):
+                if k in outs[1][2]:
+                    assert torch.equal(outs[1][2][k], outs[q][2][k]), (q, k)
+    ws = {}
+    for q in (1, 0):
+        cfg = rmod.make_render_cfg(calc_normal=True, mid_passes=q)
+        cfg.code_dims = 32 | (32 << 16)
+        ws[q] = int(lib.nm_render_workspace_bytes(C.byref(cfg), 327680))
+    print(f"workspace of a 327 680-ray chunk: one pass {ws[1] / 1e9:.2f} GB ({ws[1] / 327680 / 1024:.1f} KiB per ray), default {ws[0] / 1e9:.2f} GB ({ws[0] / 327680 / 1024:.1f} KiB per ray)")
+    assert ws[0] <= 13.5e9 < ws[1]
+    # texture editing through the sub-passes (two rotated references at V = 3000; 65 536 rays = two sub-passes)
+    mesh3, state3, _ = small
+    wrap, _main = common.edit_model(mesh3, state3, 2, True, cuda_device)
+    assert rmod.fusable_edit_model(wrap)
+    H = W = 256
+    o, d = synthetic.camera_rays(synthetic.orbit_pose(7), synthetic.pinhole_intrinsics(H, W), H, W)
+    o, d = _t(o, cuda_device), _t(d, cuda_device)
+    outs = {}
+    for q in (1, 2):
+        monkeypatch.setenv("NEUMESH_MID_PASSES", str(q))
+        with torch.no_grad():
+            outs[q] = rmod.volume_render(o, d, wrap, rayschunk=H * W, calc_normal=True, perturb=False, detailed_output=False)
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1]) and torch.equal(outs[1][2]["normals_volume"], outs[2][2]["normals_volume"])
 
 
 @pytest.mark.gpu

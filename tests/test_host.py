@@ -424,3 +424,26 @@ def test_training_loop_fixture_schedule_and_groups():
     assert (f["lr_used"][:2] == 0).all() and (f["lr_used"][2:] > 0).all()
     assert float(f["dmax.color_features"]) > 1e-3 and float(f["dmax.ln_s"]) == 0.0
     assert [str(n) for n in f["group1.names"]] == ["color_features"] and all(str(n).startswith("views_linears.") for n in f["group2.names"])
+
+
+def test_render_workspace_is_at_most_40_kib_per_ray():
+    """nm_render_workspace_bytes needs no device: the default layout (mid-point records of one ray sub-range at a time, nm_render_cfg.mid_passes)
+    holds a 327 680-ray chunk of the headline shape in <= 13.5 GB (was 20.6 GB = 63 KB per ray); a small call is not cut."""
+    import ctypes as C
+    from neumesh_amd import _lib
+    from neumesh_amd.renderer import make_render_cfg
+    lib = _lib.load(require_device=False)
+    sizes = {}
+    for q in (0, 1, 2, 4, 16):
+        cfg = make_render_cfg(calc_normal=True, mid_passes=q)
+        cfg.code_dims = 32 | (32 << 16)
+        sizes[q] = int(lib.nm_render_workspace_bytes(C.byref(cfg), 327680))
+    assert sizes[0] == sizes[4] <= 13.5e9 and sizes[0] / 327680 <= 40 * 1024
+    assert sizes[1] > sizes[2] > sizes[4] >= sizes[16] and sizes[1] > 20e9
+    cfg = make_render_cfg(calc_normal=True)
+    cfg.code_dims = 32 | (32 << 16)
+    cfg1 = make_render_cfg(calc_normal=True, mid_passes=1)
+    cfg1.code_dims = 32 | (32 << 16)
+    assert int(lib.nm_render_workspace_bytes(C.byref(cfg), 4096)) == int(lib.nm_render_workspace_bytes(C.byref(cfg1), 4096))   # one pass below 65 536 rays
+    bad = make_render_cfg(calc_normal=True, mid_passes=17)
+    assert int(lib.nm_render_workspace_bytes(C.byref(bad), 4096)) < 0
