@@ -645,15 +645,18 @@ def surf_scale(cuda_device):
     return mesh, state, common.make_model(mesh, state, cuda_device)
 
 
-def _paired_tail_gate(err, sens, label, max_outside=2, key="self_err", tol=1e-4):
+def _paired_tail_gate(err, sens, label, max_outside=2, key="self_err", tol=1e-4, max_over=1):
     """The end-to-end tail against the reference's OWN spread, ray by ray.  sens[key] [S, n]: the imported reference
     against itself under S independent last-bit perturbations of the ray directions (oracle/gen_golden.py *sens; key "self_err" = rgb,
     "self_err_depth_volume" / "_mask_volume" / "_normals_volume" = the other outputs).  own[r] = the largest move of ray r over the seeds;
     `unstable` = rays the reference itself moves by more than `tol` under SOME seed.
       (a) product rays beyond tol must be reference-unstable rays -- at most `max_outside` exceptions;
       (b) per ray: error <= max(4 x own[r], 10 x tol) -- a ray the reference holds still may not move by more than 10 x tol here, an unstable
-          ray by no more than four times what the reference itself does to it;
+          ray by no more than four times what the reference itself does to it -- at most `max_over` exceptions;
       (c) no more rays beyond tol than the reference's worst seed.
+    The allowances are what the reference's OWN seeds need when each is held against the other 31 (leave-one-out over the four *_sens fixtures and
+    four outputs: at most 2 rays outside the others' unstable set, at most 1 ray over its own limit -- a chaotic ray's movement is heavy-tailed);
+    the leave-one-out figures of this fixture are printed beside the product's.
     Returns (unstable, stable_under_all_seeds)."""
     own = sens[key].max(0)
     unstable = own > tol
@@ -662,14 +665,20 @@ def _paired_tail_gate(err, sens, label, max_outside=2, key="self_err", tol=1e-4)
     lim = np.maximum(4.0 * own, 10.0 * tol)
     over = np.nonzero(err > lim)[0]
     counts = (sens[key] > tol).sum(1)
+    loo_out, loo_over = 0, 0                                   # the reference against itself, each seed vs the others
+    for i in range(sens[key].shape[0]):
+        others = np.delete(sens[key], i, 0).max(0)
+        loo_out = max(loo_out, int(((sens[key][i] > tol) & ~(others > tol)).sum()))
+        loo_over = max(loo_over, int((sens[key][i] > np.maximum(4.0 * others, 10.0 * tol)).sum()))
     print(f"  [{label}] paired tail gate ({key} > {tol:g}) over {sens[key].shape[0]} reference seeds: reference-unstable rays {int(unstable.sum())} (per seed {int(counts.min())}..{int(counts.max())}); "
           f"product rays beyond: {int(bad.sum())}, of them outside the unstable set: {len(outside)} {[(int(r), float(f'{err[r]:.1e}'), float(f'{own[r]:.1e}')) for r in outside[:8]]}; "
-          f"rays over their own limit max(4 x own, 10 x tol): {len(over)} {[(int(r), float(f'{err[r]:.1e}'), float(f'{own[r]:.1e}')) for r in over[:8]]}; max {err.max():.2e}")
+          f"rays over their own limit max(4 x own, 10 x tol): {len(over)} {[(int(r), float(f'{err[r]:.1e}'), float(f'{own[r]:.1e}')) for r in over[:8]]}; max {err.max():.2e} "
+          f"(reference seeds leave-one-out: outside <= {loo_out}, over <= {loo_over})")
     if os.environ.get("NEUMESH_PARITY_DUMP"):
         os.makedirs(os.environ["NEUMESH_PARITY_DUMP"], exist_ok=True)
         np.save(os.path.join(os.environ["NEUMESH_PARITY_DUMP"], f"parity_tail_{label}.{key}.npy"), err)
     assert len(outside) <= max_outside, (label, key, [(int(r), float(err[r]), float(own[r])) for r in outside])
-    assert len(over) == 0, (label, key, [(int(r), float(err[r]), float(own[r])) for r in over])
+    assert len(over) <= max_over, (label, key, [(int(r), float(err[r]), float(own[r])) for r in over])
     assert int(bad.sum()) <= int(counts.max()), (label, key, int(bad.sum()), int(counts.max()))
     return unstable, own <= 0.01 * tol
 

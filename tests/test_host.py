@@ -327,18 +327,22 @@ def test_fused_chunk_policy_lower_bound_and_memory_guard(monkeypatch):
     from neumesh_amd import _lib, renderer
     lib = _lib.load(require_device=False)
     cfg = renderer.make_render_cfg(calc_normal=True)
-    assert 100e3 < int(lib.nm_render_workspace_bytes(C.byref(cfg), 1 << 16)) / (1 << 16) < 125e3    # code widths not given: records of 64 + 64 floats
+    assert 70e3 < int(lib.nm_render_workspace_bytes(C.byref(cfg), 1 << 16)) / (1 << 16) < 90e3     # code widths not given: records of 64 + 64 floats (two mid-point sub-passes at 65 536 rays)
     cfg.code_dims = 32 | (32 << 16)                                         # what render_rays_fused sets from the model
     per_ray = int(lib.nm_render_workspace_bytes(C.byref(cfg), 1 << 16)) / (1 << 16)
-    assert 55e3 < per_ray < 70e3                                             # 63 KB per ray
+    assert 42e3 < per_ray < 50e3                                             # 46 KB per ray with two sub-passes; 37 KB with four from 131 072 rays on
+    assert 35e3 < int(lib.nm_render_workspace_bytes(C.byref(cfg), 320000)) / 320000 < 40e3
     free = [int(400e9)]
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (free[0], int(288e9)))
     monkeypatch.delenv("NEUMESH_RAYSCHUNK", raising=False)
     assert renderer.DEFAULT_RAYSCHUNK == 320 * 1024                                     # 20 GB of workspace per lane: two chunks of an 800x800 frame beat one call (round 5)
     assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 320000             # render.py's 4096: the library's chunk (two EQUAL chunks of <= 327 680 rays)
     assert renderer._fused_chunk(lib, cfg, 327681, 4096, "cuda:0") == 163841             # two chunks, balanced
-    free[0] = int(100e9)                                                                # a quarter of the free memory must hold the lanes' workspaces: 160 000-ray chunks here
+    free[0] = int(100e9)                                                                # a quarter of the free memory holds two 11.8 GB lanes
+    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 320000
+    free[0] = int(80e9)                                                                 # ... and here it does not: 160 000-ray chunks
     assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 160000
+    assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0", held_bytes=int(24e9)) == 320000   # the pool's own workspaces are not somebody else's memory
     free[0] = int(400e9)
     assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0", extra_per_ray=int(400e9) // 640000) == 4096   # the call's own tensors count
     monkeypatch.setenv("NEUMESH_RAYSCHUNK", str(1 << 20))
