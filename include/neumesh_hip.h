@@ -219,7 +219,7 @@ typedef struct nm_render_cfg {
                                     positions of sample_pdf(det=False) (rend_util.py:300-302), rows in the CALLER's ray order */
     int32_t mid_passes;          /* ABI v11: the mid-point stage (K-NN records, value + tangent MLP, colour MLP, texture blend) runs in this many
                                     sub-passes over contiguous ray ranges that share one record region: the workspace shrinks from 63 to
-                                    (28 + 35 / mid_passes) KB per ray at 32 + 32-d codes.  0 = default (4); 1 = one pass (the round-5 layout);
+                                    (28 + 35 / mid_passes) KB per ray at 32 + 32-d codes.  0 = default (3); 1 = one pass (the round-5 layout);
                                     at most 16; fewer are used while a sub-pass would hold fewer than 32 768 rays.  No result bit changes. */
     /* (ABI v11: the v10 fields overlap / knn_keep / mlp_prio -- K-NN kernels yielding to other chunks' MLP kernels -- are gone: the mode was
        measured 5-15 % slower in every variant, profiles/r05_overlap_sweep.txt) */

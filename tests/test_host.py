@@ -330,15 +330,15 @@ def test_fused_chunk_policy_lower_bound_and_memory_guard(monkeypatch):
     assert 70e3 < int(lib.nm_render_workspace_bytes(C.byref(cfg), 1 << 16)) / (1 << 16) < 90e3     # code widths not given: records of 64 + 64 floats (two mid-point sub-passes at 65 536 rays)
     cfg.code_dims = 32 | (32 << 16)                                         # what render_rays_fused sets from the model
     per_ray = int(lib.nm_render_workspace_bytes(C.byref(cfg), 1 << 16)) / (1 << 16)
-    assert 42e3 < per_ray < 50e3                                             # 46 KB per ray with two sub-passes; 37 KB with four from 131 072 rays on
-    assert 35e3 < int(lib.nm_render_workspace_bytes(C.byref(cfg), 320000)) / 320000 < 40e3
+    assert 42e3 < per_ray < 50e3                                             # 46 KB per ray with two sub-passes; 40 KB with three from 98 304 rays on
+    assert 38e3 < int(lib.nm_render_workspace_bytes(C.byref(cfg), 320000)) / 320000 < 41e3
     free = [int(400e9)]
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (free[0], int(288e9)))
     monkeypatch.delenv("NEUMESH_RAYSCHUNK", raising=False)
     assert renderer.DEFAULT_RAYSCHUNK == 320 * 1024                                     # 20 GB of workspace per lane: two chunks of an 800x800 frame beat one call (round 5)
     assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 320000             # render.py's 4096: the library's chunk (two EQUAL chunks of <= 327 680 rays)
     assert renderer._fused_chunk(lib, cfg, 327681, 4096, "cuda:0") == 163841             # two chunks, balanced
-    free[0] = int(100e9)                                                                # a quarter of the free memory holds two 11.8 GB lanes
+    free[0] = int(110e9)                                                                # a quarter of the free memory holds two 12.7 GB lanes
     assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 320000
     free[0] = int(80e9)                                                                 # ... and here it does not: 160 000-ray chunks
     assert renderer._fused_chunk(lib, cfg, 640000, 4096, "cuda:0") == 160000
@@ -442,7 +442,7 @@ def test_render_workspace_is_at_most_40_kib_per_ray():
         cfg = make_render_cfg(calc_normal=True, mid_passes=q)
         cfg.code_dims = 32 | (32 << 16)
         sizes[q] = int(lib.nm_render_workspace_bytes(C.byref(cfg), 327680))
-    assert sizes[0] == sizes[4] <= 13.5e9 and sizes[0] / 327680 <= 40 * 1024
+    assert sizes[4] < sizes[0] <= 13.5e9 and sizes[0] / 327680 <= 40 * 1024
     assert sizes[1] > sizes[2] > sizes[4] >= sizes[16] and sizes[1] > 20e9
     cfg = make_render_cfg(calc_normal=True)
     cfg.code_dims = 32 | (32 << 16)
