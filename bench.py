@@ -58,7 +58,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/FP16 MFMA ~2.5 PF de
 PEAK_HBM_GBS = 8000.0
 NOMINAL_CLOCK_MHZ = 2400.0      # the clock the dense MFMA peaks above are quoted at
 KNN_BYTES_PER_QUERY = 76    # 12 in + 8*4 idx + 8*4 w  
-PROFILE_TAG, PROFILE_TAG_PREVIOUS = "r05", "r04"          # profiles/<tag>_pmc_*.json: rocprofv3 --pmc passes of this command (tools/pmc_*.py)
+PROFILE_TAG, PROFILE_TAG_PREVIOUS = "r06", "r05"          # profiles/<tag>_pmc_*.json: rocprofv3 --pmc passes of this command (tools/pmc_*.py)
 
 MODEL_CFG = dict(D_density=3, D_color=4, W=256, geometry_dim=32, color_dim=32, multires_view=4, multires_d=8,
                  multires_fg=2, multires_ft=2, enable_nablas_input=True, speed_factor=10.0, learn_indicator_weight=False)

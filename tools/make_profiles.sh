@@ -1,8 +1,8 @@
 #!/bin/bash
 # tools/make_profiles.sh <dir written by tools/profile_round.sh> <tag>: the summaries committed under profiles/
 set -eu
-[ -s "${1:-gpurun_out/r05_prof}/bench_default.json" ] || { echo "no bench_default.json in ${1:-gpurun_out/r05_prof}: profiles/ left untouched"; exit 1; }
-P=${1:-gpurun_out/r05_prof}; T=${2:-r05}
+[ -s "${1:-gpurun_out/r06_prof}/bench_default.json" ] || { echo "no bench_default.json in ${1:-gpurun_out/r06_prof}: profiles/ left untouched"; exit 1; }
+P=${1:-gpurun_out/r06_prof}; T=${2:-r06}
 f() { find $P/$1 -name "*counter_collection.csv" | head -1; }
 python tools/pmc_report.py calib $(f cfetch) $(f cwrite) > profiles/${T}_pmc_calibration.json
 python tools/pmc_report.py traffic $(f fetch) $(f write) profiles/${T}_pmc_calibration.json > profiles/${T}_pmc_traffic.json

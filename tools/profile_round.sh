@@ -2,7 +2,7 @@
 # tools/profile_round.sh <out_dir>: every rocprofv3 pass behind profiles/rNN_* (run on the GPU box through gpurun).
 # Counters are collected in their own runs (no trace domains next to --pmc).
 set -u
-OUT=${1:-gpurun_out/r05_prof}
+OUT=${1:-gpurun_out/r06_prof}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 BENCH="python bench.py --steps 2 --warmup 1 --no-extras --cpu-rays 0"
