@@ -928,7 +928,12 @@ def main():
                 del model2
             except Exception as ex:
                 extra["other_scene"] = {"error": str(ex)}
-            try:   # the TRAINED field (round 6): same shape on tests/golden/trained_v140k.pt, with its parity against the imported reference's render
+            model.mlp_precision = args.mlp_precision
+            extra.update(consumer_rows(mesh, model, dev, args.H, args.W))
+            for k_, v_ in extra.items():
+                if k_.startswith("train_step") and "ms_per_step" in v_:
+                    cfgd["train_step_ms_512_rays"], cfgd["train_step_ms_512_rays_torch_autograd_field"] = v_["ms_per_step"], v_.get("ms_per_step_torch_autograd_field")
+            try:   # the TRAINED field (round 6; after the consumer rows: a 37 MB checkpoint load in this process was followed by a 2.4x slower training-step row): same shape on tests/golden/trained_v140k.pt, with its parity against the imported reference's render
                    # of these very rays and whether the call tripped the fp16-range flag (it would have fallen back to the fp32 kernels)
                 if args.V == 140_000 and args.scene != "trained":
                     _, model3 = build_scene(args.V, dev, scene="trained")
@@ -947,11 +952,6 @@ def main():
                     del model3
             except Exception as ex:
                 extra["trained_scene"] = {"error": str(ex)[-300:]}
-            model.mlp_precision = args.mlp_precision
-            extra.update(consumer_rows(mesh, model, dev, args.H, args.W))
-            for k_, v_ in extra.items():
-                if k_.startswith("train_step") and "ms_per_step" in v_:
-                    cfgd["train_step_ms_512_rays"], cfgd["train_step_ms_512_rays_torch_autograd_field"] = v_["ms_per_step"], v_.get("ms_per_step_torch_autograd_field")
         if world == 1 and args.cpu_rays > 0:
             try:
                 r0 = (rays0[0].cpu().numpy(), rays0[1].cpu().numpy())
