@@ -648,9 +648,16 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
         cst_v[NM_H2_BIAS_LAYERS] = prm.wd[threadIdx.x];
     }
     nm_phase_stamp(11);
+#ifdef NM_TESTING_INPUT_STAMPS   // (measurement build only: stamp 13 = the record loads have arrived; 14 = first task round embedded; 8 = all rounds)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    nm_phase_stamp(13);
+#endif
     float mx = 0.f;
 #pragma unroll
     for (int rd = 0; rd < ROUNDS; ++rd) {
+#ifdef NM_TESTING_INPUT_STAMPS
+        if (rd == 1) nm_phase_stamp(14);
+#endif
         const int task = threadIdx.x + rd * NM_H_THREADS;
         const int p = task >> 3, j = task & 7;
         const long long q = base + p;
@@ -691,6 +698,9 @@ __global__ __launch_bounds__(NM_H_THREADS, NM_H_WAVES_PER_SIMD) void nm_geo_mlp_
                 trow[NM_H_PLANE + c] = (_Float16)0.0f;
             }
     }
+#ifdef NM_TESTING_INPUT_STAMPS
+    nm_phase_stamp(8);
+#endif
 #pragma unroll
     for (int l = 0; l <= NM_H2_BIAS_LAYERS; ++l) cst[l * NM_W + threadIdx.x] = cst_v[l];
     nm_phase_stamp(12);

@@ -30,6 +30,6 @@ for which in (1, 2, 3):
     d = np.diff(a[:, used], axis=1)
     print(names[which], "ms", round(ms.value, 3), "stamps", used)
     print("   median cycles per phase:", np.median(d, axis=0).astype(int).tolist(), " total", int(np.median(a[:, used[-1]] - a[:, used[0]])))
-    fine = [c for c in (0, 8, 9, 10, 11, 12, 13, 1) if a[:, c].min() > 0]
+    fine = [c for c in ((0, 10, 11, 13, 14, 8, 12, 1) if which != 3 else (0, 8, 9, 10, 11, 12, 13, 1)) if a[:, c].min() > 0]   # (13 / 14 / 8: -DNM_TESTING_INPUT_STAMPS builds)
     if len(fine) > 2:
         print("   prologue stamps", fine, "median offsets from start:", np.median(a[:, fine] - a[:, [0]], axis=0).astype(int).tolist())
