@@ -295,6 +295,7 @@ class NeuMesh(nn.Module):
         self._field_epoch = 0     # bumped by invalidate_field()
         self._range_checked = False
         self._range_pending = []  # deferred fp16-range reads: (event, pinned host word) per fused call that returned without a sync
+        self._range_words = None  # 64 pinned int32 words handed out in rotation (allocated at the first deferred read)
         # With autograd enabled (training): "hip" = forward AND backward on the HIP library (_HipField: nm_train_forward /
         # nm_train_backward, closed-form reverse pass); "recompute" = fused HIP forward + a backward that re-evaluates the
         # torch-op restatement (_FusedField); "torch" = the torch-op restatement end to end.  Same gradients.
@@ -386,7 +387,7 @@ class NeuMesh(nn.Module):
         replica = super()._replicate_for_data_parallel()
         replica._field, replica._field_key, replica._field_dev = None, None, None
         replica._scalars_key, replica._keep, replica._range_checked = None, None, False
-        replica._range_pending = []
+        replica._range_pending, replica._range_words = [], None      # (its own pinned words: replicas run on their own threads)
         replica._is_replica = True
         return replica
 
@@ -437,7 +438,7 @@ class NeuMesh(nn.Module):
         if self.mlp_precision == "fp32" or self._field is None:
             return
         lib = _lib.load()
-        if getattr(self, "_range_words", None) is None:
+        if self._range_words is None:
             self._range_words, self._range_slot = torch.zeros(64, dtype=torch.int32).pin_memory(), 0   # one pinned allocation per model, 64 words in rotation
         if len(self._range_pending) >= 48:    # a caller that never comes back to poll: read what is ready, wait for the oldest if none is
             self.poll_fp16_range(wait_oldest=len(self._range_pending) >= 63)
