@@ -451,3 +451,35 @@ def test_render_workspace_is_at_most_40_kib_per_ray():
     assert int(lib.nm_render_workspace_bytes(C.byref(cfg), 4096)) == int(lib.nm_render_workspace_bytes(C.byref(cfg1), 4096))   # one pass below 65 536 rays
     bad = make_render_cfg(calc_normal=True, mid_passes=17)
     assert int(lib.nm_render_workspace_bytes(C.byref(bad), 4096)) < 0
+
+
+def test_trained_checkpoint_is_the_one_the_fixture_was_rendered_from():
+    """tests/golden/trained_v140k.pt (tools/train_field.py; utils/checkpoints.py layout) loads strictly into the product's module tree -- the
+    keys / shapes a reference `render.py --load_pt` run would find (render.py:287-288) -- and is bit for bit the file render_v140k_trained.npz and
+    its 32-seed sensitivity were generated from (sha256 over every tensor); the field it holds is a trained one (s = 1000, weight-norm gains
+    moved off the row norms, codes no longer N(0, 1))."""
+    torch = pytest.importorskip("torch")
+    from neumesh_amd.neumesh import NeuMesh
+    ck = torch.load(os.path.join(common.GOLDEN, "trained_v140k.pt"), map_location="cpu")
+    assert set(ck) >= {"model", "global_step"} and int(ck["global_step"]) == 20000
+    st = common.trained_state()
+    f, sens = common.golden("render_v140k_trained"), common.golden("render_v140k_trained_sens")
+    digest = common.state_digest(st)
+    assert str(f["state_sha256"]) == digest and str(sens["state_sha256"]) == digest
+    assert sens["self_err"].shape == (32, 1536) and np.array_equal(sens["self_err"][0], f["self_err_1ulp"])
+
+    class FakeGrid:
+        def get_number_of_vertices(self):
+            return 140000
+
+        def get_vertex_normal_torch(self):
+            return torch.zeros(140000, 3)
+
+    m = NeuMesh(FakeGrid(), **common.MODEL_CFG)
+    res = m.load_state_dict(ck["model"], strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert abs(float(m.forward_s()) - 1000.0) < 1.0 and abs(float(f["s"]) - 1000.0) < 1.0
+    v, g = st["pts_linears.2.0.weight_v"], st["pts_linears.2.0.weight_g"]
+    assert np.abs(g[:, 0] / np.linalg.norm(v, axis=1) - 1.0).max() > 0.05          # trained: g is no longer |v|
+    untrained = common.scene_state(common.scene_mesh(140000))
+    assert float(np.abs(st["color_features"] - untrained["color_features"]).mean()) > 1e-3
