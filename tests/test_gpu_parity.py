@@ -1721,6 +1721,16 @@ def test_mid_point_sub_passes_render_identical_pixels(small, surf_scale, cuda_de
             for k in ("mask_volume", "normals_volume", "radiance", "implicit_nablas"):
                 if k in outs[1][2]:
                     assert torch.equal(outs[1][2][k], outs[q][2][k]), (q, k)
+    # a ragged ray count (70 225 rays: two sub-passes of 35 136 and 35 089 rays, the last depth-bucket group partly filled)
+    Hr = Wr = 265
+    o2, d2 = synthetic.camera_rays(synthetic.orbit_pose(9), synthetic.pinhole_intrinsics(Hr, Wr), Hr, Wr)
+    o2, d2 = _t(o2, cuda_device), _t(d2, cuda_device)
+    outs = {}
+    for q in (1, 2):
+        monkeypatch.setenv("NEUMESH_MID_PASSES", str(q))
+        with torch.no_grad():
+            outs[q] = rmod.volume_render(o2, d2, model, rayschunk=Hr * Wr, calc_normal=True, perturb=False, detailed_output=False)
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1]) and torch.equal(outs[1][2]["normals_volume"], outs[2][2]["normals_volume"])
     ws = {}
     for q in (1, 0):
         cfg = rmod.make_render_cfg(calc_normal=True, mid_passes=q)
