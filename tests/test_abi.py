@@ -45,6 +45,14 @@ def test_product_library_has_no_test_hooks():
     for n in _lib.TESTING_SIGNATURES:
         assert hasattr(tlib, n) and n not in exported
     assert "tests/_build" in build.TESTING_LIB_PATH
+    # round 6: the K-NN-under-MLP experiment is gone from BOTH builds -- no pull-form kernels, yield state or co-residency hooks
+    for path in (build.build(), build.build_testing()):
+        syms = subprocess.run(["nm", "-D", path], capture_output=True, text=True).stdout + subprocess.run(["strings", path], capture_output=True, text=True).stdout
+        for gone in ("nm_debug_knn_pull", "nm_debug_yield_add", "nm_debug_simd_keys", "nm_distance_pull_kernel", "nm_probe_bounds_pull_kernel", "nm_knn_pull_kernel", "nm_yield_add_kernel"):
+            assert gone not in syms, (path, gone)
+    import inspect
+    from neumesh_amd import renderer
+    assert not any(f[0] in ("overlap", "knn_keep", "mlp_prio") for f in _lib.RenderCfg._fields_) and "NEUMESH_OVERLAP" not in inspect.getsource(renderer)
 
 
 def test_abi_version_and_error_string():
