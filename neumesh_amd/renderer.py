@@ -846,3 +846,15 @@ class SingleRenderer(nn.Module):
 
     def forward(self, rays_o, rays_d, **kwargs):
         return volume_render(rays_o, rays_d, self.model, **kwargs)
+
+    def synchronize(self) -> bool:
+        """Not part of the reference's class: wait for every render issued so far (calls return while their kernels run) and
+        report whether all of them stayed inside the fp16 range of the split-half kernels (False: a RuntimeWarning named the affected calls and
+        the model now runs the fp32 kernels -- render those frames again)."""
+        models = [self.model] if isinstance(self.model, NeuMesh) else [m for m in self.model.modules() if isinstance(m, NeuMesh)]
+        ok = True
+        for m in models:
+            ok = m.synchronize_fp16_range() and ok
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        return ok

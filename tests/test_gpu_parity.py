@@ -1837,6 +1837,9 @@ def test_render_call_returns_without_host_sync_and_reports_a_late_overflow(small
         still_running = not torch.cuda.current_stream(cuda_device).query()
         assert len(model._range_pending) == 1
         assert model.synchronize_fp16_range() and not model._range_pending
+        rgb1b, _, _ = rmod.SingleRenderer(model)(o[None], d[None], batched=True, **kw)
+        assert len(model._range_pending) == 1 and rmod.SingleRenderer(model).synchronize() and not model._range_pending
+        assert torch.equal(rgb1b[0], rgb1)
     assert still_running, "the deferred call returned only after its kernels had finished"
     assert torch.equal(rgb0, rgb1) and model.mlp_precision == common.DEFAULT_PRECISION
     with torch.no_grad():
